@@ -1,0 +1,155 @@
+// G1 group law (y^2 = x^3 + b, a = 0) in Jacobian coordinates, complete (every exceptional case
+// is handled so results are the exact group elements the reference's ark-ec `Projective` produces,
+// for any on-curve inputs, identity included).  Z == 0 encodes the identity.
+//
+// Reference call sites: every `generators[i] * scalar`, `b + ..`, `d * r - a_bar * e` in
+// /root/reference/src/sign.rs:120-130, verify.rs:81-86, proof_gen.rs:249-263,
+// proof_verify.rs:163-182.
+#pragma once
+#include "tower.hpp"
+
+namespace bbs {
+
+#define FP typename C::FpP
+
+template <class C>
+struct G1Aff {        // (0,0) encodes the identity (not on either curve: b != 0)
+    Fp<C> x, y;
+};
+
+template <class C>
+struct G1Jac {
+    Fp<C> x, y, z;
+};
+
+template <class C> BBS_HD bool g1a_is_inf(const G1Aff<C>& p) { return fe_is_zero<FP>(p.x) & fe_is_zero<FP>(p.y); }
+template <class C> BBS_HD bool g1j_is_inf(const G1Jac<C>& p) { return fe_is_zero<FP>(p.z); }
+template <class C> BBS_HD G1Jac<C> g1j_inf() { return {fe_one<FP>(), fe_one<FP>(), fe_zero<FP>()}; }
+template <class C> BBS_HD G1Aff<C> g1a_inf() { return {fe_zero<FP>(), fe_zero<FP>()}; }
+template <class C> BBS_HD G1Aff<C> g1a_neg(const G1Aff<C>& p) { return {p.x, fe_neg<FP>(p.y)}; }
+template <class C> BBS_HD G1Jac<C> g1j_neg(const G1Jac<C>& p) { return {p.x, fe_neg<FP>(p.y), p.z}; }
+
+template <class C>
+BBS_HD G1Jac<C> g1j_from_aff(const G1Aff<C>& p) {
+    if (g1a_is_inf<C>(p)) return g1j_inf<C>();
+    return {p.x, p.y, fe_one<FP>()};
+}
+
+template <class C>
+BBS_HD Fp<C> curve_b() {
+    Fp<C> b;
+#pragma unroll
+    for (int i = 0; i < C::FpP::N; i++) b.v[i] = C::K::B_M[i];
+    return b;
+}
+
+template <class C>
+BBS_HD bool g1a_on_curve(const G1Aff<C>& p) {
+    if (g1a_is_inf<C>(p)) return true;
+    Fp<C> lhs = fe_sqr<FP>(p.y);
+    Fp<C> rhs = fe_add<FP>(fe_mul<FP>(fe_sqr<FP>(p.x), p.x), curve_b<C>());
+    return fe_eq<FP>(lhs, rhs);
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
+    // identity (Z=0) maps to Z3 = 2*Y*0 = 0 : stays the identity.  Y = 0 cannot happen on
+    // these curves (no point of order 2: x^3 = -b has no root in Fp for b = 4 / b = 3).
+    Fp<C> A = fe_sqr<FP>(p.x);
+    Fp<C> B = fe_sqr<FP>(p.y);
+    Fp<C> Cc = fe_sqr<FP>(B);
+    Fp<C> t = fe_add<FP>(p.x, B);
+    Fp<C> D = fe_dbl<FP>(fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(t), A), Cc));
+    Fp<C> E = fe_add<FP>(fe_dbl<FP>(A), A);
+    Fp<C> F = fe_sqr<FP>(E);
+    G1Jac<C> r;
+    r.x = fe_sub<FP>(F, fe_dbl<FP>(D));
+    Fp<C> c8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(Cc)));
+    r.y = fe_sub<FP>(fe_mul<FP>(E, fe_sub<FP>(D, r.x)), c8);
+    r.z = fe_dbl<FP>(fe_mul<FP>(p.y, p.z));
+    return r;
+}
+
+// madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases resolved
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
+    if (g1a_is_inf<C>(q)) return p;
+    if (g1j_is_inf<C>(p)) return {q.x, q.y, fe_one<FP>()};
+    Fp<C> Z1Z1 = fe_sqr<FP>(p.z);
+    Fp<C> U2 = fe_mul<FP>(q.x, Z1Z1);
+    Fp<C> S2 = fe_mul<FP>(fe_mul<FP>(q.y, p.z), Z1Z1);
+    Fp<C> H = fe_sub<FP>(U2, p.x);
+    Fp<C> rr = fe_sub<FP>(S2, p.y);
+    if (fe_is_zero<FP>(H)) {
+        if (fe_is_zero<FP>(rr)) return g1j_dbl<C>(p);
+        return g1j_inf<C>();
+    }
+    rr = fe_dbl<FP>(rr);
+    Fp<C> HH = fe_sqr<FP>(H);
+    Fp<C> I = fe_dbl<FP>(fe_dbl<FP>(HH));
+    Fp<C> J = fe_mul<FP>(H, I);
+    Fp<C> V = fe_mul<FP>(p.x, I);
+    G1Jac<C> r;
+    r.x = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(rr), J), fe_dbl<FP>(V));
+    r.y = fe_sub<FP>(fe_mul<FP>(rr, fe_sub<FP>(V, r.x)), fe_dbl<FP>(fe_mul<FP>(p.y, J)));
+    r.z = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(fe_add<FP>(p.z, H)), Z1Z1), HH);
+    return r;
+}
+
+// add-2007-bl: Jacobian + Jacobian, 11M + 5S, with the exceptional cases resolved
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1j_add(const G1Jac<C>& p, const G1Jac<C>& q) {
+    if (g1j_is_inf<C>(q)) return p;
+    if (g1j_is_inf<C>(p)) return q;
+    Fp<C> Z1Z1 = fe_sqr<FP>(p.z);
+    Fp<C> Z2Z2 = fe_sqr<FP>(q.z);
+    Fp<C> U1 = fe_mul<FP>(p.x, Z2Z2);
+    Fp<C> U2 = fe_mul<FP>(q.x, Z1Z1);
+    Fp<C> S1 = fe_mul<FP>(fe_mul<FP>(p.y, q.z), Z2Z2);
+    Fp<C> S2 = fe_mul<FP>(fe_mul<FP>(q.y, p.z), Z1Z1);
+    Fp<C> H = fe_sub<FP>(U2, U1);
+    Fp<C> rr = fe_sub<FP>(S2, S1);
+    if (fe_is_zero<FP>(H)) {
+        if (fe_is_zero<FP>(rr)) return g1j_dbl<C>(p);
+        return g1j_inf<C>();
+    }
+    rr = fe_dbl<FP>(rr);
+    Fp<C> I = fe_sqr<FP>(fe_dbl<FP>(H));
+    Fp<C> J = fe_mul<FP>(H, I);
+    Fp<C> V = fe_mul<FP>(U1, I);
+    G1Jac<C> r;
+    r.x = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(rr), J), fe_dbl<FP>(V));
+    r.y = fe_sub<FP>(fe_mul<FP>(rr, fe_sub<FP>(V, r.x)), fe_dbl<FP>(fe_mul<FP>(S1, J)));
+    r.z = fe_mul<FP>(fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(fe_add<FP>(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+
+template <class C>
+BBS_HD_NOINLINE G1Aff<C> g1j_to_aff(const G1Jac<C>& p) {
+    if (g1j_is_inf<C>(p)) return g1a_inf<C>();
+    Fp<C> zi = fe_inv<FP>(p.z);
+    Fp<C> zi2 = fe_sqr<FP>(zi);
+    return {fe_mul<FP>(p.x, zi2), fe_mul<FP>(fe_mul<FP>(p.y, zi2), zi)};
+}
+
+// bit i of a canonical (non-Montgomery) scalar held as N 32-bit limbs
+template <int N>
+BBS_HD uint32_t limb_bit(const uint32_t* s, int i) {
+    return (s[i >> 5] >> (i & 31)) & 1u;
+}
+
+// k * P for an affine P and a canonical 256-bit scalar: plain MSB-first double-and-add with mixed
+// additions (the group element equals ark-ec's `Projective::mul_bigint` result).
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
+    G1Jac<C> r = g1j_inf<C>();
+    for (int i = 255; i >= 0; i--) {
+        r = g1j_dbl<C>(r);
+        if (limb_bit<8>(k, i)) r = g1j_add_aff<C>(r, p);
+    }
+    return r;
+}
+
+#undef FP
+}  // namespace bbs

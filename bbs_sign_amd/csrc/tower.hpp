@@ -1,0 +1,251 @@
+// Extension tower Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3-xi), Fp12 = Fp6[w]/(w^2-v) for the two
+// curves (xi = 1+u for BLS12-381, 9+u for BN254).  Karatsuba at every level.
+//
+// This is the arithmetic behind `E::pairing(..).0 * E::pairing(..).0 == E::TargetField::ONE`
+// at /root/reference/src/verify.rs:88-92 and src/proof_verify.rs:112-115 (ark-ec 0.4.2 /
+// ark-ff 0.4.2 Fp12 there; written from the published tower formulas here).
+#pragma once
+#include "field.hpp"
+#include "params_gen.hpp"
+
+namespace bbs {
+
+struct BlsCurve {
+    using FpP = BlsFpParams;
+    using FrP = BlsFrParams;
+    using K = BlsConsts;
+    static constexpr int ID = 0;
+};
+struct BnCurve {
+    using FpP = BnFpParams;
+    using FrP = BnFrParams;
+    using K = BnConsts;
+    static constexpr int ID = 1;
+};
+
+template <class C> using Fp = Fe<typename C::FpP>;
+template <class C> using Fr = Fe<typename C::FrP>;
+
+#define FP typename C::FpP
+
+// ------------------------------------------------------------------------- Fp2
+template <class C>
+struct Fp2 {
+    Fp<C> c0, c1;
+};
+
+template <class C> BBS_HD Fp2<C> f2_zero() { return {fe_zero<FP>(), fe_zero<FP>()}; }
+template <class C> BBS_HD Fp2<C> f2_one() { return {fe_one<FP>(), fe_zero<FP>()}; }
+template <class C> BBS_HD bool f2_is_zero(const Fp2<C>& a) { return fe_is_zero<FP>(a.c0) & fe_is_zero<FP>(a.c1); }
+template <class C> BBS_HD bool f2_eq(const Fp2<C>& a, const Fp2<C>& b) { return fe_eq<FP>(a.c0, b.c0) & fe_eq<FP>(a.c1, b.c1); }
+template <class C> BBS_HD Fp2<C> f2_add(const Fp2<C>& a, const Fp2<C>& b) { return {fe_add<FP>(a.c0, b.c0), fe_add<FP>(a.c1, b.c1)}; }
+template <class C> BBS_HD Fp2<C> f2_sub(const Fp2<C>& a, const Fp2<C>& b) { return {fe_sub<FP>(a.c0, b.c0), fe_sub<FP>(a.c1, b.c1)}; }
+template <class C> BBS_HD Fp2<C> f2_neg(const Fp2<C>& a) { return {fe_neg<FP>(a.c0), fe_neg<FP>(a.c1)}; }
+template <class C> BBS_HD Fp2<C> f2_dbl(const Fp2<C>& a) { return {fe_dbl<FP>(a.c0), fe_dbl<FP>(a.c1)}; }
+template <class C> BBS_HD Fp2<C> f2_conj(const Fp2<C>& a) { return {a.c0, fe_neg<FP>(a.c1)}; }
+
+template <class C>
+BBS_HD_NOINLINE Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
+    // Karatsuba: 3 Fp multiplications
+    Fp<C> t0 = fe_mul<FP>(a.c0, b.c0);
+    Fp<C> t1 = fe_mul<FP>(a.c1, b.c1);
+    Fp<C> s = fe_mul<FP>(fe_add<FP>(a.c0, a.c1), fe_add<FP>(b.c0, b.c1));
+    return {fe_sub<FP>(t0, t1), fe_sub<FP>(fe_sub<FP>(s, t0), t1)};
+}
+
+template <class C>
+BBS_HD_NOINLINE Fp2<C> f2_sqr(const Fp2<C>& a) {
+    // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp multiplications
+    Fp<C> t = fe_mul<FP>(fe_add<FP>(a.c0, a.c1), fe_sub<FP>(a.c0, a.c1));
+    Fp<C> m = fe_mul<FP>(a.c0, a.c1);
+    return {t, fe_dbl<FP>(m)};
+}
+
+template <class C>
+BBS_HD Fp2<C> f2_mul_fp(const Fp2<C>& a, const Fp<C>& s) {
+    return {fe_mul<FP>(a.c0, s), fe_mul<FP>(a.c1, s)};
+}
+
+// a * xi, xi = XI_C0 + u
+template <class C>
+BBS_HD Fp2<C> f2_mul_xi(const Fp2<C>& a) {
+    if constexpr (C::K::XI_C0 == 1) {
+        return {fe_sub<FP>(a.c0, a.c1), fe_add<FP>(a.c0, a.c1)};
+    } else {
+        static_assert(C::K::XI_C0 == 9 || C::K::XI_C0 == 1, "xi");
+        // 9a = 8a + a
+        Fp<C> a0_8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(a.c0)));
+        Fp<C> a1_8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(a.c1)));
+        Fp<C> a0_9 = fe_add<FP>(a0_8, a.c0);
+        Fp<C> a1_9 = fe_add<FP>(a1_8, a.c1);
+        return {fe_sub<FP>(a0_9, a.c1), fe_add<FP>(a1_9, a.c0)};
+    }
+}
+
+template <class C>
+BBS_HD_NOINLINE Fp2<C> f2_inv(const Fp2<C>& a) {
+    Fp<C> n = fe_add<FP>(fe_sqr<FP>(a.c0), fe_sqr<FP>(a.c1));
+    Fp<C> ni = fe_inv<FP>(n);
+    return {fe_mul<FP>(a.c0, ni), fe_neg<FP>(fe_mul<FP>(a.c1, ni))};
+}
+
+// ------------------------------------------------------------------------- Fp6
+template <class C>
+struct Fp6 {
+    Fp2<C> c0, c1, c2;
+};
+
+template <class C> BBS_HD Fp6<C> f6_zero() { return {f2_zero<C>(), f2_zero<C>(), f2_zero<C>()}; }
+template <class C> BBS_HD Fp6<C> f6_one() { return {f2_one<C>(), f2_zero<C>(), f2_zero<C>()}; }
+template <class C> BBS_HD Fp6<C> f6_add(const Fp6<C>& a, const Fp6<C>& b) { return {f2_add<C>(a.c0, b.c0), f2_add<C>(a.c1, b.c1), f2_add<C>(a.c2, b.c2)}; }
+template <class C> BBS_HD Fp6<C> f6_sub(const Fp6<C>& a, const Fp6<C>& b) { return {f2_sub<C>(a.c0, b.c0), f2_sub<C>(a.c1, b.c1), f2_sub<C>(a.c2, b.c2)}; }
+template <class C> BBS_HD Fp6<C> f6_neg(const Fp6<C>& a) { return {f2_neg<C>(a.c0), f2_neg<C>(a.c1), f2_neg<C>(a.c2)}; }
+template <class C> BBS_HD bool f6_eq(const Fp6<C>& a, const Fp6<C>& b) { return f2_eq<C>(a.c0, b.c0) & f2_eq<C>(a.c1, b.c1) & f2_eq<C>(a.c2, b.c2); }
+
+// a * v : (c0, c1, c2) -> (xi c2, c0, c1)
+template <class C>
+BBS_HD Fp6<C> f6_mul_v(const Fp6<C>& a) { return {f2_mul_xi<C>(a.c2), a.c0, a.c1}; }
+
+template <class C>
+BBS_HD_NOINLINE Fp6<C> f6_mul(const Fp6<C>& a, const Fp6<C>& b) {
+    // Karatsuba / Toom-style: 6 Fp2 multiplications
+    Fp2<C> v0 = f2_mul<C>(a.c0, b.c0);
+    Fp2<C> v1 = f2_mul<C>(a.c1, b.c1);
+    Fp2<C> v2 = f2_mul<C>(a.c2, b.c2);
+    Fp2<C> t0 = f2_sub<C>(f2_sub<C>(f2_mul<C>(f2_add<C>(a.c1, a.c2), f2_add<C>(b.c1, b.c2)), v1), v2);
+    Fp2<C> t1 = f2_sub<C>(f2_sub<C>(f2_mul<C>(f2_add<C>(a.c0, a.c1), f2_add<C>(b.c0, b.c1)), v0), v1);
+    Fp2<C> t2 = f2_sub<C>(f2_sub<C>(f2_mul<C>(f2_add<C>(a.c0, a.c2), f2_add<C>(b.c0, b.c2)), v0), v2);
+    return {f2_add<C>(v0, f2_mul_xi<C>(t0)), f2_add<C>(t1, f2_mul_xi<C>(v2)), f2_add<C>(t2, v1)};
+}
+
+// a * (b0 + b1 v)
+template <class C>
+BBS_HD_NOINLINE Fp6<C> f6_mul_by_01(const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
+    Fp2<C> v0 = f2_mul<C>(a.c0, b0);
+    Fp2<C> v1 = f2_mul<C>(a.c1, b1);
+    // c0 = v0 + xi * a2 b1
+    Fp2<C> c0 = f2_add<C>(v0, f2_mul_xi<C>(f2_mul<C>(a.c2, b1)));
+    // c1 = (a0+a1)(b0+b1) - v0 - v1
+    Fp2<C> c1 = f2_sub<C>(f2_sub<C>(f2_mul<C>(f2_add<C>(a.c0, a.c1), f2_add<C>(b0, b1)), v0), v1);
+    // c2 = a2 b0 + v1
+    Fp2<C> c2 = f2_add<C>(f2_mul<C>(a.c2, b0), v1);
+    return {c0, c1, c2};
+}
+
+// a * (b1 v)
+template <class C>
+BBS_HD Fp6<C> f6_mul_by_1(const Fp6<C>& a, const Fp2<C>& b1) {
+    return {f2_mul_xi<C>(f2_mul<C>(a.c2, b1)), f2_mul<C>(a.c0, b1), f2_mul<C>(a.c1, b1)};
+}
+
+// a * (b0), b0 in Fp2
+template <class C>
+BBS_HD Fp6<C> f6_mul_by_0(const Fp6<C>& a, const Fp2<C>& b0) {
+    return {f2_mul<C>(a.c0, b0), f2_mul<C>(a.c1, b0), f2_mul<C>(a.c2, b0)};
+}
+
+template <class C>
+BBS_HD Fp6<C> f6_mul_fp(const Fp6<C>& a, const Fp<C>& s) {
+    return {f2_mul_fp<C>(a.c0, s), f2_mul_fp<C>(a.c1, s), f2_mul_fp<C>(a.c2, s)};
+}
+
+template <class C>
+BBS_HD_NOINLINE Fp6<C> f6_inv(const Fp6<C>& a) {
+    Fp2<C> t0 = f2_sub<C>(f2_sqr<C>(a.c0), f2_mul_xi<C>(f2_mul<C>(a.c1, a.c2)));
+    Fp2<C> t1 = f2_sub<C>(f2_mul_xi<C>(f2_sqr<C>(a.c2)), f2_mul<C>(a.c0, a.c1));
+    Fp2<C> t2 = f2_sub<C>(f2_sqr<C>(a.c1), f2_mul<C>(a.c0, a.c2));
+    Fp2<C> d = f2_add<C>(f2_mul<C>(a.c0, t0),
+                         f2_mul_xi<C>(f2_add<C>(f2_mul<C>(a.c2, t1), f2_mul<C>(a.c1, t2))));
+    Fp2<C> di = f2_inv<C>(d);
+    return {f2_mul<C>(t0, di), f2_mul<C>(t1, di), f2_mul<C>(t2, di)};
+}
+
+// ------------------------------------------------------------------------ Fp12
+template <class C>
+struct Fp12 {
+    Fp6<C> c0, c1;
+};
+
+template <class C> BBS_HD Fp12<C> f12_one() { return {f6_one<C>(), f6_zero<C>()}; }
+template <class C> BBS_HD bool f12_eq(const Fp12<C>& a, const Fp12<C>& b) { return f6_eq<C>(a.c0, b.c0) & f6_eq<C>(a.c1, b.c1); }
+template <class C> BBS_HD bool f12_is_one(const Fp12<C>& a) { return f12_eq<C>(a, f12_one<C>()); }
+template <class C> BBS_HD Fp12<C> f12_conj(const Fp12<C>& a) { return {a.c0, f6_neg<C>(a.c1)}; }
+
+template <class C>
+BBS_HD_NOINLINE Fp12<C> f12_mul(const Fp12<C>& a, const Fp12<C>& b) {
+    Fp6<C> v0 = f6_mul<C>(a.c0, b.c0);
+    Fp6<C> v1 = f6_mul<C>(a.c1, b.c1);
+    Fp6<C> s = f6_mul<C>(f6_add<C>(a.c0, a.c1), f6_add<C>(b.c0, b.c1));
+    return {f6_add<C>(v0, f6_mul_v<C>(v1)), f6_sub<C>(f6_sub<C>(s, v0), v1)};
+}
+
+template <class C>
+BBS_HD_NOINLINE Fp12<C> f12_sqr(const Fp12<C>& a) {
+    // complex squaring: 2 Fp6 multiplications
+    Fp6<C> ab = f6_mul<C>(a.c0, a.c1);
+    Fp6<C> t = f6_mul<C>(f6_add<C>(a.c0, a.c1), f6_add<C>(a.c0, f6_mul_v<C>(a.c1)));
+    // c0 = t - ab - v*ab ; c1 = 2ab
+    Fp6<C> c0 = f6_sub<C>(f6_sub<C>(t, ab), f6_mul_v<C>(ab));
+    return {c0, f6_add<C>(ab, ab)};
+}
+
+template <class C>
+BBS_HD_NOINLINE Fp12<C> f12_inv(const Fp12<C>& a) {
+    // 1/(c0 + c1 w) = (c0 - c1 w) / (c0^2 - v c1^2)
+    Fp6<C> d = f6_sub<C>(f6_mul<C>(a.c0, a.c0), f6_mul_v<C>(f6_mul<C>(a.c1, a.c1)));
+    Fp6<C> di = f6_inv<C>(d);
+    return {f6_mul<C>(a.c0, di), f6_neg<C>(f6_mul<C>(a.c1, di))};
+}
+
+// coefficient i (0..5) of the w-basis: f = sum g_i w^i ; g0,g2,g4 = c0.{c0,c1,c2} ; g1,g3,g5 = c1.{c0,c1,c2}
+template <class C, int K>
+BBS_HD_NOINLINE Fp12<C> f12_frob(const Fp12<C>& a) {
+    static_assert(K >= 1 && K <= 3, "frobenius power");
+    auto coef = [](int i) {
+        Fp2<C> g;
+#pragma unroll
+        for (int j = 0; j < C::FpP::N; j++) {
+            g.c0.v[j] = C::K::FROB[K - 1][i][0][j];
+            g.c1.v[j] = C::K::FROB[K - 1][i][1][j];
+        }
+        return g;
+    };
+    auto cj = [](const Fp2<C>& x) { return (K & 1) ? f2_conj<C>(x) : x; };
+    Fp12<C> r;
+    r.c0.c0 = cj(a.c0.c0);
+    r.c1.c0 = f2_mul<C>(cj(a.c1.c0), coef(1));
+    r.c0.c1 = f2_mul<C>(cj(a.c0.c1), coef(2));
+    r.c1.c1 = f2_mul<C>(cj(a.c1.c1), coef(3));
+    r.c0.c2 = f2_mul<C>(cj(a.c0.c2), coef(4));
+    r.c1.c2 = f2_mul<C>(cj(a.c1.c2), coef(5));
+    return r;
+}
+
+// ---- sparse multiplications by Miller-loop line values --------------------------------------
+// M-type twist (BLS12-381): line = l0 + l1 v + (yP) v w        (l0, l1 in Fp2, yP in Fp)
+template <class C>
+BBS_HD_NOINLINE Fp12<C> f12_mul_by_line_M(const Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const Fp<C>& yP) {
+    // A = (l0, l1, 0), B = (0, yP, 0)
+    Fp6<C> v0 = f6_mul_by_01<C>(f.c0, l0, l1);
+    // f.c1 * (yP v) : (xi c2 yP, c0 yP, c1 yP)
+    Fp6<C> v1 = {f2_mul_xi<C>(f2_mul_fp<C>(f.c1.c2, yP)), f2_mul_fp<C>(f.c1.c0, yP), f2_mul_fp<C>(f.c1.c1, yP)};
+    Fp2<C> l1y = l1;
+    l1y.c0 = fe_add<FP>(l1y.c0, yP);
+    Fp6<C> s = f6_mul_by_01<C>(f6_add<C>(f.c0, f.c1), l0, l1y);
+    return {f6_add<C>(v0, f6_mul_v<C>(v1)), f6_sub<C>(f6_sub<C>(s, v0), v1)};
+}
+
+// D-type twist (BN254): line = (yP) + (l0 + l1 v) w             (l0, l1 in Fp2, yP in Fp)
+template <class C>
+BBS_HD_NOINLINE Fp12<C> f12_mul_by_line_D(const Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const Fp<C>& yP) {
+    // A = (yP, 0, 0), B = (l0, l1, 0)
+    Fp6<C> v0 = f6_mul_fp<C>(f.c0, yP);
+    Fp6<C> v1 = f6_mul_by_01<C>(f.c1, l0, l1);
+    Fp2<C> l0y = l0;
+    l0y.c0 = fe_add<FP>(l0y.c0, yP);
+    Fp6<C> s = f6_mul_by_01<C>(f6_add<C>(f.c0, f.c1), l0y, l1);
+    return {f6_add<C>(v0, f6_mul_v<C>(v1)), f6_sub<C>(f6_sub<C>(s, v0), v1)};
+}
+
+#undef FP
+}  // namespace bbs

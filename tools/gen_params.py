@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Generates bbs_sign_amd/csrc/params_gen.hpp: Montgomery constants, curve constants and
+Frobenius coefficients for BLS12-381 and BN254 as 32-bit little-endian limb arrays.
+
+Self-contained (plain Python integers; does not import the oracle).  Re-run after editing:
+    python tools/gen_params.py
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "bbs_sign_amd", "csrc", "params_gen.hpp")
+
+
+def limbs(v, n):
+    assert 0 <= v < (1 << (32 * n))
+    return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+def arr(name, v, n):
+    body = ", ".join("0x%08xu" % w for w in limbs(v, n))
+    return "    static constexpr uint32_t %s[%d] = {%s};\n" % (name, n, body)
+
+
+def f2_mul(a, b, p):
+    return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+
+def f2_pow(a, e, p):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2_mul(r, a, p)
+        a = f2_mul(a, a, p)
+        e >>= 1
+    return r
+
+
+def field_struct(name, mod, n):
+    R = 1 << (32 * n)
+    inv = (-pow(mod, -1, 1 << 32)) % (1 << 32)
+    s = "struct %s {\n" % name
+    s += "    static constexpr int N = %d;\n" % n
+    s += "    static constexpr int BITS = %d;\n" % mod.bit_length()
+    s += "    static constexpr uint32_t INV = 0x%08xu;   // -mod^-1 mod 2^32\n" % inv
+    s += arr("MOD", mod, n)
+    s += arr("ONE", R % mod, n)            # R mod p  (Montgomery 1)
+    s += arr("R2", R * R % mod, n)         # R^2 mod p
+    s += arr("R3", R * R * R % mod, n)     # R^3 mod p
+    s += arr("HALF", (mod - 1) // 2, n)    # (p-1)/2 : y > HALF <=> lexicographically largest
+    s += arr("MOD_M2", mod - 2, n)         # exponent for Fermat inversion
+    s += "};\n\n"
+    return s
+
+
+def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_desc):
+    R = 1 << (32 * n)
+    m = lambda v: v * R % p
+    s = "struct %sConsts {\n" % tag
+    s += "    static constexpr int N = %d;\n" % n
+    s += "    static constexpr bool TWIST_M = %s;\n" % ("true" if twist == "M" else "false")
+    s += "    static constexpr bool X_NEG = %s;\n" % ("true" if xneg else "false")
+    s += "    static constexpr uint64_t X_ABS = 0x%016xull;\n" % xabs
+    s += "    static constexpr uint32_t XI_C0 = %d;   // xi = XI_C0 + u\n" % xi[0]
+    s += arr("B_M", m(b), n)
+    s += arr("B3_M", m(3 * b), n)
+    s += arr("G1X_M", m(g1[0]), n) + arr("G1Y_M", m(g1[1]), n)
+    s += arr("P1X_M", m(p1[0]), n) + arr("P1Y_M", m(p1[1]), n)
+    s += arr("G2X0_M", m(g2[0][0]), n) + arr("G2X1_M", m(g2[0][1]), n)
+    s += arr("G2Y0_M", m(g2[1][0]), n) + arr("G2Y1_M", m(g2[1][1]), n)
+    # twist curve coefficient b' (Fp2)
+    if twist == "M":
+        b2 = f2_mul((b, 0), xi, p)
+    else:
+        d = pow(xi[0] * xi[0] + xi[1] * xi[1], -1, p)
+        b2 = f2_mul((b, 0), (xi[0] * d % p, -xi[1] * d % p), p)
+    s += arr("B2_C0_M", m(b2[0]), n) + arr("B2_C1_M", m(b2[1]), n)
+    # Frobenius coefficients gamma[k][i] = xi^(i (p^k - 1)/6), k = 1..3, i = 0..5
+    s += "    // FROB[k-1][i][c] : xi^(i*(p^k-1)/6), Montgomery form, c = 0 real / 1 imaginary\n"
+    s += "    static constexpr uint32_t FROB[3][6][2][%d] = {\n" % n
+    for k in (1, 2, 3):
+        s += "      {\n"
+        for i in range(6):
+            g = f2_pow(xi, i * (p ** k - 1) // 6, p)
+            s += "        {{%s}, {%s}},\n" % (
+                ", ".join("0x%08xu" % w for w in limbs(m(g[0]), n)),
+                ", ".join("0x%08xu" % w for w in limbs(m(g[1]), n)))
+        s += "      },\n"
+    s += "    };\n"
+    s += "};\n\n"
+    return s
+
+
+def main():
+    bls_p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    bls_r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    bn_p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    bn_r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    bls_g1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+              0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+    bls_g2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+               0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+              (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+               0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
+    bls_p1 = (1355253221325668152696183518801331769866100080859571110928822005264442742039790254588065001486134245057142899747017,
+              2563071790429735027383427649950865259619709115697058137448106859255609577834149037543606665262210555960464099235249)
+    bn_g2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+              11559732032986387107991004021392285783925812861821192530917403151452391805634),
+             (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+              4082367875863433681332203403145435568316851327593401208105741076214120093531))
+    bn_p1 = (7738860219269362160002109478394842060990190871738832255540382874922375322334,
+             8255268479661695615178834896135584953541182794935974658059743263102507888551)
+
+    s = "// GENERATED by tools/gen_params.py -- do not edit.\n#pragma once\n#include <cstdint>\n\nnamespace bbs {\n\n"
+    s += field_struct("BlsFpParams", bls_p, 12)
+    s += field_struct("BlsFrParams", bls_r, 8)
+    s += field_struct("BnFpParams", bn_p, 8)
+    s += field_struct("BnFrParams", bn_r, 8)
+    s += curve_struct("Bls", bls_p, bls_r, 12, 4, (1, 1), "M", bls_g1, bls_g2, bls_p1,
+                      0xD201000000010000, True, "")
+    s += curve_struct("Bn", bn_p, bn_r, 8, 3, (9, 1), "D", (1, 2), bn_g2, bn_p1,
+                      4965661367192848881, False, "")
+    s += "}  // namespace bbs\n"
+    with open(OUT, "w") as f:
+        f.write(s)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
