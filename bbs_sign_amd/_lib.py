@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI declared in include/bbs_sign_amd.h.
+
+The product library (bbs_sign_amd/libbbs_sign_amd.so, built by __graft_entry__.build() with
+hipcc --offload-arch=gfx950) is the ONLY thing loaded by default; there is no CPU fallback: a
+missing library or a missing GPU raises.  Tests of the host logic may pass an explicit path to
+the host-twin test library (tests/hosttwin) instead.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "libbbs_sign_amd.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_i8p = ctypes.POINTER(ctypes.c_int8)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+vp = ctypes.c_void_p
+sz = ctypes.c_size_t
+ci = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/bbs_sign_amd.h declares
+SIGNATURES = {
+    "bbs_fp_bytes": (sz, [ci]),
+    "bbs_version": (ctypes.c_char_p, []),
+    "bbs_device_count": (ci, []),
+    "bbs_ctx_create": (ci, [ci, ci, ctypes.POINTER(vp)]),
+    "bbs_ctx_destroy": (None, [vp]),
+    "bbs_ctx_set_window_bits": (ci, [vp, ci]),
+    "bbs_ctx_set_generators": (ci, [vp, c_u8p, sz, c_u8p, sz]),
+    "bbs_ctx_set_public_key": (ci, [vp, c_u8p, ci]),
+    "bbs_ctx_set_secret_key": (ci, [vp, c_u8p]),
+    "bbs_ctx_get_public_key": (ci, [vp, c_u8p, ctypes.POINTER(ci)]),
+    "bbs_ctx_get_public_key_compressed": (ci, [vp, c_u8p, sz, ctypes.POINTER(sz)]),
+    "bbs_core_proof_verify_upload": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p,
+                                          c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
+    "bbs_core_proof_verify_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p,
+                                         c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
+    "bbs_core_verify_upload": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
+    "bbs_core_verify_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
+    "bbs_core_sign_upload": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
+    "bbs_core_sign_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p]),
+    "bbs_core_proof_gen_upload": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p,
+                                       c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
+    "bbs_core_proof_gen_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p,
+                                      c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_u64p, c_i8p]),
+    "bbs_job_run": (ci, [vp]),
+    "bbs_job_wait": (ci, [vp]),
+    "bbs_job_size": (sz, [vp]),
+    "bbs_job_fetch_status": (ci, [vp, c_i8p]),
+    "bbs_job_fetch_signatures": (ci, [vp, c_u8p]),
+    "bbs_job_fetch_proofs": (ci, [vp, c_u8p, c_u8p, c_u64p]),
+    "bbs_job_free": (None, [vp]),
+    "bbs_job_run_timed": (ci, [vp, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
+    "bbs_job_stage_name": (ctypes.c_char_p, [vp, ci]),
+    "bbs_hash_to_scalar_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, sz, c_u8p]),
+    "bbs_g1_msm_batch": (ci, [vp, sz, c_u8p, sz, c_u8p, c_u8p, sz, c_u8p, c_i8p]),
+    "bbs_pairing_product2_is_one_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
+}
+
+_cache = {}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load the C-ABI library.  ``path=None`` means the product library; it is an error if it has
+    not been built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    path = os.path.abspath(path or PRODUCT_LIB)
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise LibraryMissing(
+            "%s not found: the HIP extension is not built; there is no CPU fallback "
+            "(build it with __graft_entry__.build())" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _cache[path] = lib
+    return lib

@@ -1,0 +1,205 @@
+// C ABI entry points (include/bbs_sign_amd.h) dispatching on the curve.
+#include "ops_decl.hpp"
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+#define DISPATCH(ctx, expr_bls, expr_bn) ((ctx)->curve == BBS_CURVE_BLS12_381 ? (expr_bls) : (expr_bn))
+#define AS_BLS(ctx) static_cast<Ctx<BlsCurve>*>(ctx)
+#define AS_BN(ctx) static_cast<Ctx<BnCurve>*>(ctx)
+
+extern "C" {
+
+size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
+const char* bbs_version(void) {
+#ifdef BBS_HOST_TWIN
+    return "bbs_sign_amd 0.1 (HOST TWIN - TEST ONLY)";
+#else
+    return "bbs_sign_amd 0.1 (gfx950)";
+#endif
+}
+int bbs_device_count(void) { return rt::device_count(); }
+
+int bbs_ctx_create(int curve, int device_id, bbs_ctx** out) {
+    if (!out || (curve != BBS_CURVE_BLS12_381 && curve != BBS_CURVE_BN254)) return BBS_E_ARG;
+    if (device_id < 0 || device_id >= rt::device_count()) return BBS_E_NO_DEVICE;
+    int rc;
+    if (curve == BBS_CURVE_BLS12_381) {
+        auto* c = new Ctx<BlsCurve>();
+        c->curve = curve;
+        rc = c->init(device_id);
+        if (rc) { delete c; return rc; }
+        *out = c;
+    } else {
+        auto* c = new Ctx<BnCurve>();
+        c->curve = curve;
+        rc = c->init(device_id);
+        if (rc) { delete c; return rc; }
+        *out = c;
+    }
+    return BBS_OK;
+}
+void bbs_ctx_destroy(bbs_ctx* ctx) { delete ctx; }
+
+int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
+    if (!ctx || bits < 4 || bits > 16) return BBS_E_ARG;
+    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->win_bits = bits; else AS_BN(ctx)->win_bits = bits;
+    return BBS_OK;
+}
+int bbs_ctx_set_generators(bbs_ctx* ctx, const uint8_t* g, size_t count, const uint8_t* api_id, size_t api_id_len) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, AS_BLS(ctx)->set_generators(g, count, api_id, api_id_len), AS_BN(ctx)->set_generators(g, count, api_id, api_id_len));
+}
+int bbs_ctx_set_public_key(bbs_ctx* ctx, const uint8_t* pk, int is_identity) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, AS_BLS(ctx)->set_public_key(pk, is_identity), AS_BN(ctx)->set_public_key(pk, is_identity));
+}
+int bbs_ctx_set_secret_key(bbs_ctx* ctx, const uint8_t* sk32) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, AS_BLS(ctx)->set_secret_key(sk32), AS_BN(ctx)->set_secret_key(sk32));
+}
+int bbs_ctx_get_public_key(bbs_ctx* ctx, uint8_t* out, int* inf) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, AS_BLS(ctx)->get_public_key(out, inf), AS_BN(ctx)->get_public_key(out, inf));
+}
+int bbs_ctx_get_public_key_compressed(bbs_ctx* ctx, uint8_t* out, size_t cap, size_t* len_out) {
+    if (!ctx || !out) return BBS_E_ARG;
+    const size_t need = 2 * bbs_fp_bytes(ctx->curve);
+    if (cap < need) return BBS_E_ARG;
+    if (ctx->curve == BBS_CURVE_BLS12_381) {
+        if (!AS_BLS(ctx)->pk_set) return BBS_E_STATE;
+        g2_compress<BlsCurve>(AS_BLS(ctx)->pk, out);
+    } else {
+        if (!AS_BN(ctx)->pk_set) return BBS_E_STATE;
+        g2_compress<BnCurve>(AS_BN(ctx)->pk, out);
+    }
+    if (len_out) *len_out = need;
+    return BBS_OK;
+}
+
+int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
+                                 const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
+                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, bbs_job** job) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job),
+                    pv_upload<BnCurve>(AS_BN(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job));
+}
+int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                           const uint8_t* h, const uint64_t* ho, bbs_job** job) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, h, ho, job), vf_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, h, ho, job));
+}
+int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho, bbs_job** job) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, sg_upload<BlsCurve>(AS_BLS(ctx), n, m, mo, h, ho, job), sg_upload<BnCurve>(AS_BN(ctx), n, m, mo, h, ho, job));
+}
+int bbs_core_proof_gen_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                              const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                              const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, bbs_job** job) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, pg_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job),
+                    pg_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job));
+}
+
+int bbs_job_run(bbs_job* job) { return job ? job->run() : BBS_E_ARG; }
+int bbs_job_wait(bbs_job* job) { return job ? job->wait() : BBS_E_ARG; }
+size_t bbs_job_size(const bbs_job* job) { return job ? job->n : 0; }
+int bbs_job_fetch_status(bbs_job* job, int8_t* st) { return (job && st) ? job->fetch_status(st) : BBS_E_ARG; }
+int bbs_job_fetch_signatures(bbs_job* job, uint8_t* out) { return (job && out) ? job->fetch_signatures(out) : BBS_E_ARG; }
+int bbs_job_fetch_proofs(bbs_job* job, uint8_t* pf, uint8_t* cm, uint64_t* cmo) { return job ? job->fetch_proofs(pf, cm, cmo) : BBS_E_ARG; }
+void bbs_job_free(bbs_job* job) { delete job; }
+const char* bbs_job_stage_name(const bbs_job* job, int k) {
+    return (job && k >= 0 && (size_t)k < job->stages.size()) ? job->stages[k].name : nullptr;
+}
+int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms, int cap, int* n_stages) {
+    if (!job || reps < 1) return BBS_E_ARG;
+    if (job->use()) return BBS_E_HIP;
+    const int ns = (int)job->stages.size();
+    if (n_stages) *n_stages = ns;
+    std::vector<float> acc(ns, 0.f);
+    rt::Timer tot, st;
+    float total = 0.f;
+    for (int r = 0; r < reps; r++) {
+        if (job->reset()) return BBS_E_HIP;
+        if (rt::sync(job->stream())) return BBS_E_HIP;
+        tot.start(job->stream());
+        for (int k = 0; k < ns; k++) {
+            if (kernel_ms) {
+                // per-stage events serialise nothing extra: the stages already depend on each other
+                st.start(job->stream());
+                if (job->stages[k].launch()) return BBS_E_HIP;
+                acc[k] += st.stop(job->stream());
+            } else if (job->stages[k].launch()) return BBS_E_HIP;
+        }
+        total += tot.stop(job->stream());
+    }
+    if (total_ms) *total_ms = total;
+    if (kernel_ms) for (int k = 0; k < ns && k < cap; k++) kernel_ms[k] = acc[k];
+    return BBS_OK;
+}
+
+static int run_fetch_free(bbs_job* job, int8_t* status) {
+    int rc = job->run();
+    if (!rc && status) rc = job->fetch_status(status);
+    return rc;
+}
+
+int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
+                                const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
+                                const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_core_proof_verify_upload(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, &job);
+    if (rc) return rc;
+    rc = run_fetch_free(job, status);
+    delete job;
+    return rc;
+}
+int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                          const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_core_verify_upload(ctx, n, sigs, m, mo, h, ho, &job);
+    if (rc) return rc;
+    rc = run_fetch_free(job, status);
+    delete job;
+    return rc;
+}
+int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
+                        uint8_t* sigs_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_core_sign_upload(ctx, n, m, mo, h, ho, &job);
+    if (rc) return rc;
+    rc = run_fetch_free(job, status);
+    if (!rc && sigs_out) rc = job->fetch_signatures(sigs_out);
+    delete job;
+    return rc;
+}
+int bbs_core_proof_gen_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                             const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                             const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                             uint8_t* pf_out, uint8_t* cm_out, uint64_t* cmo_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_core_proof_gen_upload(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, &job);
+    if (rc) return rc;
+    rc = run_fetch_free(job, status);
+    if (!rc) rc = job->fetch_proofs(pf_out, cm_out, cmo_out);
+    delete job;
+    return rc;
+}
+
+// ---- unit-parity primitives -------------------------------------------------------------------
+int bbs_hash_to_scalar_batch(bbs_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* off, const uint8_t* dst, size_t dst_len, uint8_t* out) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, h2s_batch<BlsCurve>(AS_BLS(ctx), n, msgs, off, dst, dst_len, out), h2s_batch<BnCurve>(AS_BN(ctx), n, msgs, off, dst, dst_len, out));
+}
+
+int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t* vp, const uint8_t* vs, size_t nv, uint8_t* out, int8_t* status) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, msm_batch<BlsCurve>(AS_BLS(ctx), n, fs, nf, vp, vs, nv, out, status), msm_batch<BnCurve>(AS_BN(ctx), n, fs, nf, vp, vs, nv, out, status));
+}
+
+int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, pairing_batch<BlsCurve>(AS_BLS(ctx), n, pa, pb, status), pairing_batch<BnCurve>(AS_BN(ctx), n, pa, pb, status));
+}
+
+}  // extern "C"

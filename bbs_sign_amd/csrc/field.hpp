@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #define BBS_HD __host__ __device__ __forceinline__
-#define BBS_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define BBS_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 
 namespace bbs {
 

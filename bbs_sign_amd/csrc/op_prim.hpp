@@ -1,0 +1,135 @@
+// Host orchestration of one batched operation (template over the curve); instantiated by the
+// per-curve translation units tu_*.hip so the library builds in parallel.
+#pragma once
+#include "runtime.hpp"
+
+template <class C>
+int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, size_t aid_len) {
+    if (count < 1 || (!g) || (aid_len && !aid)) return BBS_E_ARG;
+    if (use()) return BBS_E_HIP;
+    std::vector<G1Aff<C>> tmp(count);
+    for (size_t k = 0; k < count; k++) {
+        if (!fe_from_le_bytes<typename C::FpP>(g + k * 2 * FPB, tmp[k].x)) return BBS_E_ARG;
+        if (!fe_from_le_bytes<typename C::FpP>(g + k * 2 * FPB + FPB, tmp[k].y)) return BBS_E_ARG;
+        if (!g1a_on_curve<C>(tmp[k])) return BBS_E_ARG;
+    }
+    gens.swap(tmp);
+    L = (int)count - 1;
+    api_id.assign(aid, aid + aid_len);
+    gens_set = true;
+    // fixed-base tables over [P1, Q1, H_1..H_L]
+    const int nb = L + 2, W = (256 + win_bits - 1) / win_bits;
+    const size_t per_win = ((size_t)1 << win_bits) - 1;
+    std::vector<uint32_t> bases((size_t)nb * 2 * N);
+    auto put = [&](size_t k, const G1Aff<C>& p) {
+        for (int j = 0; j < N; j++) { bases[k * 2 * N + j] = p.x.v[j]; bases[k * 2 * N + N + j] = p.y.v[j]; }
+    };
+    put(0, hc.p1);
+    for (size_t k = 0; k < gens.size(); k++) put(1 + k, gens[k]);
+    if (d_bases.alloc(bases.size() * 4)) return BBS_E_NOMEM;
+    if (d_winbase.alloc((size_t)nb * W * 2 * N * 4)) return BBS_E_NOMEM;
+    if (d_tables.alloc((size_t)nb * W * per_win * 2 * N * 4)) return BBS_E_NOMEM;
+    if (rt::h2d(d_bases.p, bases.data(), bases.size() * 4, stream)) return BBS_E_HIP;
+    TabArgs<C> ta;
+    ta.n_bases = nb; ta.win_bits = win_bits; ta.n_windows = W;
+    ta.bases = d_bases.as<uint32_t>(); ta.winbase = d_winbase.as<uint32_t>(); ta.tables = d_tables.as<uint32_t>();
+    if (rt::launch<TabWinBase<C>>(stream, ta, (size_t)nb)) return BBS_E_HIP;
+    if (rt::launch<TabEntry<C>>(stream, ta, (size_t)nb * W * per_win)) return BBS_E_HIP;
+    if (rt::sync(stream)) return BBS_E_HIP;
+    hc.L = L; hc.n_bases = nb; hc.win_bits = win_bits; hc.n_windows = W;
+    rebuild_hash();
+    return BBS_OK;
+}
+
+
+template <class C>
+int h2s_batch(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* off, const uint8_t* dst, size_t dst_len, uint8_t* out) {
+    if (dst_len > 255 || !out || (n && !off)) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    BytePool bp;
+    if (!bp.build(n, msgs, off)) return BBS_E_ARG;
+    DevBuf d_off, d_len, d_bytes, d_out;
+    if (d_off.alloc(n * 4 + 4) || d_len.alloc(n * 4 + 4) || d_bytes.alloc(bp.bytes.size()) || d_out.alloc(n * 32 + 4)) return BBS_E_NOMEM;
+    if (rt::h2d(d_off.p, bp.off.data(), n * 4, ctx->stream) || rt::h2d(d_len.p, bp.len.data(), n * 4, ctx->stream) ||
+        rt::h2d(d_bytes.p, bp.bytes.data(), bp.bytes.size(), ctx->stream)) return BBS_E_HIP;
+    H2sArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n; a.off = d_off.as<uint32_t>(); a.len = d_len.as<uint32_t>(); a.bytes = d_bytes.as<uint8_t>();
+    if (dst_len) std::memcpy(a.dst, dst, dst_len);
+    a.dst_len = (uint32_t)dst_len; a.out = d_out.as<uint32_t>();
+    if (rt::launch<H2sItem<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> w(n * 8);
+    if (rt::d2h(w.data(), d_out.p, n * 32, ctx->stream)) return BBS_E_HIP;
+    for (size_t i = 0; i < n; i++) unpack_words_le(w, n, 0, i, 8, out + i * 32);
+    return BBS_OK;
+}
+template <class C>
+int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t* vp, const uint8_t* vs, size_t nv,
+                     uint8_t* out, int8_t* status) {
+    constexpr int N = C::FpP::N;
+    constexpr int FPB = 4 * N;
+    using R = typename C::FrP;
+    if (!ctx->gens_set) return BBS_E_STATE;
+    if (nf > (size_t)ctx->L + 2 || !out || !status || (nf && !fs) || (nv && (!vp || !vs))) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    Soa F, VP, VS;
+    F.init(std::max<size_t>(nf, 1) * 8, n); VP.init(std::max<size_t>(nv, 1) * 2 * N, n); VS.init(std::max<size_t>(nv, 1) * 8, n);
+    std::vector<int8_t> st0(n, 1);
+    for (size_t i = 0; i < n; i++) {
+        bool ok = true;
+        for (size_t k = 0; k < nf; k++) ok &= pack_fe<R>(F, k * 8, i, fs + (i * nf + k) * 32);
+        for (size_t k = 0; k < nv; k++) {
+            ok &= pack_g1<C>(VP, k * 2 * N, i, vp + (i * nv + k) * 2 * FPB);
+            ok &= pack_fe<R>(VS, k * 8, i, vs + (i * nv + k) * 32);
+        }
+        if (!ok) st0[i] = BBS_ST_NONCANONICAL;
+    }
+    DevBuf dF, dVP, dVS, dSt, dPart, dOut;
+    if (dF.alloc(F.bytes()) || dVP.alloc(VP.bytes()) || dVS.alloc(VS.bytes()) || dSt.alloc(n + 4) ||
+        dPart.alloc((nv + NFIX) * 3 * N * n * 4 + 4) || dOut.alloc((size_t)2 * N * n * 4 + 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dF.p, F.v.data(), F.bytes(), ctx->stream) || rt::h2d(dVP.p, VP.v.data(), VP.bytes(), ctx->stream) ||
+        rt::h2d(dVS.p, VS.v.data(), VS.bytes(), ctx->stream) || rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
+    int rc = ctx->sync_consts();
+    if (rc) return rc;
+    MsmArgs<C> a;
+    a.n = n; a.n_fixed = (int)nf; a.n_var = (int)nv; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
+    a.fscal = dF.as<uint32_t>(); a.vpts = dVP.as<uint32_t>(); a.vscal = dVS.as<uint32_t>();
+    a.status = dSt.as<int8_t>(); a.partials = dPart.as<uint32_t>(); a.out = dOut.as<uint32_t>();
+    if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> w((size_t)2 * N * n);
+    if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
+    for (size_t i = 0; i < n; i++) {
+        if (status[i] == 1) unpack_words_le(w, n, 0, i, 2 * N, out + i * 2 * FPB);
+        else std::memset(out + i * 2 * FPB, 0, 2 * FPB);
+    }
+    return BBS_OK;
+}
+template <class C>
+int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
+    constexpr int N = C::FpP::N;
+    constexpr int FPB = 4 * N;
+    if (!ctx->pk_set) return BBS_E_STATE;
+    if (!status || (n && (!pa || !pb))) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    Soa A, B;
+    A.init(2 * N, n); B.init(2 * N, n);
+    std::vector<int8_t> st0(n, 1);
+    for (size_t i = 0; i < n; i++) {
+        bool ok = pack_g1<C>(A, 0, i, pa + i * 2 * FPB) & pack_g1<C>(B, 0, i, pb + i * 2 * FPB);
+        if (!ok) st0[i] = BBS_ST_NONCANONICAL;
+    }
+    DevBuf dA, dB, dAm, dBm, dSt, dF;
+    if (dA.alloc(A.bytes()) || dB.alloc(B.bytes()) || dAm.alloc(A.bytes()) || dBm.alloc(B.bytes()) || dSt.alloc(n + 4) ||
+        dF.alloc((size_t)2 * 12 * N * n * 4 + 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dA.p, A.v.data(), A.bytes(), ctx->stream) || rt::h2d(dB.p, B.v.data(), B.bytes(), ctx->stream) ||
+        rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
+    int rc = ctx->sync_consts();
+    if (rc) return rc;
+    PairPrep<C> pp{dA.as<uint32_t>(), dB.as<uint32_t>(), dAm.as<uint32_t>(), dBm.as<uint32_t>(), dSt.as<int8_t>(), n};
+    PairArgs<C> a;
+    a.n = n; a.cc = ctx->d_consts.template as<CtxConsts<C>>(); a.pa = dAm.as<uint32_t>(); a.pb = dBm.as<uint32_t>();
+    a.negate_b = 0; a.status = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
+    if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) || rt::launch<PairMiller<C>>(ctx->stream, a, n * 2) ||
+        rt::launch<PairFinal<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    return rt::d2h(status, dSt.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
+}

@@ -1,0 +1,364 @@
+#pragma once
+// Runtime layer of the MI355X BBS+ engine (included by every translation unit): contexts (device-resident tables), jobs
+// (device-resident batches), validation in the reference's order, kernel launches on the
+// context's HIP stream.  See include/bbs_sign_amd.h for the contract.
+//
+// Build: hipcc --offload-arch=gfx950 (product, libbbs_sign_amd.so).  The macro BBS_HOST_TWIN
+// (tests/hosttwin only, never part of the product library) swaps the HIP runtime calls for
+// malloc/memcpy/for-loops so that the host logic in this file can be unit-tested in a container
+// without a GPU; the product build contains no CPU execution path for the stages.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bbs_sign_amd.h"
+#include "host_g2.hpp"
+#include "stages.hpp"
+
+using namespace bbs;
+
+// =============================================================================================
+// runtime layer
+// =============================================================================================
+namespace rt {
+#ifdef BBS_HOST_TWIN
+struct Stream {};
+inline int set_device(int) { return 0; }
+inline int device_count() { return 1; }
+inline int stream_create(Stream*) { return 0; }
+inline void stream_destroy(Stream&) {}
+inline int dmalloc(void** p, size_t b) { *p = std::calloc(b ? b : 1, 1); return *p ? 0 : -1; }
+inline void dfree(void* p) { std::free(p); }
+inline int h2d(void* d, const void* h, size_t b, Stream&) { std::memcpy(d, h, b); return 0; }
+inline int d2h(void* h, const void* d, size_t b, Stream&) { std::memcpy(h, d, b); return 0; }
+inline int dmemset(void* d, int v, size_t b, Stream&) { std::memset(d, v, b); return 0; }
+inline int sync(Stream&) { return 0; }
+template <class F, class A>
+inline int launch(Stream&, const A& a, size_t nthreads) {
+    for (size_t t = 0; t < nthreads; t++) F::run(a, t);
+    return 0;
+}
+struct Timer {
+    std::chrono::steady_clock::time_point t0;
+    void start(Stream&) { t0 = std::chrono::steady_clock::now(); }
+    float stop(Stream&) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#else
+using Stream = hipStream_t;
+inline int set_device(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
+inline int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+inline int stream_create(Stream* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; }
+inline void stream_destroy(Stream& s) { (void)hipStreamDestroy(s); }
+inline int dmalloc(void** p, size_t b) { return hipMalloc(p, b ? b : 4) == hipSuccess ? 0 : -1; }
+inline void dfree(void* p) { (void)hipFree(p); }
+inline int h2d(void* d, const void* h, size_t b, Stream& s) {
+    if (!b) return 0;
+    if (hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;   // host staging buffers are transient
+}
+inline int d2h(void* h, const void* d, size_t b, Stream& s) {
+    if (!b) return 0;
+    if (hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+inline int dmemset(void* d, int v, size_t b, Stream& s) { return (!b || hipMemsetAsync(d, v, b, s) == hipSuccess) ? 0 : -1; }
+inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+
+template <class F, class A>
+__global__ void __launch_bounds__(64) k_stage(A a, size_t nthreads) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t < nthreads) F::run(a, t);
+}
+template <class F, class A>
+inline int launch(Stream& s, const A& a, size_t nthreads) {
+    if (!nthreads) return 0;
+    const unsigned blocks = (unsigned)((nthreads + 63) / 64);
+    hipLaunchKernelGGL((k_stage<F, A>), dim3(blocks), dim3(64), 0, s, a, nthreads);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    Timer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void start(Stream& s) { (void)hipEventRecord(a, s); }
+    float stop(Stream& s) {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+};
+#endif
+}  // namespace rt
+
+// device buffer with ownership
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) rt::dfree(p); p = nullptr; bytes = 0; }
+    int alloc(size_t b) { release(); bytes = b; return rt::dmalloc(&p, b); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// =============================================================================================
+// host-side packing helpers
+// =============================================================================================
+inline uint32_t le32(const uint8_t* b) {
+    return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+}
+inline void put_le32(uint8_t* b, uint32_t v) {
+    b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); b[2] = (uint8_t)(v >> 16); b[3] = (uint8_t)(v >> 24);
+}
+
+// SoA array of `words` 32-bit words per item
+struct Soa {
+    std::vector<uint32_t> v;
+    size_t n = 0, words = 0;
+    void init(size_t words_, size_t n_) { words = words_; n = n_; v.assign(words_ * n_, 0u); }
+    uint32_t& at(size_t w, size_t i) { return v[w * n + i]; }
+    size_t bytes() const { return v.size() * 4; }
+};
+
+// canonical scalar (32 B LE) into SoA words [w0, w0+8); returns false if >= r
+template <class P>
+inline bool pack_fe(Soa& s, size_t w0, size_t i, const uint8_t* le) {
+    uint32_t l[P::N];
+    for (int k = 0; k < P::N; k++) l[k] = le32(le + 4 * k);
+    for (int k = 0; k < P::N; k++) s.at(w0 + k, i) = l[k];
+    return limbs_lt_mod<P>(l);
+}
+template <class C>
+inline bool pack_g1(Soa& s, size_t w0, size_t i, const uint8_t* xy) {
+    constexpr int N = C::FpP::N;
+    bool a = pack_fe<typename C::FpP>(s, w0, i, xy);
+    bool b = pack_fe<typename C::FpP>(s, w0 + N, i, xy + 4 * N);
+    return a && b;
+}
+inline void unpack_words_le(const std::vector<uint32_t>& v, size_t n, size_t w0, size_t i, int words, uint8_t* out) {
+    for (int k = 0; k < words; k++) put_le32(out + 4 * k, v[(w0 + k) * n + i]);
+}
+
+// ragged bytes -> device pool + u32 offset / len
+struct BytePool {
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off, len;
+    bool build(size_t n, const uint8_t* data, const uint64_t* offs) {
+        off.assign(n, 0); len.assign(n, 0);
+        if (!offs) { bytes.assign(4, 0); return true; }        // all empty
+        const uint64_t total = offs[n] - offs[0];
+        if (total > 0xF0000000ull) return false;
+        for (size_t i = 0; i < n; i++) {
+            if (offs[i + 1] < offs[i]) return false;
+            off[i] = (uint32_t)(offs[i] - offs[0]);
+            len[i] = (uint32_t)(offs[i + 1] - offs[i]);
+        }
+        bytes.assign(data ? data + offs[0] : nullptr, data ? data + offs[n] : nullptr);
+        if (bytes.size() != total) return false;
+        bytes.resize(bytes.size() + 4, 0);
+        return true;
+    }
+};
+
+// =============================================================================================
+// context
+// =============================================================================================
+struct IJob;
+struct bbs_ctx {
+    int curve = 0;
+    virtual ~bbs_ctx() {}
+};
+
+template <class C>
+struct Ctx : bbs_ctx {
+    static constexpr int N = C::FpP::N;
+    static constexpr int FPB = 4 * N;
+    int device = 0;
+    rt::Stream stream{};
+    int win_bits = 8;
+    // host state
+    bool gens_set = false, pk_set = false, sk_set = false, dst_too_long = false;
+    int L = 0;
+    std::vector<G1Aff<C>> gens;      // Q1, H_1..H_L  (Montgomery)
+    std::vector<uint8_t> api_id;
+    G2Aff<C> pk{};
+    uint32_t sk[8] = {0};
+    // device state
+    CtxConsts<C> hc{};               // host mirror
+    DevBuf d_consts, d_tables, d_winbase, d_bases;
+    bool consts_dirty = true;
+
+    int init(int dev) {
+        device = dev;
+        if (rt::set_device(dev)) return BBS_E_NO_DEVICE;
+        if (rt::stream_create(&stream)) return BBS_E_HIP;
+        std::memset(&hc, 0, sizeof(hc));
+        for (int j = 0; j < N; j++) { hc.p1.x.v[j] = C::K::P1X_M[j]; hc.p1.y.v[j] = C::K::P1Y_M[j]; }
+        build_schedule<C>(hc.sched);
+        if (!build_line_table<C>(g2_generator<C>(), hc.tab_bp2)) return BBS_E_ARG;
+        hc.tab_pk.q_is_identity = 1;
+        hc.tab_pk.n_lines = 0;
+        if (d_consts.alloc(sizeof(CtxConsts<C>))) return BBS_E_NOMEM;
+        return BBS_OK;
+    }
+    ~Ctx() override { rt::stream_destroy(stream); }
+
+    int use() { return rt::set_device(device) ? BBS_E_HIP : BBS_OK; }
+
+    // domain prefix:  Z_pad || compress(pk) || I2OSP(L,8) || compress(Q1) || compress(H_i).. || api_id
+    void rebuild_hash() {
+        HashCtx& h = hc.hash;
+        std::memset(&h, 0, sizeof(h));
+        std::vector<uint8_t> dst(api_id);
+        const char* suf = "H2S_";
+        dst.insert(dst.end(), suf, suf + 4);
+        dst_too_long = dst.size() > 255;
+        if (!dst_too_long) { std::memcpy(h.dst_h2s, dst.data(), dst.size()); h.dst_h2s_len = (uint32_t)dst.size(); }
+        if (!(gens_set && pk_set)) { consts_dirty = true; return; }
+        Sha256 s;
+        xmd48_begin(s);
+        uint8_t buf[4 * FPB];
+        g2_compress<C>(pk, buf);
+        sha256_bytes(s, buf, 2 * FPB);
+        sha256_u64be(s, (uint64_t)L);
+        for (const auto& g : gens) { g1_compress_host<C>(g, buf); sha256_bytes(s, buf, FPB); }
+        sha256_bytes(s, api_id.data(), (uint32_t)api_id.size());
+        for (int k = 0; k < 8; k++) h.dom_mid[k] = s.h[k];
+        h.dom_mid_total = s.total - s.fill;
+        h.dom_tail_len = s.fill;
+        for (uint32_t k = 0; k < s.fill; k++) h.dom_tail[k] = (uint8_t)(s.w[k >> 2] >> ((3 - (k & 3)) * 8));
+        consts_dirty = true;
+    }
+
+    int sync_consts() {
+        if (!consts_dirty) return BBS_OK;
+        hc.tables = d_tables.as<uint32_t>();
+        if (rt::h2d(d_consts.p, &hc, sizeof(hc), stream)) return BBS_E_HIP;
+        consts_dirty = false;
+        return BBS_OK;
+    }
+
+    int set_generators(const uint8_t* g, size_t count, const uint8_t* aid, size_t aid_len);   // op_prim.hpp
+
+    int set_pk_internal(const G2Aff<C>& q) {
+        if (!g2_on_curve<C>(q) || !g2_in_subgroup<C>(q)) return BBS_E_PUBLIC_KEY;
+        if (!build_line_table<C>(q, hc.tab_pk)) return BBS_E_PUBLIC_KEY;
+        pk = q;
+        pk_set = true;
+        rebuild_hash();
+        return BBS_OK;
+    }
+    int set_public_key(const uint8_t* b, int is_identity) {
+        G2Aff<C> q{};
+        q.inf = is_identity != 0;
+        if (!q.inf) {
+            if (!b) return BBS_E_ARG;
+            using P = typename C::FpP;
+            if (!fe_from_le_bytes<P>(b, q.x.c0) || !fe_from_le_bytes<P>(b + FPB, q.x.c1) ||
+                !fe_from_le_bytes<P>(b + 2 * FPB, q.y.c0) || !fe_from_le_bytes<P>(b + 3 * FPB, q.y.c1))
+                return BBS_E_PUBLIC_KEY;
+        } else {
+            q.x = f2_zero<C>(); q.y = f2_zero<C>();
+        }
+        sk_set = false;
+        return set_pk_internal(q);
+    }
+    int set_secret_key(const uint8_t* sk32) {
+        if (!sk32) return BBS_E_ARG;
+        uint32_t l[8];
+        for (int k = 0; k < 8; k++) l[k] = le32(sk32 + 4 * k);
+        if (!limbs_lt_mod<typename C::FrP>(l)) return BBS_E_ARG;
+        std::memcpy(sk, l, sizeof(sk));
+        int rc = set_pk_internal(g2_mul<C>(g2_generator<C>(), l));     // key_gen.rs:83-90
+        if (rc) return rc;
+        sk_set = true;
+        return BBS_OK;
+    }
+    int get_public_key(uint8_t* out, int* inf) {
+        if (!pk_set) return BBS_E_STATE;
+        using P = typename C::FpP;
+        if (inf) *inf = pk.inf ? 1 : 0;
+        if (out) {
+            if (pk.inf) std::memset(out, 0, 4 * FPB);
+            else {
+                fe_to_le_bytes<P>(pk.x.c0, out); fe_to_le_bytes<P>(pk.x.c1, out + FPB);
+                fe_to_le_bytes<P>(pk.y.c0, out + 2 * FPB); fe_to_le_bytes<P>(pk.y.c1, out + 3 * FPB);
+            }
+        }
+        return BBS_OK;
+    }
+};
+
+// =============================================================================================
+// jobs
+// =============================================================================================
+struct bbs_job {
+    size_t n = 0;
+    virtual ~bbs_job() {}
+    struct Stage { const char* name; std::function<int()> launch; };
+    std::vector<Stage> stages;
+    virtual int use() = 0;
+    virtual rt::Stream& stream() = 0;
+    virtual int reset() = 0;                     // restore the pre-run status so the job can run again
+    virtual int fetch_status(int8_t*) = 0;
+    virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
+    virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }
+    int run() {
+        if (use()) return BBS_E_HIP;
+        if (reset()) return BBS_E_HIP;
+        for (auto& s : stages) if (s.launch()) return BBS_E_HIP;
+        return BBS_OK;
+    }
+    int wait() { return (use() || rt::sync(stream())) ? BBS_E_HIP : BBS_OK; }
+};
+
+template <class C>
+struct JobBase : bbs_job {
+    Ctx<C>* ctx;
+    std::vector<int8_t> status0;     // host-validated initial status (1 placeholder = to compute)
+    DevBuf d_status;
+    std::vector<std::unique_ptr<DevBuf>> bufs;
+    explicit JobBase(Ctx<C>* c) : ctx(c) {}
+    int use() override { return ctx->use(); }
+    rt::Stream& stream() override { return ctx->stream; }
+    int reset() override { return rt::h2d(d_status.p, status0.data(), n, ctx->stream) ? BBS_E_HIP : BBS_OK; }
+    int fetch_status(int8_t* out) override {
+        if (use() || rt::sync(ctx->stream)) return BBS_E_HIP;
+        return rt::d2h(out, d_status.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
+    }
+    // upload a host vector, return device pointer (owned by the job)
+    template <class T>
+    T* up(const std::vector<T>& v, int& rc) {
+        bufs.emplace_back(new DevBuf());
+        DevBuf& b = *bufs.back();
+        if (b.alloc(v.size() * sizeof(T))) { rc = BBS_E_NOMEM; return nullptr; }
+        if (rt::h2d(b.p, v.data(), v.size() * sizeof(T), ctx->stream)) { rc = BBS_E_HIP; return nullptr; }
+        return b.as<T>();
+    }
+    template <class T>
+    T* scratch(size_t count, int& rc) {
+        bufs.emplace_back(new DevBuf());
+        DevBuf& b = *bufs.back();
+        if (b.alloc(count * sizeof(T))) { rc = BBS_E_NOMEM; return nullptr; }
+        return b.as<T>();
+    }
+    int finish_setup() {
+        if (d_status.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        return ctx->sync_consts();
+    }
+    template <class T>
+    int down(std::vector<T>& v, const T* dptr) {
+        return rt::d2h(v.data(), dptr, v.size() * sizeof(T), ctx->stream) ? BBS_E_HIP : BBS_OK;
+    }
+};
+

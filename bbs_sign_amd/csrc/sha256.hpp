@@ -18,7 +18,7 @@ struct Sha256 {
 
 BBS_HD uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
-__host__ __device__ inline void sha256_compress(uint32_t* h, const uint32_t* blk) {
+BBS_HD_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* blk) {
     const uint32_t K[64] = {
         0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
         0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
@@ -71,7 +71,7 @@ BBS_HD void sha256_init_mid(Sha256& s, const uint32_t* mid, uint64_t total) {
     s.total = total;
 }
 
-__host__ __device__ inline void sha256_byte(Sha256& s, uint32_t b) {
+BBS_HD_NOINLINE void sha256_byte(Sha256& s, uint32_t b) {
     const uint32_t wi = s.fill >> 2, sh = (3 - (s.fill & 3)) * 8;
     // select-update instead of a dynamically indexed store keeps w[] in registers
 #pragma unroll
@@ -87,7 +87,7 @@ __host__ __device__ inline void sha256_byte(Sha256& s, uint32_t b) {
 }
 
 // absorb one big-endian 32-bit word (fast path when the stream is word aligned)
-__host__ __device__ inline void sha256_word(Sha256& s, uint32_t wv) {
+BBS_HD_NOINLINE void sha256_word(Sha256& s, uint32_t wv) {
     if ((s.fill & 3) == 0) {
         const uint32_t wi = s.fill >> 2;
 #pragma unroll
@@ -106,7 +106,7 @@ __host__ __device__ inline void sha256_word(Sha256& s, uint32_t wv) {
     }
 }
 
-__host__ __device__ inline void sha256_bytes(Sha256& s, const uint8_t* p, uint32_t n) {
+BBS_HD_NOINLINE void sha256_bytes(Sha256& s, const uint8_t* p, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) sha256_byte(s, p[i]);
 }
 
@@ -115,7 +115,7 @@ BBS_HD void sha256_u64be(Sha256& s, uint64_t v) {
     sha256_word(s, (uint32_t)v);
 }
 
-__host__ __device__ inline void sha256_final(Sha256& s, uint32_t* out8) {
+BBS_HD_NOINLINE void sha256_final(Sha256& s, uint32_t* out8) {
     const uint64_t bits = s.total * 8;
     sha256_byte(s, 0x80);
     while (s.fill != 56) sha256_byte(s, 0);
@@ -138,12 +138,12 @@ BBS_HD void xmd48_begin(Sha256& s) {
     s.total = 64;
 }
 
-__host__ __device__ inline void xmd_dst_prime(Sha256& s, const uint8_t* dst, uint32_t dst_len) {
+BBS_HD_NOINLINE void xmd_dst_prime(Sha256& s, const uint8_t* dst, uint32_t dst_len) {
     sha256_bytes(s, dst, dst_len);
     sha256_byte(s, dst_len);
 }
 
-__host__ __device__ inline void xmd48_finish(Sha256& s, const uint8_t* dst, uint32_t dst_len, uint32_t* out12) {
+BBS_HD_NOINLINE void xmd48_finish(Sha256& s, const uint8_t* dst, uint32_t dst_len, uint32_t* out12) {
     // l_i_b_str = I2OSP(48, 2) || I2OSP(0, 1)
     sha256_byte(s, 0); sha256_byte(s, 48); sha256_byte(s, 0);
     xmd_dst_prime(s, dst, dst_len);

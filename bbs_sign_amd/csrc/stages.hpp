@@ -1,0 +1,918 @@
+// Per-item device stages of the four batched BBS+ core operations.
+//
+// Every stage is a __host__ __device__ "item function" run by one GPU lane; the __global__
+// wrappers live in capi.hip.  Batch data is SoA in HBM: word w of item i of an array is at
+// base[w * n + i], so the 64 lanes of a wavefront (64 consecutive items) read 256 contiguous
+// bytes per word -- coalesced.
+//
+// Work split (MI355X: 1024 SIMDs, a batch of 4096 items is only 64 wavefronts, so each item is
+// split over several lanes wherever the algebra allows):
+//   * a multi-scalar multiplication is cut into PARTS -- one variable-base scalar multiplication
+//     each, plus NFIX chunks of the fixed-base (windowed, precomputed-table) sum -- every part on
+//     its own lane (part-major thread index: a wavefront runs one kind of part);
+//   * the two Miller loops of a pairing product run on two lanes and are multiplied before the
+//     single shared final exponentiation.
+//
+// Algebraic restructurings (bit-identical group elements / booleans):
+//   proof_verify: T2 = Bv*c + D*r3^ + sum H_j m^_j  with  Bv = P1 + Q1*domain + sum H_i m_i
+//                 (src/proof_verify.rs:165-182) is evaluated as ONE fixed-base sum over
+//                 {P1, Q1, H_*} with scalars {c, domain*c, m_i*c | m^_j} plus D*r3^.
+//   verify      : e(A, W + e*BP2) * e(B, -BP2) == 1  (src/verify.rs:88-92)
+//                 <=>  e(A, W) * e(e*A - B, BP2) == 1 : both G2 arguments fixed.
+//   sign        : A = B * (sk+e)^-1 (src/sign.rs:128-130) = fixed-base sum with scalars * inv.
+//   proof_gen   : D, Abar, Bbar, T1, T2 (src/proof_gen.rs:249-263) as fixed-base sums over B's
+//                 terms plus scalar multiples of the signature point A.
+#pragma once
+#include "pairing.hpp"
+#include "sha256.hpp"
+
+namespace bbs {
+
+constexpr int NFIX = 2;          // fixed-base chunks per MSM
+constexpr int MAX_DST = 255;
+
+// ---- context constants resident in HBM ------------------------------------------------------
+struct HashCtx {
+    uint32_t dom_mid[8];         // SHA-256 state after Z_pad || domain prefix, at a block boundary
+    uint64_t dom_mid_total;
+    uint8_t dom_tail[64];
+    uint32_t dom_tail_len;
+    uint8_t dst_h2s[256];        // api_id || "H2S_"
+    uint32_t dst_h2s_len;
+};
+
+template <class C>
+struct CtxConsts {
+    HashCtx hash;
+    G1Aff<C> p1;                 // Montgomery form
+    int L;                       // number of message generators
+    int n_bases;                 // L + 2 : P1, Q1, H_1..H_L
+    int win_bits;                // c
+    int n_windows;               // ceil(256 / c)
+    const uint32_t* tables;      // [base][window][digit-1][2N] affine Montgomery
+    MillerSchedule sched;
+    LineTable<C> tab_pk;         // lines of W = pk
+    LineTable<C> tab_bp2;        // lines of BP2
+};
+
+// ---- SoA helpers ----------------------------------------------------------------------------
+template <int NW>
+BBS_HD void soa_ld(const uint32_t* base, size_t n, size_t i, uint32_t* out) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) out[w] = base[(size_t)w * n + i];
+}
+template <int NW>
+BBS_HD void soa_st(uint32_t* base, size_t n, size_t i, const uint32_t* v) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) base[(size_t)w * n + i] = v[w];
+}
+
+template <class C>
+BBS_HD Fr<C> fr_load_canon(const uint32_t* base, size_t n, size_t i) {   // canonical limbs, no conversion
+    Fr<C> r;
+    soa_ld<8>(base, n, i, r.v);
+    return r;
+}
+template <class C>
+BBS_HD Fr<C> fr_to_mont(const Fr<C>& canon) { return fe_from_limbs<typename C::FrP>(canon.v); }
+
+template <class C>
+BBS_HD G1Aff<C> g1a_load_canon_to_mont(const uint32_t* base, size_t n, size_t i) {
+    constexpr int N = C::FpP::N;
+    uint32_t w[2 * N];
+    soa_ld<2 * N>(base, n, i, w);
+    G1Aff<C> p;
+    p.x = fe_from_limbs<typename C::FpP>(w);
+    p.y = fe_from_limbs<typename C::FpP>(w + N);
+    return p;
+}
+template <class C>
+BBS_HD G1Aff<C> g1a_load_mont(const uint32_t* base, size_t n, size_t i) {
+    constexpr int N = C::FpP::N;
+    G1Aff<C> p;
+    soa_ld<N>(base, n, i, p.x.v);
+    soa_ld<N>(base + (size_t)N * n, n, i, p.y.v);
+    return p;
+}
+template <class C>
+BBS_HD void g1a_store_mont(uint32_t* base, size_t n, size_t i, const G1Aff<C>& p) {
+    constexpr int N = C::FpP::N;
+    soa_st<N>(base, n, i, p.x.v);
+    soa_st<N>(base + (size_t)N * n, n, i, p.y.v);
+}
+template <class C>
+BBS_HD void g1a_store_canon(uint32_t* base, size_t n, size_t i, const G1Aff<C>& p) {
+    constexpr int N = C::FpP::N;
+    Fp<C> x = fe_to_canonical<typename C::FpP>(p.x), y = fe_to_canonical<typename C::FpP>(p.y);
+    soa_st<N>(base, n, i, x.v);
+    soa_st<N>(base + (size_t)N * n, n, i, y.v);
+}
+template <class C>
+BBS_HD G1Jac<C> g1j_load(const uint32_t* base, size_t n, size_t i) {
+    constexpr int N = C::FpP::N;
+    G1Jac<C> p;
+    soa_ld<N>(base, n, i, p.x.v);
+    soa_ld<N>(base + (size_t)N * n, n, i, p.y.v);
+    soa_ld<N>(base + (size_t)2 * N * n, n, i, p.z.v);
+    return p;
+}
+template <class C>
+BBS_HD void g1j_store(uint32_t* base, size_t n, size_t i, const G1Jac<C>& p) {
+    constexpr int N = C::FpP::N;
+    soa_st<N>(base, n, i, p.x.v);
+    soa_st<N>(base + (size_t)N * n, n, i, p.y.v);
+    soa_st<N>(base + (size_t)2 * N * n, n, i, p.z.v);
+}
+
+// ---- hashing helpers ------------------------------------------------------------------------
+// ark-serialize compressed G1 absorbed into a hash (core_utilities.rs:39-47, proof_gen.rs:304-311)
+template <class C>
+__host__ __device__ inline void sha256_g1_compressed(Sha256& s, const G1Aff<C>& p) {
+    using P = typename C::FpP;
+    constexpr int N = P::N;
+    const bool inf = g1a_is_inf<C>(p);
+    Fp<C> x = fe_to_canonical<P>(p.x);
+    const bool ybig = canonical_gt_half<P>(fe_to_canonical<P>(p.y));
+    if constexpr (C::ID == 0) {
+        // 48 bytes big-endian, flags in the first byte
+        uint32_t flags = inf ? 0xC0000000u : (0x80000000u | (ybig ? 0x20000000u : 0u));
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+            uint32_t w = inf ? 0u : x.v[i];
+            if (i == N - 1) w |= flags;
+            sha256_word(s, w);
+        }
+    } else {
+        // 32 bytes little-endian, flags in the last byte
+        uint32_t flags = inf ? 0x40u : (ybig ? 0x80u : 0u);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint32_t l = inf ? 0u : x.v[i];
+            uint32_t w = (l << 24) | ((l & 0xff00u) << 8) | ((l >> 8) & 0xff00u) | (l >> 24);   // bswap
+            if (i == N - 1) w |= flags;
+            sha256_word(s, w);
+        }
+    }
+}
+
+// calculate_domain (core_utilities.rs:24-63) from the cached prefix midstate
+template <class C>
+__host__ __device__ inline Fr<C> domain_from_header(const HashCtx& h, const uint8_t* hdr, uint32_t hdr_len) {
+    Sha256 s;
+    sha256_init_mid(s, h.dom_mid, h.dom_mid_total);
+    sha256_bytes(s, h.dom_tail, h.dom_tail_len);
+    sha256_u64be(s, hdr_len);
+    sha256_bytes(s, hdr, hdr_len);
+    uint32_t okm[12];
+    xmd48_finish(s, h.dst_h2s, h.dst_h2s_len, okm);
+    return fr_from_okm<C>(okm);
+}
+
+// ---- multi-scalar multiplication parts --------------------------------------------------------
+// one chunk of the fixed-base sum: terms are (base k, window w) pairs, flattened index t = k*W + w,
+// chunk f of NFIX handles t in [f*T/NFIX, (f+1)*T/NFIX).
+template <class C>
+__host__ __device__ inline G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
+                                                    int n_terms, int chunk) {
+    constexpr int N = C::FpP::N;
+    const int W = cc.n_windows, c = cc.win_bits;
+    const int T = n_terms * W;
+    const int t0 = (int)(((long long)T * chunk) / NFIX), t1 = (int)(((long long)T * (chunk + 1)) / NFIX);
+    const size_t per_win = ((size_t)1 << c) - 1;
+    G1Jac<C> acc = g1j_inf<C>();
+    int k_cur = -1;
+    uint32_t sc[8];
+    for (int t = t0; t < t1; t++) {
+        const int k = t / W, w = t - k * W;
+        if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); k_cur = k; }
+        // digit = bits [w*c, w*c + c) of the scalar
+        const int bit = w * c;
+        const int li = bit >> 5, sh = bit & 31;
+        uint64_t two = sc[li];
+        if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
+        uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
+        if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
+        if (d == 0) continue;
+        const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
+        G1Aff<C> q;
+#pragma unroll
+        for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
+        acc = g1j_add_aff<C>(acc, q);
+    }
+    return acc;
+}
+
+// shared inversion for two Jacobian points -> affine (Montgomery trick), identities preserved
+template <class C>
+__host__ __device__ inline void g1j_to_aff2(const G1Jac<C>& a, const G1Jac<C>& b, G1Aff<C>& oa, G1Aff<C>& ob) {
+    using P = typename C::FpP;
+    const bool ia = g1j_is_inf<C>(a), ib = g1j_is_inf<C>(b);
+    Fp<C> za = ia ? fe_one<P>() : a.z, zb = ib ? fe_one<P>() : b.z;
+    Fp<C> inv = fe_inv<P>(fe_mul<P>(za, zb));
+    Fp<C> zai = fe_mul<P>(inv, zb), zbi = fe_mul<P>(inv, za);
+    Fp<C> zai2 = fe_sqr<P>(zai), zbi2 = fe_sqr<P>(zbi);
+    oa = ia ? g1a_inf<C>() : G1Aff<C>{fe_mul<P>(a.x, zai2), fe_mul<P>(fe_mul<P>(a.y, zai2), zai)};
+    ob = ib ? g1a_inf<C>() : G1Aff<C>{fe_mul<P>(b.x, zbi2), fe_mul<P>(fe_mul<P>(b.y, zbi2), zbi)};
+}
+
+// =============================================================================================
+// proof_verify
+// =============================================================================================
+constexpr int PV_NVAR = 4;                    // c*Bbar, e^*Abar, r1^*D, r3^*D
+constexpr int PV_NPARTS = PV_NVAR + NFIX;
+
+template <class C>
+struct PvArgs {
+    size_t n;
+    int L, Rmax;
+    const CtxConsts<C>* cc;
+    // inputs (canonical limbs, SoA)
+    const uint32_t* pts;      // [3][2N][n]  a_bar, b_bar, d
+    const uint32_t* sc;       // [4][8][n]   e_cap, r1_cap, r3_cap, challenge
+    const uint32_t* slots;    // [L][8][n]   slot j: disclosed message m_j or commitment m^_j
+    const uint32_t* dmask;    // [ceil(L/32)][n]
+    const uint32_t* didx;     // [Rmax][n]   disclosed indexes in caller order
+    const uint32_t* rcount;   // [n]
+    const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
+    const uint32_t* ph_off;  const uint32_t* ph_len;  const uint8_t* ph_bytes;
+    int8_t* status;           // [n]; < 0 preset by host validation; 2 = pairing pending
+    // intermediates
+    uint32_t* dom;            // [8][n] domain, Montgomery
+    uint32_t* fscal;          // [L+2][8][n] canonical fixed-base scalars
+    uint32_t* partials;       // [PV_NPARTS][3N][n] Jacobian
+    uint32_t* aff;            // [5][2N][n] Montgomery affine: a_bar, b_bar, d, T1, T2
+    uint32_t* fmiller;        // [2][12N][n]
+};
+
+// stage 1 (lane per item): domain, fixed-base scalars
+template <class C>
+struct PvScalars {
+    static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        if (a.status[i] < 0) return;
+        const size_t n = a.n;
+        Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
+        soa_st<8>(a.dom, n, i, dom.v);
+        Fr<C> c_canon = fr_load_canon<C>(a.sc + (size_t)3 * 8 * n, n, i);
+        Fr<C> c_m = fr_to_mont<C>(c_canon);
+        // P1 * c
+        soa_st<8>(a.fscal, n, i, c_canon.v);
+        // Q1 * (domain * c) : mont_mul(dom_mont, c_canon) = dom*c canonical... dom is Montgomery:
+        Fr<C> dc = fe_mul<R>(dom, c_canon);                 // (dom*R)*c/R = dom*c canonical
+        soa_st<8>(a.fscal + (size_t)1 * 8 * n, n, i, dc.v);
+        for (int j = 0; j < a.L; j++) {
+            Fr<C> s = fr_load_canon<C>(a.slots + (size_t)j * 8 * n, n, i);
+            const uint32_t m = a.dmask[(size_t)(j >> 5) * n + i];
+            if ((m >> (j & 31)) & 1u) s = fe_mul<R>(c_m, s);    // (c*R)*m/R = c*m canonical
+            soa_st<8>(a.fscal + (size_t)(2 + j) * 8 * n, n, i, s.v);
+        }
+    }
+};
+
+// stage 2 (lane per (part, item)): MSM parts
+template <class C>
+struct PvMsmPart {
+    static __host__ __device__ void run(const PvArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
+        if (part < PV_NVAR) {
+            // part: 0 c*Bbar | 1 e^*Abar | 2 r1^*D | 3 r3^*D
+            const int pt = (part == 0) ? 1 : (part == 1) ? 0 : 2;
+            const int scw = (part == 0) ? 3 : (part == 1) ? 0 : (part == 2) ? 1 : 2;
+            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * N * n, n, i);
+            if (part < 3) {
+                if (!g1a_on_curve<C>(p)) { a.status[i] = -41; return; }
+                g1a_store_mont<C>(a.aff + (size_t)pt * 2 * N * n, n, i, p);
+            }
+            uint32_t k[8];
+            soa_ld<8>(a.sc + (size_t)scw * 8 * n, n, i, k);
+            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+        } else {
+            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - PV_NVAR));
+        }
+    }
+};
+
+// stage 3 (lane per item): combine parts, normalise, challenge hash, compare
+template <class C>
+struct PvChallenge {
+    static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
+        G1Jac<C> t1 = g1j_add<C>(g1j_add<C>(part(0), part(1)), part(2));
+        G1Jac<C> t2 = part(3);
+        for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(PV_NVAR + f));
+        G1Aff<C> T1, T2;
+        g1j_to_aff2<C>(t1, t2, T1, T2);
+        // challenge (proof_gen.rs:272-328)
+        Sha256 s;
+        xmd48_begin(s);
+        const uint32_t R = a.rcount[i];
+        sha256_u64be(s, R);
+        for (uint32_t k = 0; k < R; k++) {
+            const uint32_t idx = a.didx[(size_t)k * n + i];
+            sha256_u64be(s, idx);
+            uint32_t m[8];
+            soa_ld<8>(a.slots + (size_t)idx * 8 * n, n, i, m);
+            sha256_limbs_be8(s, m);
+        }
+        for (int p = 0; p < 3; p++) sha256_g1_compressed<C>(s, g1a_load_mont<C>(a.aff + (size_t)p * 2 * N * n, n, i));
+        sha256_g1_compressed<C>(s, T1);
+        sha256_g1_compressed<C>(s, T2);
+        Fr<C> dom;
+        soa_ld<8>(a.dom, n, i, dom.v);
+        sha256_fr_be<C>(s, dom);
+        sha256_u64be(s, a.ph_len[i]);
+        sha256_bytes(s, a.ph_bytes + a.ph_off[i], a.ph_len[i]);
+        uint32_t okm[12];
+        xmd48_finish(s, a.cc->hash.dst_h2s, a.cc->hash.dst_h2s_len, okm);
+        Fr<C> chal = fe_to_canonical<typename C::FrP>(fr_from_okm<C>(okm));
+        Fr<C> c = fr_load_canon<C>(a.sc + (size_t)3 * 8 * n, n, i);
+        // proof_verify.rs:108-110: mismatch -> Ok(false) before any pairing
+        a.status[i] = fe_eq<typename C::FrP>(chal, c) ? 2 : 0;
+    }
+};
+
+// generic pairing stages: e(Pa, pk) * e(Pb, BP2) == 1 for items whose status is 2
+template <class C>
+struct PairArgs {
+    size_t n;
+    const CtxConsts<C>* cc;
+    const uint32_t* pa;       // [2N][n] Montgomery affine
+    const uint32_t* pb;       // [2N][n]
+    int negate_b;             // use -Pb (e(P, -Q) = e(-P, Q))
+    int8_t* status;
+    uint32_t* fmiller;        // [2][12N][n]
+};
+
+template <class C>
+BBS_HD void f12_store(uint32_t* base, size_t n, size_t i, const Fp12<C>& f) {
+    constexpr int N = C::FpP::N;
+    const Fp<C>* e = reinterpret_cast<const Fp<C>*>(&f);
+    for (int k = 0; k < 12; k++) soa_st<N>(base + (size_t)k * N * n, n, i, e[k].v);
+}
+template <class C>
+BBS_HD Fp12<C> f12_load(const uint32_t* base, size_t n, size_t i) {
+    constexpr int N = C::FpP::N;
+    Fp12<C> f;
+    Fp<C>* e = reinterpret_cast<Fp<C>*>(&f);
+    for (int k = 0; k < 12; k++) soa_ld<N>(base + (size_t)k * N * n, n, i, e[k].v);
+    return f;
+}
+
+// lane per (pair, item)
+template <class C>
+struct PairMiller {
+    static __host__ __device__ void run(const PairArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int pair = (int)(t / n);
+        const size_t i = t - (size_t)pair * n;
+        if (a.status[i] != 2) return;
+        G1Aff<C> P = g1a_load_mont<C>(pair == 0 ? a.pa : a.pb, n, i);
+        if (pair == 1 && a.negate_b) P = g1a_neg<C>(P);
+        const LineTable<C>* tab = pair == 0 ? &a.cc->tab_pk : &a.cc->tab_bp2;
+        Fp12<C> f = f12_one<C>();
+        const bool skip = g1a_is_inf<C>(P) | (tab->q_is_identity != 0);
+        if (!skip) {
+            int li = 0;
+            const int nops = a.cc->sched.n_ops;
+            for (int k = 0; k < nops; k++) {
+                if (a.cc->sched.op[k] == 0) f = f12_sqr<C>(f);
+                else f = f12_mul_line<C>(f, tab->e[li++], P);
+            }
+            if constexpr (C::K::X_NEG) f = f12_conj<C>(f);
+        }
+        f12_store<C>(a.fmiller + (size_t)pair * 12 * N * n, n, i, f);
+    }
+};
+
+// lane per item
+template <class C>
+struct PairFinal {
+    static __host__ __device__ void run(const PairArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] != 2) return;
+        Fp12<C> f = f12_mul<C>(f12_load<C>(a.fmiller, n, i), f12_load<C>(a.fmiller + (size_t)12 * N * n, n, i));
+        a.status[i] = f12_is_one<C>(final_exponentiation<C>(f)) ? 1 : 0;
+    }
+};
+
+// n-point batch normalisation (one inversion), identities preserved
+template <class C, int K>
+__host__ __device__ inline void g1j_batch_to_aff(const G1Jac<C>* in, G1Aff<C>* out) {
+    using P = typename C::FpP;
+    Fp<C> pre[K];
+    Fp<C> acc = fe_one<P>();
+    for (int k = 0; k < K; k++) {
+        pre[k] = acc;
+        if (!g1j_is_inf<C>(in[k])) acc = fe_mul<P>(acc, in[k].z);
+    }
+    Fp<C> inv = fe_inv<P>(acc);
+    for (int k = K - 1; k >= 0; k--) {
+        if (g1j_is_inf<C>(in[k])) { out[k] = g1a_inf<C>(); continue; }
+        Fp<C> zi = fe_mul<P>(inv, pre[k]);
+        inv = fe_mul<P>(inv, in[k].z);
+        Fp<C> zi2 = fe_sqr<P>(zi);
+        out[k] = {fe_mul<P>(in[k].x, zi2), fe_mul<P>(fe_mul<P>(in[k].y, zi2), zi)};
+    }
+}
+
+// =============================================================================================
+// fixed-base table construction (once per generator set)
+// =============================================================================================
+template <class C>
+struct TabArgs {
+    int n_bases, win_bits, n_windows;
+    const uint32_t* bases;    // [n_bases][2N] Montgomery affine (AoS)
+    uint32_t* winbase;        // [n_bases][W][2N] : 2^(c*w) * G_k
+    uint32_t* tables;         // [n_bases][W][2^c - 1][2N]
+};
+
+// lane per base: the W window bases by repeated doubling
+template <class C>
+struct TabWinBase {
+    static __host__ __device__ void run(const TabArgs<C>& a, size_t k) {
+        constexpr int N = C::FpP::N;
+        G1Aff<C> b;
+        for (int j = 0; j < N; j++) { b.x.v[j] = a.bases[k * 2 * N + j]; b.y.v[j] = a.bases[k * 2 * N + N + j]; }
+        for (int w = 0; w < a.n_windows; w++) {
+            uint32_t* o = a.winbase + ((size_t)k * a.n_windows + w) * 2 * N;
+            for (int j = 0; j < N; j++) { o[j] = b.x.v[j]; o[N + j] = b.y.v[j]; }
+            G1Jac<C> t = g1j_from_aff<C>(b);
+            for (int d = 0; d < a.win_bits; d++) t = g1j_dbl<C>(t);
+            b = g1j_to_aff<C>(t);
+        }
+    }
+};
+
+// lane per table entry (k, w, d): d * winbase[k][w], affine
+template <class C>
+struct TabEntry {
+    static __host__ __device__ void run(const TabArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t per_win = ((size_t)1 << a.win_bits) - 1;
+        const size_t kw = t / per_win;
+        const uint32_t d = (uint32_t)(t - kw * per_win) + 1;
+        const uint32_t* bsrc = a.winbase + kw * 2 * N;
+        G1Aff<C> b;
+        for (int j = 0; j < N; j++) { b.x.v[j] = bsrc[j]; b.y.v[j] = bsrc[N + j]; }
+        G1Jac<C> r = g1j_inf<C>();
+        for (int i = a.win_bits - 1; i >= 0; i--) {
+            r = g1j_dbl<C>(r);
+            if ((d >> i) & 1u) r = g1j_add_aff<C>(r, b);
+        }
+        G1Aff<C> o = g1j_to_aff<C>(r);
+        uint32_t* dst = a.tables + t * 2 * N;
+        for (int j = 0; j < N; j++) { dst[j] = o.x.v[j]; dst[N + j] = o.y.v[j]; }
+    }
+};
+
+// =============================================================================================
+// verify
+// =============================================================================================
+constexpr int VF_NPARTS = 1 + NFIX;
+
+template <class C>
+struct VfArgs {
+    size_t n;
+    int L;
+    const CtxConsts<C>* cc;
+    const uint32_t* sig_a;    // [2N][n] canonical
+    const uint32_t* sig_e;    // [8][n]
+    const uint32_t* msgs;     // [L][8][n]
+    const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
+    int8_t* status;
+    uint32_t* fscal;          // [L+2][8][n]
+    uint32_t* partials;       // [VF_NPARTS][3N][n]
+    uint32_t* aff;            // [2][2N][n] : A, e*A - B  (Montgomery)
+    uint32_t* fmiller;
+};
+
+template <class C>
+struct VfScalars {
+    static __host__ __device__ void run(const VfArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        if (a.status[i] < 0) return;
+        const size_t n = a.n;
+        Fr<C> dom = fe_to_canonical<R>(domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]));
+        Fr<C> one = fe_zero<R>();
+        one.v[0] = 1;
+        soa_st<8>(a.fscal, n, i, one.v);
+        soa_st<8>(a.fscal + (size_t)8 * n, n, i, dom.v);
+        for (int j = 0; j < a.L; j++) {
+            uint32_t m[8];
+            soa_ld<8>(a.msgs + (size_t)j * 8 * n, n, i, m);
+            soa_st<8>(a.fscal + (size_t)(2 + j) * 8 * n, n, i, m);
+        }
+    }
+};
+
+template <class C>
+struct VfMsmPart {
+    static __host__ __device__ void run(const VfArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
+        if (part == 0) {
+            G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
+            if (!g1a_on_curve<C>(A)) { a.status[i] = -41; return; }
+            g1a_store_mont<C>(a.aff, n, i, A);
+            uint32_t k[8];
+            soa_ld<8>(a.sig_e, n, i, k);
+            g1j_store<C>(out, n, i, g1_mul_aff<C>(A, k));
+        } else {
+            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - 1));
+        }
+    }
+};
+
+template <class C>
+struct VfCombine {
+    static __host__ __device__ void run(const VfArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
+        G1Jac<C> b = part(1);
+        for (int f = 1; f < NFIX; f++) b = g1j_add<C>(b, part(1 + f));
+        G1Jac<C> x = g1j_add<C>(part(0), g1j_neg<C>(b));          // e*A - B
+        g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, g1j_to_aff<C>(x));
+        a.status[i] = 2;
+    }
+};
+
+// =============================================================================================
+// sign
+// =============================================================================================
+template <class C>
+struct SgArgs {
+    size_t n;
+    int L;
+    const CtxConsts<C>* cc;
+    uint32_t sk[8];           // canonical
+    const uint32_t* msgs;     // [L][8][n]
+    const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
+    int8_t* status;
+    uint32_t* fscal;          // [L+2][8][n]
+    uint32_t* partials;       // [NFIX][3N][n]
+    uint32_t* out_a;          // [2N][n] canonical
+    uint32_t* out_e;          // [8][n] canonical
+};
+
+template <class C>
+struct SgScalars {
+    static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        if (a.status[i] < 0) return;
+        const size_t n = a.n;
+        Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
+        // e = hash_to_scalar(sk || m_1 .. m_L || domain)   (sign.rs:90-118)
+        Sha256 s;
+        xmd48_begin(s);
+        sha256_limbs_be8(s, a.sk);
+        for (int j = 0; j < a.L; j++) {
+            uint32_t m[8];
+            soa_ld<8>(a.msgs + (size_t)j * 8 * n, n, i, m);
+            sha256_limbs_be8(s, m);
+        }
+        sha256_fr_be<C>(s, dom);
+        uint32_t okm[12];
+        xmd48_finish(s, a.cc->hash.dst_h2s, a.cc->hash.dst_h2s_len, okm);
+        Fr<C> e = fr_from_okm<C>(okm);
+        Fr<C> ec = fe_to_canonical<R>(e);
+        soa_st<8>(a.out_e, n, i, ec.v);
+        Fr<C> skm = fe_from_limbs<R>(a.sk);
+        Fr<C> spe = fe_add<R>(skm, e);
+        if (fe_is_zero<R>(spe)) { a.status[i] = -20; return; }     // sign.rs:129 unwrap
+        Fr<C> inv = fe_inv<R>(spe);                                 // Montgomery
+        Fr<C> invc = fe_to_canonical<R>(inv);
+        soa_st<8>(a.fscal, n, i, invc.v);
+        Fr<C> di = fe_mul<R>(dom, invc);                            // (dom R) inv / R = dom*inv canonical
+        soa_st<8>(a.fscal + (size_t)8 * n, n, i, di.v);
+        for (int j = 0; j < a.L; j++) {
+            Fr<C> m = fr_load_canon<C>(a.msgs + (size_t)j * 8 * n, n, i);
+            Fr<C> mi = fe_mul<R>(inv, m);
+            soa_st<8>(a.fscal + (size_t)(2 + j) * 8 * n, n, i, mi.v);
+        }
+    }
+};
+
+template <class C>
+struct SgMsmPart {
+    static __host__ __device__ void run(const SgArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        g1j_store<C>(a.partials + (size_t)part * 3 * N * n, n, i,
+                     fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part));
+    }
+};
+
+template <class C>
+struct SgCombine {
+    static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        G1Jac<C> acc = g1j_load<C>(a.partials, n, i);
+        for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)f * 3 * N * n, n, i));
+        g1a_store_canon<C>(a.out_a, n, i, g1j_to_aff<C>(acc));
+        a.status[i] = 1;
+    }
+};
+
+// =============================================================================================
+// proof_gen
+// =============================================================================================
+constexpr int PG_NVAR = 7;                  // 4 multiples of B, 3 multiples of A
+constexpr int PG_NPARTS = PG_NVAR + NFIX;   // + chunks of sum m~_j H_j
+
+template <class C>
+struct PgArgs {
+    size_t n;
+    int L, Rmax;
+    const CtxConsts<C>* cc;
+    const uint32_t* sig_a;    // [2N][n] canonical
+    const uint32_t* sig_e;    // [8][n]
+    const uint32_t* msgs;     // [L][8][n]
+    const uint32_t* dmask;    // [ceil(L/32)][n] disclosed slots
+    const uint32_t* didx;     // [Rmax][n] sorted distinct disclosed indexes
+    const uint32_t* rcount;   // [n] number of distinct disclosed indexes
+    const uint32_t* rnd5;     // [5][8][n]  r1, r2, e~, r1~, r3~
+    const uint32_t* mtilde;   // [L][8][n]  m~_j at undisclosed slots, 0 elsewhere
+    const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
+    const uint32_t* ph_off;  const uint32_t* ph_len;  const uint8_t* ph_bytes;
+    int8_t* status;
+    // intermediates
+    uint32_t* dom;            // [8][n] Montgomery
+    uint32_t* fscal;          // [L+2][8][n]  B's scalars (1, domain, m_j)
+    uint32_t* fscal2;         // [L+2][8][n]  (0, 0, m~_j)
+    uint32_t* vscal;          // [PG_NVAR][8][n] canonical scalars of the variable-base parts
+    uint32_t* bpart;          // [NFIX][3N][n]
+    uint32_t* baff;           // [2][2N][n]  B, A (Montgomery affine)
+    uint32_t* partials;       // [PG_NPARTS][3N][n]
+    // outputs (canonical)
+    uint32_t* out_pts;        // [3][2N][n]  a_bar, b_bar, d
+    uint32_t* out_sc;         // [4][8][n]   e^, r1^, r3^, c
+    uint32_t* out_mhat;       // [L][8][n]   m^_j at undisclosed slots
+};
+
+template <class C>
+struct PgScalars {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        if (a.status[i] < 0) return;
+        const size_t n = a.n;
+        Fr<C> r2c = fr_load_canon<C>(a.rnd5 + (size_t)1 * 8 * n, n, i);
+        Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
+        soa_st<8>(a.dom, n, i, dom.v);
+        Fr<C> domc = fe_to_canonical<R>(dom);
+        Fr<C> one = fe_zero<R>();
+        one.v[0] = 1;
+        Fr<C> zero = fe_zero<R>();
+        soa_st<8>(a.fscal, n, i, one.v);
+        soa_st<8>(a.fscal + (size_t)8 * n, n, i, domc.v);
+        soa_st<8>(a.fscal2, n, i, zero.v);
+        soa_st<8>(a.fscal2 + (size_t)8 * n, n, i, zero.v);
+        for (int j = 0; j < a.L; j++) {
+            uint32_t m[8];
+            soa_ld<8>(a.msgs + (size_t)j * 8 * n, n, i, m);
+            soa_st<8>(a.fscal + (size_t)(2 + j) * 8 * n, n, i, m);
+            soa_ld<8>(a.mtilde + (size_t)j * 8 * n, n, i, m);
+            soa_st<8>(a.fscal2 + (size_t)(2 + j) * 8 * n, n, i, m);
+        }
+        // variable-base scalars (proof_gen.rs:254-258, restructured over B and A)
+        Fr<C> r1 = fr_to_mont<C>(fr_load_canon<C>(a.rnd5, n, i));
+        Fr<C> r2 = fr_to_mont<C>(r2c);
+        Fr<C> et = fr_load_canon<C>(a.rnd5 + (size_t)2 * 8 * n, n, i);
+        Fr<C> r1t = fr_load_canon<C>(a.rnd5 + (size_t)3 * 8 * n, n, i);
+        Fr<C> r3t = fr_load_canon<C>(a.rnd5 + (size_t)4 * 8 * n, n, i);
+        Fr<C> e = fr_load_canon<C>(a.sig_e, n, i);
+        Fr<C> r1r2 = fe_mul<R>(r1, r2);                               // Montgomery
+        Fr<C> v[PG_NVAR];
+        v[0] = r2c;                                                   // D      = r2 * B
+        v[1] = fe_to_canonical<R>(r1r2);                              // r1r2 * B
+        v[2] = fe_mul<R>(r2, r1t);                                    // T1 part: (r1~ r2) * B
+        v[3] = fe_mul<R>(r2, r3t);                                    // T2 part: (r3~ r2) * B
+        v[4] = v[1];                                                  // Abar   = (r1 r2) * A
+        v[5] = fe_mul<R>(r1r2, e);                                    // (e r1 r2) * A
+        v[6] = fe_mul<R>(r1r2, et);                                   // (e~ r1 r2) * A
+        for (int k = 0; k < PG_NVAR; k++) soa_st<8>(a.vscal + (size_t)k * 8 * n, n, i, v[k].v);
+    }
+};
+
+// lane per (chunk, item): B = P1 + Q1*domain + sum H_j m_j
+template <class C>
+struct PgBPart {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        g1j_store<C>(a.bpart + (size_t)part * 3 * N * n, n, i,
+                     fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part));
+    }
+};
+
+template <class C>
+struct PgBCombine {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        G1Jac<C> acc = g1j_load<C>(a.bpart, n, i);
+        for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.bpart + (size_t)f * 3 * N * n, n, i));
+        g1a_store_mont<C>(a.baff, n, i, g1j_to_aff<C>(acc));
+        G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
+        if (!g1a_on_curve<C>(A)) { a.status[i] = -41; return; }
+        g1a_store_mont<C>(a.baff + (size_t)2 * N * n, n, i, A);
+    }
+};
+
+template <class C>
+struct PgMsmPart {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
+        if (part < PG_NVAR) {
+            G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part < 4 ? 0 : 1) * 2 * N * n, n, i);
+            uint32_t k[8];
+            soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
+            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+        } else {
+            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal2, n, i, a.L + 2, part - PG_NVAR));
+        }
+    }
+};
+
+template <class C>
+struct PgFinalize {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
+        G1Jac<C> pj[5];
+        pj[0] = part(4);                                              // Abar
+        pj[1] = g1j_add<C>(part(1), g1j_neg<C>(part(5)));             // Bbar = r1r2 B - e r1r2 A
+        pj[2] = part(0);                                              // D
+        pj[3] = g1j_add<C>(part(6), part(2));                         // T1
+        pj[4] = part(3);                                              // T2
+        for (int f = 0; f < NFIX; f++) pj[4] = g1j_add<C>(pj[4], part(PG_NVAR + f));
+        G1Aff<C> pa[5];
+        g1j_batch_to_aff<C, 5>(pj, pa);
+        // challenge (proof_gen.rs:272-328), disclosed indexes sorted + deduplicated (:151-161)
+        Sha256 s;
+        xmd48_begin(s);
+        const uint32_t Rn = a.rcount[i];
+        sha256_u64be(s, Rn);
+        for (uint32_t k = 0; k < Rn; k++) {
+            const uint32_t idx = a.didx[(size_t)k * n + i];
+            sha256_u64be(s, idx);
+            uint32_t m[8];
+            soa_ld<8>(a.msgs + (size_t)idx * 8 * n, n, i, m);
+            sha256_limbs_be8(s, m);
+        }
+        for (int p = 0; p < 5; p++) sha256_g1_compressed<C>(s, pa[p]);
+        Fr<C> dom;
+        soa_ld<8>(a.dom, n, i, dom.v);
+        sha256_fr_be<C>(s, dom);
+        sha256_u64be(s, a.ph_len[i]);
+        sha256_bytes(s, a.ph_bytes + a.ph_off[i], a.ph_len[i]);
+        uint32_t okm[12];
+        xmd48_finish(s, a.cc->hash.dst_h2s, a.cc->hash.dst_h2s_len, okm);
+        Fr<C> c = fr_from_okm<C>(okm);                                // Montgomery
+        // proof_finalize (proof_gen.rs:331-365)
+        Fr<C> r2 = fr_to_mont<C>(fr_load_canon<C>(a.rnd5 + (size_t)1 * 8 * n, n, i));
+        if (fe_is_zero<R>(r2)) { a.status[i] = -21; return; }         // :346 unwrap
+        Fr<C> r3 = fe_inv<R>(r2);
+        Fr<C> r1 = fr_to_mont<C>(fr_load_canon<C>(a.rnd5, n, i));
+        Fr<C> et = fr_to_mont<C>(fr_load_canon<C>(a.rnd5 + (size_t)2 * 8 * n, n, i));
+        Fr<C> r1t = fr_to_mont<C>(fr_load_canon<C>(a.rnd5 + (size_t)3 * 8 * n, n, i));
+        Fr<C> r3t = fr_to_mont<C>(fr_load_canon<C>(a.rnd5 + (size_t)4 * 8 * n, n, i));
+        Fr<C> e = fr_to_mont<C>(fr_load_canon<C>(a.sig_e, n, i));
+        Fr<C> o[4];
+        o[0] = fe_to_canonical<R>(fe_add<R>(et, fe_mul<R>(e, c)));
+        o[1] = fe_to_canonical<R>(fe_sub<R>(r1t, fe_mul<R>(r1, c)));
+        o[2] = fe_to_canonical<R>(fe_sub<R>(r3t, fe_mul<R>(r3, c)));
+        o[3] = fe_to_canonical<R>(c);
+        for (int k = 0; k < 4; k++) soa_st<8>(a.out_sc + (size_t)k * 8 * n, n, i, o[k].v);
+        for (int j = 0; j < a.L; j++) {
+            const uint32_t dm = a.dmask[(size_t)(j >> 5) * n + i];
+            if ((dm >> (j & 31)) & 1u) continue;
+            Fr<C> m = fr_load_canon<C>(a.msgs + (size_t)j * 8 * n, n, i);       // canonical
+            Fr<C> mt = fr_load_canon<C>(a.mtilde + (size_t)j * 8 * n, n, i);   // canonical
+            // m~ + m*c : mont_mul(c_mont, m_canon) = m*c canonical ; add canonical values mod r
+            Fr<C> mh = fe_add<R>(mt, fe_mul<R>(c, m));
+            soa_st<8>(a.out_mhat + (size_t)j * 8 * n, n, i, mh.v);
+        }
+        for (int p = 0; p < 3; p++) g1a_store_canon<C>(a.out_pts + (size_t)p * 2 * N * n, n, i, pa[p]);
+        a.status[i] = 1;
+    }
+};
+
+// =============================================================================================
+// unit-parity primitives
+// =============================================================================================
+struct H2sArgs {
+    size_t n;
+    const uint32_t* off; const uint32_t* len; const uint8_t* bytes;
+    uint8_t dst[256];
+    uint32_t dst_len;
+    uint32_t* out;            // [8][n] canonical
+};
+
+template <class C>
+struct H2sItem {
+    static __host__ __device__ void run(const H2sArgs& a, size_t i) {
+        Sha256 s;
+        xmd48_begin(s);
+        sha256_bytes(s, a.bytes + a.off[i], a.len[i]);
+        uint32_t okm[12];
+        xmd48_finish(s, a.dst, a.dst_len, okm);
+        Fr<C> r = fe_to_canonical<typename C::FrP>(fr_from_okm<C>(okm));
+        soa_st<8>(a.out, a.n, i, r.v);
+    }
+};
+
+template <class C>
+struct MsmArgs {
+    size_t n;
+    int n_fixed, n_var;
+    const CtxConsts<C>* cc;
+    const uint32_t* fscal;    // [n_fixed][8][n]
+    const uint32_t* vpts;     // [n_var][2N][n] canonical
+    const uint32_t* vscal;    // [n_var][8][n]
+    int8_t* status;
+    uint32_t* partials;       // [n_var + NFIX][3N][n]
+    uint32_t* out;            // [2N][n] canonical
+};
+
+template <class C>
+struct MsmPart {
+    static __host__ __device__ void run(const MsmArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int part = (int)(t / n);
+        const size_t i = t - (size_t)part * n;
+        if (a.status[i] < 0) return;
+        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
+        if (part < a.n_var) {
+            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * N * n, n, i);
+            if (!g1a_on_curve<C>(p)) { a.status[i] = -41; g1j_store<C>(out, n, i, g1j_inf<C>()); return; }
+            uint32_t k[8];
+            soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
+            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+        } else {
+            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.n_fixed, part - a.n_var));
+        }
+    }
+};
+
+template <class C>
+struct MsmCombine {
+    static __host__ __device__ void run(const MsmArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] < 0) return;
+        G1Jac<C> acc = g1j_inf<C>();
+        for (int p = 0; p < a.n_var + NFIX; p++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i));
+        g1a_store_canon<C>(a.out, n, i, g1j_to_aff<C>(acc));
+        a.status[i] = 1;
+    }
+};
+
+// canonical affine inputs -> Montgomery, on-curve check, status 2 (pairing pending)
+template <class C>
+struct PairPrep {
+    const uint32_t* pa_c; const uint32_t* pb_c; uint32_t* pa; uint32_t* pb; int8_t* status; size_t n;
+    static __host__ __device__ void run(const PairPrep<C>& a, size_t i) {
+        if (a.status[i] < 0) return;     // flagged by host validation
+        G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pa_c, a.n, i), q = g1a_load_canon_to_mont<C>(a.pb_c, a.n, i);
+        if (!g1a_on_curve<C>(p) || !g1a_on_curve<C>(q)) { a.status[i] = -41; return; }
+        g1a_store_mont<C>(a.pa, a.n, i, p);
+        g1a_store_mont<C>(a.pb, a.n, i, q);
+        a.status[i] = 2;
+    }
+};
+
+}  // namespace bbs

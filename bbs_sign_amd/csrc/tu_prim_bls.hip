@@ -1,0 +1,6 @@
+// explicit instantiation: prim for BlsCurve
+#include "op_prim.hpp"
+template int Ctx<BlsCurve>::set_generators(const uint8_t*, size_t, const uint8_t*, size_t);
+template int h2s_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const uint64_t*, const uint8_t*, size_t, uint8_t*);
+template int msm_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
+template int pairing_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const uint8_t*, int8_t*);

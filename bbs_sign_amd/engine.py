@@ -1,0 +1,456 @@
+"""Host-side mirror of the reference's core_* interface over the C ABI (ctypes).
+
+Values are exchanged as plain Python integers / tuples so that parity tests read like the
+reference's own tests:
+    scalar  : int in [0, r)
+    G1 point: None (identity) or (x, y)
+    G2 point: None (identity) or ((x0, x1), (y0, y1))
+    Signature(a, e) / Proof(a_bar, b_bar, d, e_cap, r1_cap, r3_cap, commitments, challenge)
+mirror src/sign.rs:18-22 and src/proof_gen.rs:29-39.
+
+Errors: a negative per-item status becomes ``BbsError(variant)`` with the reference's variant
+name (single-item helpers) or is returned as the raw status (batch helpers).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+BLS12_381 = 0
+BN254 = 1
+CURVE_IDS = {"bls12_381": BLS12_381, "bn254": BN254}
+
+STATUS_NAMES = {
+    1: "Ok(true)", 0: "Ok(false)",
+    -1: "InvalidMessageAndGeneratorsLength",
+    -2: "InvalidDisclosedIndicesLength",
+    -3: "InvalidDisclosedIndex",
+    -4: "InvalidRandomScalarsAndUndisclosedIndicesLength",
+    -5: "InvalidUndisclosedIndicesLength",
+    -6: "InvalidIndicesAndMessagesLength",
+    -20: "Panic(sk+e has no inverse)",
+    -21: "Panic(r2 has no inverse)",
+    -22: "Panic(index out of bounds: proof.commitments)",
+    -23: "Panic(dst size is invalid)",
+    -40: "NonCanonical",
+    -41: "NotOnCurve",
+}
+ERRORS = {-100: "BBS_E_ARG", -101: "BBS_E_HIP", -102: "BBS_E_STATE", -103: "BBS_E_PUBLIC_KEY",
+          -104: "BBS_E_NO_DEVICE", -105: "BBS_E_NOMEM"}
+
+
+class BbsError(Exception):
+    """A reference ``Err(variant)`` / panic for one item."""
+
+    def __init__(self, status: int):
+        self.status = int(status)
+        self.variant = STATUS_NAMES.get(int(status), "status %d" % status)
+        super().__init__(self.variant)
+
+
+class BbsRuntimeError(RuntimeError):
+    """Batch-level failure (bad argument, HIP error, missing key/generators)."""
+
+    def __init__(self, rc: int, where: str):
+        self.rc = rc
+        super().__init__("%s failed: %s" % (where, ERRORS.get(rc, rc)))
+
+
+@dataclass
+class Signature:
+    a: Optional[tuple]
+    e: int
+
+
+@dataclass
+class Proof:
+    a_bar: Optional[tuple] = None
+    b_bar: Optional[tuple] = None
+    d: Optional[tuple] = None
+    e_cap: int = 0
+    r1_cap: int = 0
+    r3_cap: int = 0
+    commitments: List[int] = field(default_factory=list)
+    challenge: int = 0
+
+
+def _u8(buf) -> "ctypes.POINTER(ctypes.c_uint8)":
+    return buf.ctypes.data_as(_lib.c_u8p)
+
+
+def _u64(buf):
+    return buf.ctypes.data_as(_lib.c_u64p)
+
+
+def _bytes_arr(b: bytes) -> np.ndarray:
+    return np.frombuffer(bytes(b) + b"\0", dtype=np.uint8).copy()
+
+
+def _ragged_bytes(items: Sequence[bytes]):
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    for i, it in enumerate(items):
+        off[i + 1] = off[i] + len(it)
+    return _bytes_arr(b"".join(bytes(x) for x in items)), off
+
+
+class Engine:
+    """One context: (curve, GPU, generator set + api_id, issuer key)."""
+
+    def __init__(self, curve, device: int = 0, lib_path: Optional[str] = None, window_bits: Optional[int] = None):
+        self.lib = _lib.load_library(lib_path)
+        self.curve = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        self.fpb = int(self.lib.bbs_fp_bytes(self.curve))
+        h = ctypes.c_void_p()
+        rc = self.lib.bbs_ctx_create(self.curve, device, ctypes.byref(h))
+        if rc:
+            raise BbsRuntimeError(rc, "bbs_ctx_create")
+        self.h = h
+        self.L = None
+        if window_bits is not None:
+            self._chk(self.lib.bbs_ctx_set_window_bits(self.h, window_bits), "bbs_ctx_set_window_bits")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bbs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _chk(rc, where):
+        if rc:
+            raise BbsRuntimeError(rc, where)
+
+    # ------------------------------------------------------------------ encoders
+    def _fp(self, v: int) -> bytes:
+        return int(v).to_bytes(self.fpb, "little")
+
+    @staticmethod
+    def _fr(v: int) -> bytes:
+        return int(v).to_bytes(32, "little")
+
+    def _g1(self, p) -> bytes:
+        if p is None:
+            return bytes(2 * self.fpb)
+        return self._fp(p[0]) + self._fp(p[1])
+
+    def _g1_dec(self, b: bytes):
+        x = int.from_bytes(b[:self.fpb], "little")
+        y = int.from_bytes(b[self.fpb:2 * self.fpb], "little")
+        return None if (x == 0 and y == 0) else (x, y)
+
+    def _scalars(self, rows: Sequence[Sequence[int]]):
+        off = np.zeros(len(rows) + 1, dtype=np.uint64)
+        chunks = []
+        for i, row in enumerate(rows):
+            off[i + 1] = off[i] + len(row)
+            chunks.extend(self._fr(s) for s in row)
+        return _bytes_arr(b"".join(chunks)), off
+
+    @staticmethod
+    def _indexes(rows: Sequence[Sequence[int]]):
+        off = np.zeros(len(rows) + 1, dtype=np.uint64)
+        flat = []
+        for i, row in enumerate(rows):
+            off[i + 1] = off[i] + len(row)
+            flat.extend(int(x) for x in row)
+        return np.array(flat + [0], dtype=np.uint64), off
+
+    def _sigs(self, sigs: Sequence[Signature]) -> np.ndarray:
+        return _bytes_arr(b"".join(self._g1(s.a) + self._fr(s.e) for s in sigs))
+
+    # --------------------------------------------------------------------- setup
+    def set_generators(self, generators: Sequence, api_id: bytes):
+        """``generators`` = [Q1, H_1..H_L] -- the `generators: &[E::G1]` of every core_* fn."""
+        buf = _bytes_arr(b"".join(self._g1(g) for g in generators))
+        aid = _bytes_arr(api_id)
+        self._chk(self.lib.bbs_ctx_set_generators(self.h, _u8(buf), len(generators), _u8(aid), len(api_id)),
+                  "bbs_ctx_set_generators")
+        self.L = len(generators) - 1
+
+    def set_public_key(self, pk):
+        if pk is None:
+            self._chk(self.lib.bbs_ctx_set_public_key(self.h, None, 1), "bbs_ctx_set_public_key")
+            return
+        (x0, x1), (y0, y1) = pk
+        buf = _bytes_arr(self._fp(x0) + self._fp(x1) + self._fp(y0) + self._fp(y1))
+        self._chk(self.lib.bbs_ctx_set_public_key(self.h, _u8(buf), 0), "bbs_ctx_set_public_key")
+
+    def set_secret_key(self, sk: int):
+        buf = _bytes_arr(self._fr(sk))
+        self._chk(self.lib.bbs_ctx_set_secret_key(self.h, _u8(buf)), "bbs_ctx_set_secret_key")
+
+    def public_key(self):
+        """sk_to_pk (src/key_gen.rs:83-90) of the secret key set on this context."""
+        out = np.zeros(4 * self.fpb, dtype=np.uint8)
+        inf = ctypes.c_int(0)
+        self._chk(self.lib.bbs_ctx_get_public_key(self.h, _u8(out), ctypes.byref(inf)), "bbs_ctx_get_public_key")
+        if inf.value:
+            return None
+        b = out.tobytes()
+        f = [int.from_bytes(b[i * self.fpb:(i + 1) * self.fpb], "little") for i in range(4)]
+        return ((f[0], f[1]), (f[2], f[3]))
+
+    def public_key_compressed(self) -> bytes:
+        out = np.zeros(2 * self.fpb, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        self._chk(self.lib.bbs_ctx_get_public_key_compressed(self.h, _u8(out), out.size, ctypes.byref(n)),
+                  "bbs_ctx_get_public_key_compressed")
+        return out.tobytes()[:n.value]
+
+    # ------------------------------------------------------------ batched core_*
+    def _pv_inputs(self, proofs, disclosed_msgs, disclosed_idx, headers, phs):
+        n = len(proofs)
+        rec = b"".join(
+            self._g1(p.a_bar) + self._g1(p.b_bar) + self._g1(p.d) + self._fr(p.e_cap) + self._fr(p.r1_cap)
+            + self._fr(p.r3_cap) + self._fr(p.challenge) for p in proofs)
+        pf = _bytes_arr(rec)
+        cm, cmo = self._scalars([p.commitments for p in proofs])
+        dm, dmo = self._scalars(disclosed_msgs)
+        di, dio = self._indexes(disclosed_idx)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        keep = (pf, cm, cmo, dm, dmo, di, dio, hb, ho, pb, po)
+        args = (_u8(pf), _u8(cm), _u64(cmo), _u8(dm), _u64(dmo), _u64(di), _u64(dio), _u8(hb), _u64(ho), _u8(pb), _u64(po))
+        return n, keep, args
+
+    def core_proof_verify_batch(self, proofs, disclosed_msgs, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+        """core_proof_verify (src/proof_verify.rs:64-116) over a batch; returns int8 statuses."""
+        n, keep, args = self._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_core_proof_verify_batch(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)),
+                  "bbs_core_proof_verify_batch")
+        return st[:n]
+
+    def core_proof_verify_upload(self, proofs, disclosed_msgs, disclosed_idx, headers=None, phs=None) -> "Job":
+        n, keep, args = self._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_proof_verify_upload(self.h, n, *args, ctypes.byref(j)), "bbs_core_proof_verify_upload")
+        return Job(self, j, n)
+
+    def core_verify_batch(self, signatures, messages, headers=None) -> np.ndarray:
+        """core_verify (src/verify.rs:53-93) over a batch."""
+        n = len(signatures)
+        sg = self._sigs(signatures)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_core_verify_batch(self.h, n, _u8(sg), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
+                                                 st.ctypes.data_as(_lib.c_i8p)), "bbs_core_verify_batch")
+        return st[:n]
+
+    def core_verify_upload(self, signatures, messages, headers=None) -> "Job":
+        n = len(signatures)
+        sg = self._sigs(signatures)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_verify_upload(self.h, n, _u8(sg), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
+                                                  ctypes.byref(j)), "bbs_core_verify_upload")
+        return Job(self, j, n)
+
+    def _dec_sigs(self, out: np.ndarray, st: np.ndarray, n: int):
+        rec = 2 * self.fpb + 32
+        b = out.tobytes()
+        sigs = []
+        for i in range(n):
+            if st[i] != 1:
+                sigs.append(None)
+                continue
+            r = b[i * rec:(i + 1) * rec]
+            sigs.append(Signature(self._g1_dec(r), int.from_bytes(r[2 * self.fpb:], "little")))
+        return sigs
+
+    def core_sign_batch(self, messages, headers=None):
+        """core_sign (src/sign.rs:63-133) over a batch -> (signatures | None, statuses)."""
+        n = len(messages)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        out = np.zeros(max(n, 1) * (2 * self.fpb + 32), dtype=np.uint8)
+        self._chk(self.lib.bbs_core_sign_batch(self.h, n, _u8(ms), _u64(mo), _u8(hb), _u64(ho), _u8(out),
+                                               st.ctypes.data_as(_lib.c_i8p)), "bbs_core_sign_batch")
+        return self._dec_sigs(out, st, n), st[:n]
+
+    def core_sign_upload(self, messages, headers=None) -> "Job":
+        n = len(messages)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_sign_upload(self.h, n, _u8(ms), _u64(mo), _u8(hb), _u64(ho), ctypes.byref(j)),
+                  "bbs_core_sign_upload")
+        return Job(self, j, n)
+
+    def _pg_inputs(self, signatures, messages, disclosed_idx, random_scalars, headers, phs):
+        n = len(signatures)
+        sg = self._sigs(signatures)
+        ms, mo = self._scalars(messages)
+        di, dio = self._indexes(disclosed_idx)
+        rs, ro = self._scalars(random_scalars)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        keep = (sg, ms, mo, di, dio, rs, ro, hb, ho, pb, po)
+        args = (_u8(sg), _u8(ms), _u64(mo), _u64(di), _u64(dio), _u8(rs), _u64(ro), _u8(hb), _u64(ho), _u8(pb), _u64(po))
+        return n, keep, args
+
+    def _dec_proofs(self, pf: np.ndarray, cm: np.ndarray, cmo: np.ndarray, st: np.ndarray, n: int):
+        rec = 6 * self.fpb + 128
+        b = pf.tobytes()
+        c = cm.tobytes()
+        proofs = []
+        for i in range(n):
+            if st[i] != 1:
+                proofs.append(None)
+                continue
+            r = b[i * rec:(i + 1) * rec]
+            pts = [self._g1_dec(r[k * 2 * self.fpb:(k + 1) * 2 * self.fpb]) for k in range(3)]
+            sc = [int.from_bytes(r[6 * self.fpb + 32 * k:6 * self.fpb + 32 * (k + 1)], "little") for k in range(4)]
+            cms = [int.from_bytes(c[32 * k:32 * (k + 1)], "little") for k in range(int(cmo[i]), int(cmo[i + 1]))]
+            proofs.append(Proof(pts[0], pts[1], pts[2], sc[0], sc[1], sc[2], cms, sc[3]))
+        return proofs
+
+    def core_proof_gen_batch(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None):
+        """core_proof_gen (src/proof_gen.rs:116-208) over a batch -> (proofs | None, statuses).
+        ``random_scalars[i]`` are the 5 + L - R scalars the reference draws at :145-149."""
+        n, keep, args = self._pg_inputs(signatures, messages, disclosed_idx, random_scalars, headers, phs)
+        total = sum(len(m) for m in messages)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        pf = np.zeros(max(n, 1) * (6 * self.fpb + 128), dtype=np.uint8)
+        cm = np.zeros(max(total, 1) * 32, dtype=np.uint8)
+        cmo = np.zeros(n + 1, dtype=np.uint64)
+        self._chk(self.lib.bbs_core_proof_gen_batch(self.h, n, *args, _u8(pf), _u8(cm), _u64(cmo),
+                                                    st.ctypes.data_as(_lib.c_i8p)), "bbs_core_proof_gen_batch")
+        return self._dec_proofs(pf, cm, cmo, st, n), st[:n]
+
+    def core_proof_gen_upload(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None) -> "Job":
+        n, keep, args = self._pg_inputs(signatures, messages, disclosed_idx, random_scalars, headers, phs)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_proof_gen_upload(self.h, n, *args, ctypes.byref(j)), "bbs_core_proof_gen_upload")
+        job = Job(self, j, n)
+        job.total_msgs = sum(len(m) for m in messages)
+        return job
+
+    # --------------------------------------------------------- single-item mirror
+    @staticmethod
+    def _one(st):
+        s = int(st[0])
+        if s < 0:
+            raise BbsError(s)
+        return s
+
+    def core_sign(self, header: bytes, messages: Sequence[int]) -> Signature:
+        sigs, st = self.core_sign_batch([list(messages)], [header])
+        self._one(st)
+        return sigs[0]
+
+    def core_verify(self, signature: Signature, header: bytes, messages: Sequence[int]) -> bool:
+        return bool(self._one(self.core_verify_batch([signature], [list(messages)], [header])))
+
+    def core_proof_gen(self, signature: Signature, header: bytes, ph: bytes, messages: Sequence[int],
+                       disclosed_indexes: Sequence[int], random_scalars: Sequence[int]) -> Proof:
+        proofs, st = self.core_proof_gen_batch([signature], [list(messages)], [list(disclosed_indexes)],
+                                               [list(random_scalars)], [header], [ph])
+        self._one(st)
+        return proofs[0]
+
+    def core_proof_verify(self, proof: Proof, header: bytes, ph: bytes, disclosed_messages: Sequence[int],
+                          disclosed_indexes: Sequence[int]) -> bool:
+        st = self.core_proof_verify_batch([proof], [list(disclosed_messages)], [list(disclosed_indexes)], [header], [ph])
+        return bool(self._one(st))
+
+    # ------------------------------------------------------------------ primitives
+    def hash_to_scalar_batch(self, msgs: Sequence[bytes], dst: bytes) -> List[int]:
+        n = len(msgs)
+        mb, mo = _ragged_bytes(msgs)
+        d = _bytes_arr(dst)
+        out = np.zeros(max(n, 1) * 32, dtype=np.uint8)
+        self._chk(self.lib.bbs_hash_to_scalar_batch(self.h, n, _u8(mb), _u64(mo), _u8(d), len(dst), _u8(out)),
+                  "bbs_hash_to_scalar_batch")
+        b = out.tobytes()
+        return [int.from_bytes(b[32 * i:32 * (i + 1)], "little") for i in range(n)]
+
+    def g1_msm_batch(self, fixed_scalars, var_points, var_scalars):
+        n = len(fixed_scalars)
+        nf = len(fixed_scalars[0]) if n else 0
+        nv = len(var_points[0]) if (n and var_points) else 0
+        fs = _bytes_arr(b"".join(self._fr(s) for row in fixed_scalars for s in row))
+        vpb = _bytes_arr(b"".join(self._g1(p) for row in (var_points or []) for p in row))
+        vs = _bytes_arr(b"".join(self._fr(s) for row in (var_scalars or []) for s in row))
+        out = np.zeros(max(n, 1) * 2 * self.fpb, dtype=np.uint8)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_g1_msm_batch(self.h, n, _u8(fs), nf, _u8(vpb), _u8(vs), nv, _u8(out),
+                                            st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_batch")
+        b = out.tobytes()
+        return [self._g1_dec(b[i * 2 * self.fpb:(i + 1) * 2 * self.fpb]) if st[i] == 1 else None for i in range(n)], st[:n]
+
+    def pairing_product2_is_one_batch(self, pa, pb) -> np.ndarray:
+        n = len(pa)
+        a = _bytes_arr(b"".join(self._g1(p) for p in pa))
+        b = _bytes_arr(b"".join(self._g1(p) for p in pb))
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_pairing_product2_is_one_batch(self.h, n, _u8(a), _u8(b), st.ctypes.data_as(_lib.c_i8p)),
+                  "bbs_pairing_product2_is_one_batch")
+        return st[:n]
+
+
+class Job:
+    """A device-resident batch (bbs_job): run() is asynchronous on the context's stream."""
+
+    def __init__(self, eng: Engine, handle, n: int):
+        self.eng, self.h, self.n = eng, handle, n
+        self.total_msgs = 0
+
+    def run(self):
+        Engine._chk(self.eng.lib.bbs_job_run(self.h), "bbs_job_run")
+
+    def wait(self):
+        Engine._chk(self.eng.lib.bbs_job_wait(self.h), "bbs_job_wait")
+
+    def status(self) -> np.ndarray:
+        st = np.zeros(max(self.n, 1), dtype=np.int8)
+        Engine._chk(self.eng.lib.bbs_job_fetch_status(self.h, st.ctypes.data_as(_lib.c_i8p)), "bbs_job_fetch_status")
+        return st[:self.n]
+
+    def signatures(self):
+        st = self.status()
+        out = np.zeros(max(self.n, 1) * (2 * self.eng.fpb + 32), dtype=np.uint8)
+        Engine._chk(self.eng.lib.bbs_job_fetch_signatures(self.h, _u8(out)), "bbs_job_fetch_signatures")
+        return self.eng._dec_sigs(out, st, self.n), st
+
+    def proofs(self):
+        st = self.status()
+        pf = np.zeros(max(self.n, 1) * (6 * self.eng.fpb + 128), dtype=np.uint8)
+        cm = np.zeros(max(self.total_msgs, 1) * 32, dtype=np.uint8)
+        cmo = np.zeros(self.n + 1, dtype=np.uint64)
+        Engine._chk(self.eng.lib.bbs_job_fetch_proofs(self.h, _u8(pf), _u8(cm), _u64(cmo)), "bbs_job_fetch_proofs")
+        return self.eng._dec_proofs(pf, cm, cmo, st, self.n), st
+
+    def run_timed(self, reps: int = 1, per_stage: bool = True):
+        """-> (total_ms, {stage: ms}) measured with HIP events on the context's own stream."""
+        tot = ctypes.c_float(0)
+        ks = (ctypes.c_float * 16)()
+        ns = ctypes.c_int(0)
+        Engine._chk(self.eng.lib.bbs_job_run_timed(self.h, reps, ctypes.byref(tot), ks if per_stage else None, 16,
+                                                   ctypes.byref(ns)), "bbs_job_run_timed")
+        names = [self.eng.lib.bbs_job_stage_name(self.h, k).decode() for k in range(ns.value)]
+        return tot.value, ({names[k]: ks[k] for k in range(ns.value)} if per_stage else {})
+
+    def free(self):
+        if self.h:
+            self.eng.lib.bbs_job_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,195 @@
+/*
+ * bbs_sign_amd -- C ABI of the MI355X-native batched BBS+ engine.
+ *
+ * This is the drop-in boundary for the hot path of hashcloak/bbs_sign: the `core_*` level of the
+ * reference (the narrowest seam that isolates all heavy arithmetic and that the reference's own
+ * tests call directly, src/tests/core_sign_tests.rs:53-64).  Each entry point names the reference
+ * function it replaces.  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * Data formats (both curves):
+ *   Fp / Fr element : canonical value < modulus, LITTLE-endian bytes (48 B for BLS12-381 Fp,
+ *                     32 B otherwise) == ark-ff `into_bigint().to_bytes_le()`.
+ *   G1 affine       : x || y (2 * fp_bytes); the identity is encoded as all-zero bytes.
+ *   G2 affine       : x.c0 || x.c1 || y.c0 || y.c1 (4 * fp_bytes) + a separate identity flag.
+ *   scalar          : 32 B LE, must be < r (else per-item status BBS_ST_NONCANONICAL).
+ *   ragged arrays   : a flat buffer + an offsets array of n+1 uint64 (item i owns
+ *                     [off[i], off[i+1]) in units of elements: scalars, indexes or bytes).
+ *
+ * Per-item status (int8): mirrors the reference's Result<bool|T, Error>:
+ *     1  Ok(true) / Ok(value)        0  Ok(false)
+ *   < 0  the Err variant, a reference panic, or an input the reference's types cannot hold.
+ * Function return: 0 on success, BBS_E_* on a batch-level failure (nothing was computed).
+ */
+#ifndef BBS_SIGN_AMD_H
+#define BBS_SIGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBS_CURVE_BLS12_381 0
+#define BBS_CURVE_BN254 1
+
+#define BBS_FR_BYTES 32
+
+/* per-item status codes */
+#define BBS_ST_TRUE 1
+#define BBS_ST_FALSE 0
+/* SignatureError (src/sign.rs:24-28) / ProofGenError (src/proof_gen.rs:59-75) */
+#define BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH (-1)
+#define BBS_ST_INVALID_DISCLOSED_INDICES_LENGTH (-2)
+#define BBS_ST_INVALID_DISCLOSED_INDEX (-3)
+#define BBS_ST_INVALID_RANDOM_SCALARS_AND_UNDISCLOSED_INDICES_LENGTH (-4)
+#define BBS_ST_INVALID_UNDISCLOSED_INDICES_LENGTH (-5)
+#define BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH (-6)
+/* reference panics */
+#define BBS_ST_PANIC_SK_PLUS_E_ZERO (-20)     /* src/sign.rs:129 unwrap on inverse of 0 */
+#define BBS_ST_PANIC_R2_ZERO (-21)            /* src/proof_gen.rs:346 unwrap on inverse of 0 */
+#define BBS_ST_PANIC_INDEX_OUT_OF_BOUNDS (-22)/* src/proof_verify.rs:177-179 commitments[i] */
+#define BBS_ST_PANIC_DST_TOO_LONG (-23)       /* src/utils/utilities_helper.rs:46-52 */
+/* inputs arkworks' types cannot represent */
+#define BBS_ST_NONCANONICAL (-40)             /* scalar >= r or coordinate >= p */
+#define BBS_ST_NOT_ON_CURVE (-41)
+
+/* batch-level errors */
+#define BBS_OK 0
+#define BBS_E_ARG (-100)
+#define BBS_E_HIP (-101)
+#define BBS_E_STATE (-102)       /* generators / public key / secret key not set */
+#define BBS_E_PUBLIC_KEY (-103)  /* public key not on the twist or not of order r */
+#define BBS_E_NO_DEVICE (-104)
+#define BBS_E_NOMEM (-105)
+
+typedef struct bbs_ctx bbs_ctx;
+typedef struct bbs_job bbs_job;
+
+/* ------------------------------------------------------------------------------------------
+ * Context: one per (curve, GPU, issuer key, generator set).  Holds the device-resident
+ * fixed-base window tables of {P1, Q1, H_1..H_L}, the domain-hash midstate and the Miller-loop
+ * line tables of the issuer key.  Thread-compatible (one call at a time per context).
+ * ------------------------------------------------------------------------------------------ */
+size_t bbs_fp_bytes(int curve);
+const char* bbs_version(void);
+int bbs_device_count(void);
+
+int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);
+void bbs_ctx_destroy(bbs_ctx* ctx);
+
+/* window width (bits) of the fixed-base tables, 4..16; takes effect at the next
+ * bbs_ctx_set_generators.  Table bytes = (count+1) * ceil(256/w) * (2^w - 1) * 2 * fp_bytes. */
+int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
+
+/* generators = [Q1, H_1 .. H_L] (count = L+1 affine G1 points) and the api_id they belong to:
+ * the `generators: &[E::G1]` and `api_id: &[u8]` arguments of every reference core_* function
+ * (src/sign.rs:63-69, src/verify.rs:53-60, src/proof_gen.rs:116-125, src/proof_verify.rs:64-73). */
+int bbs_ctx_set_generators(bbs_ctx* ctx, const uint8_t* generators_affine, size_t count,
+                           const uint8_t* api_id, size_t api_id_len);
+
+/* issuer public key (`pk: PublicKey<E>`, src/key_gen.rs:12-15). */
+int bbs_ctx_set_public_key(bbs_ctx* ctx, const uint8_t* pk_affine, int is_identity);
+/* issuer secret key (`&self` of core_sign, src/sign.rs:63); also sets pk = sk * BP2
+ * (src/key_gen.rs:83-90, src/sign.rs:81). */
+int bbs_ctx_set_secret_key(bbs_ctx* ctx, const uint8_t* sk32);
+int bbs_ctx_get_public_key(bbs_ctx* ctx, uint8_t* pk_affine_out, int* is_identity_out);
+/* ark-serialize compressed public key as hashed into the domain (96 B BLS / 64 B BN254). */
+int bbs_ctx_get_public_key_compressed(bbs_ctx* ctx, uint8_t* out, size_t cap, size_t* len_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched core operations.  `*_upload` validates (reference order of checks), packs and copies
+ * the batch to HBM and returns a device-resident job; `bbs_job_run` enqueues the kernels on the
+ * context's stream (asynchronous); `bbs_job_wait` blocks; `bbs_job_fetch_*` copies results back.
+ * The one-shot `*_batch` functions do all of it.
+ * ------------------------------------------------------------------------------------------ */
+
+/* core_proof_verify (src/proof_verify.rs:64-116 with proof_verify_init :119-188).
+ * proofs_fixed: n records of  a_bar || b_bar || d (3 G1 affine) || e_cap || r1_cap || r3_cap ||
+ * challenge (4 scalars)  == 6*fp_bytes + 128 bytes each (src/proof_gen.rs:29-39).
+ * commitments / disclosed_msgs: scalars, ragged; disclosed_idx: uint64 indexes, ragged, caller
+ * order is significant exactly as in the reference (src/proof_verify.rs:18). */
+int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* proofs_fixed,
+                                 const uint8_t* commitments, const uint64_t* commit_off,
+                                 const uint8_t* disclosed_msgs, const uint64_t* dmsg_off,
+                                 const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                 const uint8_t* headers, const uint64_t* hdr_off,
+                                 const uint8_t* ph, const uint64_t* ph_off, bbs_job** job_out);
+int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* proofs_fixed,
+                                const uint8_t* commitments, const uint64_t* commit_off,
+                                const uint8_t* disclosed_msgs, const uint64_t* dmsg_off,
+                                const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                const uint8_t* headers, const uint64_t* hdr_off,
+                                const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
+
+/* core_verify (src/verify.rs:53-93).  signatures: n records  A (G1 affine) || e (scalar). */
+int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                           const uint8_t* messages, const uint64_t* msg_off,
+                           const uint8_t* headers, const uint64_t* hdr_off, bbs_job** job_out);
+int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                          const uint8_t* messages, const uint64_t* msg_off,
+                          const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
+
+/* core_sign (src/sign.rs:63-133); needs bbs_ctx_set_secret_key.
+ * signatures_out: n records A || e (status 1 where written). */
+int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
+                         const uint8_t* headers, const uint64_t* hdr_off, bbs_job** job_out);
+int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
+                        const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signatures_out,
+                        int8_t* status);
+
+/* core_proof_gen (src/proof_gen.rs:116-208: proof_init :211-269, proof_challenge_calculate
+ * :272-328, proof_finalize :331-365).  random_scalars replaces the draw at :145-149 and must hold
+ * 5 + L - R scalars per item (R = number of disclosed indexes BEFORE dedup, as the reference
+ * sizes it), else BBS_E_ARG.  Outputs: proofs_fixed_out (same record as above), commitments_out
+ * packed with commit_off_out (n+1 entries; capacity sum_i L_i scalars is always enough). */
+int bbs_core_proof_gen_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                              const uint8_t* messages, const uint64_t* msg_off,
+                              const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                              const uint8_t* random_scalars, const uint64_t* rnd_off,
+                              const uint8_t* headers, const uint64_t* hdr_off,
+                              const uint8_t* ph, const uint64_t* ph_off, bbs_job** job_out);
+int bbs_core_proof_gen_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                             const uint8_t* messages, const uint64_t* msg_off,
+                             const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                             const uint8_t* random_scalars, const uint64_t* rnd_off,
+                             const uint8_t* headers, const uint64_t* hdr_off,
+                             const uint8_t* ph, const uint64_t* ph_off,
+                             uint8_t* proofs_fixed_out, uint8_t* commitments_out,
+                             uint64_t* commit_off_out, int8_t* status);
+
+int bbs_job_run(bbs_job* job);                       /* asynchronous */
+int bbs_job_wait(bbs_job* job);
+size_t bbs_job_size(const bbs_job* job);
+int bbs_job_fetch_status(bbs_job* job, int8_t* status);
+int bbs_job_fetch_signatures(bbs_job* job, uint8_t* signatures_out);
+int bbs_job_fetch_proofs(bbs_job* job, uint8_t* proofs_fixed_out, uint8_t* commitments_out,
+                         uint64_t* commit_off_out);
+void bbs_job_free(bbs_job* job);
+
+/* Run the job `reps` times back to back and time it with HIP events recorded on the context's
+ * own stream: total_ms = whole pipeline; kernel_ms[k] = accumulated time of stage k
+ * (n_stages_out stages, names via bbs_job_stage_name).  Used by bench.py for the roofline line. */
+int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms, int kernel_cap,
+                      int* n_stages_out);
+const char* bbs_job_stage_name(const bbs_job* job, int stage);
+
+/* ------------------------------------------------------------------------------------------
+ * Unit-parity primitives (hash_to_scalar, G1 multi-scalar multiplication, pairing product).
+ * ------------------------------------------------------------------------------------------ */
+/* hash_to_scalar (src/utils/core_utilities.rs:11-21) of n ragged messages under one dst. */
+int bbs_hash_to_scalar_batch(bbs_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
+                             const uint8_t* dst, size_t dst_len, uint8_t* scalars_out);
+/* out[i] = sum_k fixed_scalars[i][k] * G_k  +  sum_m var_scalars[i][m] * var_points[i][m]
+ * with G = [P1, Q1, H_1..H_L] of the context (n_fixed <= L+2), affine output. */
+int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fixed_scalars, size_t n_fixed,
+                     const uint8_t* var_points, const uint8_t* var_scalars, size_t n_var,
+                     uint8_t* out_affine, int8_t* status);
+/* status[i] = ( e(Pa[i], pk) * e(Pb[i], BP2) == 1 ) */
+int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_affine,
+                                      const uint8_t* pb_affine, int8_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBS_SIGN_AMD_H */

@@ -1,0 +1,404 @@
+"""Parity checks of the C-ABI engine against the oracle and the committed golden fixtures.
+
+The same bodies run (a) on the GPU through the product library (tests/test_parity_gpu.py,
+``-m gpu``) and (b) on the CPU through the TEST-ONLY host twin of the same stage code
+(tests/test_parity_hosttwin.py) -- (b) checks the host logic (validation order, packing, index
+bookkeeping) in a container without a GPU; only (a) is a parity claim about the product.
+
+Structure follows the reference's tests: known-answer vectors (src/tests/test_vector.rs),
+round trips (src/tests/bbs_over_bls_tests.rs:41-84, core_sign_tests.rs:38-65), negative cases
+(bbs_over_bls_tests.rs:86-187, core_sign_tests.rs:67-155, sign_verify_tests.rs:60-105).
+"""
+import json
+import os
+import random
+
+from bbs_sign_amd import BbsError, Engine, Proof, Signature
+from oracle import bbs
+from oracle.hashing import expand_message, i2osp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden", "bbs_golden.json")
+_golden = None
+
+
+def golden():
+    global _golden
+    if _golden is None:
+        with open(GOLDEN) as f:
+            _golden = json.load(f)
+    return _golden
+
+
+def _i(h):
+    return int(h, 16)
+
+
+def _pt(p):
+    return None if p is None else (_i(p[0]), _i(p[1]))
+
+
+def _pt2(q):
+    return None if q is None else ((_i(q[0][0]), _i(q[0][1])), (_i(q[1][0]), _i(q[1][1])))
+
+
+def make_engine(curve, gens, api_id, lib_path=None, sk=None, pk="unset", window_bits=None):
+    if window_bits is None:
+        window_bits = 4 if lib_path else 8
+    eng = Engine(curve, lib_path=lib_path, window_bits=window_bits)
+    eng.set_generators(gens, api_id)
+    if sk is not None:
+        eng.set_secret_key(sk)
+    if pk != "unset":
+        eng.set_public_key(pk)
+    return eng
+
+
+def gens_for(suite, count):
+    if suite.curve.name == "bls12_381":
+        return bbs.create_generators(suite, count, suite.api_id)
+    return bbs.synthetic_generators(suite, count)
+
+
+def proof_eq(a, b):
+    return (a.a_bar == b.a_bar and a.b_bar == b.b_bar and a.d == b.d and a.e_cap == b.e_cap
+            and a.r1_cap == b.r1_cap and a.r3_cap == b.r3_cap and list(a.commitments) == list(b.commitments)
+            and a.challenge == b.challenge)
+
+
+def to_engine_proof(p):
+    return Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_kat_vectors(lib_path=None):
+    """The reference's full signature and proof vectors (test_vector.rs:163-192, :199-260) through
+    the engine's core_* entry points."""
+    S = bbs.BLS_SUITE
+    c = S.curve
+    H = bytes.fromhex
+    ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+    key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+    key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+    m1 = H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")
+    header = H("11223344556677889900aabbccddeeff")
+    ph = H("bed231d880675ed101ead304512e043ade9958dd0241ea70b4b3957fba941501")
+    sk = bbs.key_gen(S, ikm, key_info, key_dst)
+    gens = bbs.create_generators(S, 2, S.api_id)
+    eng = make_engine("bls12_381", gens, S.api_id, lib_path, sk=sk)
+    assert eng.public_key_compressed().hex() == (
+        "a820f230f6ae38503b86c70dc50b61c58a77e45c39ab25c0652bbaa8fa136f2851bd4781c9dcde39fc9d1d52c9e60268"
+        "061e7d7632171d91aa8d460acee0e96f1e7c4cfb12d3ff9ab5d5dc91c277db75c845d649ef3c4f63aebc364cd55ded0c")
+    # msg_to_scalars on the device (test_vector.rs:100-120)
+    msg = eng.hash_to_scalar_batch([m1, b""], S.api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
+    assert bbs.scalar_be(c, msg[0]).hex() == "1cb5bb86114b34dc438a911617655a1db595abafac92f47c5001799cf624b430"
+    assert bbs.scalar_be(c, msg[1]).hex() == "08e3afeb2b4f2b5f907924ef42856616e6f2d5f1fb373736db1cca32707a7d16"
+    sig = eng.core_sign(header, [msg[0]])
+    got = bbs.g1_compress(c, sig.a).hex() + bbs.scalar_be(c, sig.e).hex()
+    assert got == ("84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f271"
+                   "64657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0")
+    assert eng.core_verify(sig, header, [msg[0]]) is True
+    rnd = bbs.mocked_calculate_random_scalars(S, 5)
+    proof = eng.core_proof_gen(sig, header, ph, [msg[0]], [0], rnd)
+    got = (bbs.g1_compress(c, proof.a_bar) + bbs.g1_compress(c, proof.b_bar) + bbs.g1_compress(c, proof.d)).hex()
+    got += "".join(bbs.scalar_be(c, x).hex() for x in (proof.e_cap, proof.r1_cap, proof.r3_cap, proof.challenge))
+    assert proof.commitments == []
+    assert got == (
+        "94916292a7a6bade28456c601d3af33fcf39278d6594b467e128a3f83686a104ef2b2fcf72df0215eeaf69262ffe8194a19fab31a82ddbe06908985abc4c9825788b8a1610942d12b7f5debbea8985296361206dbace7af0cc834c80f33e0aadaeea5597befbb651827b5eed5a66f1a959bb46cfd5ca1a817a14475960f69b32c54db7587b5ee3ab665fbd37b506830a49f21d592f5e634f47cee05a025a2f8f94e73a6c15f02301d1178a92873b6e8634bafe4983c3e15a663d64080678dbf29417519b78af042be2b3e1c4d08b8d520ffab008cbaaca5671a15b22c239b38e940cfeaa5e72104576a9ec4a6fad78c532381aeaa6fb56409cef56ee5c140d455feeb04426193c57086c9b6d397d9418")
+    assert eng.core_proof_verify(proof, header, ph, [msg[0]], [0]) is True
+    assert eng.core_proof_verify(proof, header, ph + b"x", [msg[0]], [0]) is False
+
+
+# ------------------------------------------------------------------------------------------------
+def check_golden(curve, lib_path=None, max_L=None):
+    """Golden fixtures (tests/golden): sign / verify / proof_gen / proof_verify, byte for byte."""
+    g = golden()["suites"][curve]
+    suite = bbs.SUITES[curve]
+    api_id = bytes.fromhex(g["api_id"])
+    sk = _i(g["sk"])
+    n = 0
+    for case in g["cases"]:
+        L = case["L"]
+        if max_L is not None and L > max_L:
+            continue
+        gens = [_pt(p) for p in case["generators"]]
+        eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+        assert eng.public_key() == _pt2(g["pk"])
+        assert eng.public_key_compressed().hex() == g["pk_compressed"]
+        msgs = [_i(m) for m in case["messages"]]
+        header, ph = bytes.fromhex(case["header"]), bytes.fromhex(case["ph"])
+        disclosed = case["disclosed"]
+        rnd = [_i(x) for x in case["random_scalars"]]
+        sig = eng.core_sign(header, msgs)
+        assert sig.a == _pt(case["signature"]["a"]) and sig.e == _i(case["signature"]["e"]), (curve, L, "sign")
+        assert eng.core_verify(sig, header, msgs) is True
+        proof = eng.core_proof_gen(sig, header, ph, msgs, disclosed, rnd)
+        gp = case["proof"]
+        want = Proof(_pt(gp["a_bar"]), _pt(gp["b_bar"]), _pt(gp["d"]), _i(gp["e_cap"]), _i(gp["r1_cap"]), _i(gp["r3_cap"]),
+                     [_i(x) for x in gp["commitments"]], _i(gp["challenge"]))
+        assert proof_eq(proof, want), (curve, L, "proof_gen")
+        assert eng.core_proof_verify(proof, header, ph, [msgs[i] for i in disclosed], disclosed) is True
+        # one flipped bit anywhere must turn the boolean
+        assert eng.core_proof_verify(proof, header + b"!", ph, [msgs[i] for i in disclosed], disclosed) is False
+        eng.close()
+        n += 1
+    assert n > 0
+
+
+def check_oracle_reproduces_golden(curve, max_L=10):
+    g = golden()["suites"][curve]
+    suite = bbs.SUITES[curve]
+    api_id = bytes.fromhex(g["api_id"])
+    sk = _i(g["sk"])
+    pk = bbs.sk_to_pk(suite, sk)
+    assert bbs.g2_compress(suite.curve, pk).hex() == g["pk_compressed"]
+    for case in g["cases"]:
+        if case["L"] > max_L:
+            continue
+        gens = [_pt(p) for p in case["generators"]]
+        if curve == "bls12_381":
+            assert gens == bbs.create_generators(suite, case["L"] + 1, api_id)
+        msgs = [_i(m) for m in case["messages"]]
+        header, ph = bytes.fromhex(case["header"]), bytes.fromhex(case["ph"])
+        sig = bbs.core_sign(suite, sk, gens, header, msgs, api_id)
+        assert sig.a == _pt(case["signature"]["a"]) and sig.e == _i(case["signature"]["e"])
+        assert bbs.g1_compress(suite.curve, sig.a).hex() == case["signature"]["a_compressed"]
+        rnd = [_i(x) for x in case["random_scalars"]]
+        proof = bbs.core_proof_gen(suite, pk, sig, header, gens, ph, msgs, case["disclosed"], api_id, rnd)
+        assert proof.challenge == _i(case["proof"]["challenge"])
+        assert proof.commitments == [_i(x) for x in case["proof"]["commitments"]]
+
+
+# ------------------------------------------------------------------------------------------------
+def check_random_batch(curve, lib_path=None, n=6, L=5, seed=1):
+    """Seeded random batch with ragged headers / disclosed sets, every output against the oracle."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = b"api-%d-" % seed if seed % 2 else suite.api_id     # core_* takes an arbitrary api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    assert eng.public_key() == pk
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 0, 3, 17, 64, 70]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 32, 100]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    want_sigs = [bbs.core_sign(suite, sk, gens, headers[i], msgs[i], api_id) for i in range(n)]
+    for i in range(n):
+        assert sigs[i].a == want_sigs[i].a and sigs[i].e == want_sigs[i].e, (curve, i, "sign")
+    # verify: half the items forged in different ways (core_sign_tests.rs:67-155)
+    vs = [Signature(s.a, s.e) for s in sigs]
+    vm = [list(m) for m in msgs]
+    vh = list(headers)
+    expect = [1] * n
+    for i in range(n):
+        k = i % 4
+        if k == 1:
+            vs[i] = Signature(None, sigs[i].e); expect[i] = 0            # forged A = identity
+        elif k == 2 and L:
+            vm[i][0] = (vm[i][0] + 1) % c.r; expect[i] = 0               # forged message
+        elif k == 3:
+            vh[i] = vh[i] + b"x"; expect[i] = 0                          # forged header
+    st = eng.core_verify_batch(vs, vm, vh)
+    assert list(st) == expect, (curve, list(st), expect)
+    for i in range(min(n, 3)):
+        assert bbs.core_verify(suite, pk, bbs.Signature(vs[i].a, vs[i].e), gens, vh[i], vm[i], api_id) == bool(expect[i])
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    for i in range(n):
+        want = bbs.core_proof_gen(suite, pk, want_sigs[i], headers[i], gens, phs[i], msgs[i], disclosed[i], api_id, rnds[i])
+        assert proof_eq(proofs[i], want), (curve, i, "proof_gen")
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)
+    assert list(st) == [1] * n, (curve, list(st))
+    # corrupt: one field per item
+    bad = [to_engine_proof(p) for p in proofs]
+    expect = [1] * n
+    for i in range(n):
+        k = i % 6
+        p = bad[i]
+        if k == 0:
+            p.e_cap = (p.e_cap + 1) % c.r; expect[i] = 0
+        elif k == 1:
+            p.a_bar = None; expect[i] = 0                                  # bbs_over_bls_tests.rs:119-133
+        elif k == 2:
+            p.challenge = (p.challenge + 1) % c.r; expect[i] = 0
+        elif k == 3 and p.commitments:
+            p.commitments[-1] = (p.commitments[-1] + 5) % c.r; expect[i] = 0
+        elif k == 4:
+            p.d = c.g1_add(p.d, c.g1); expect[i] = 0
+    st = eng.core_proof_verify_batch(bad, dm, disclosed, headers, phs)
+    assert list(st) == expect, (curve, list(st), expect)
+    for i in range(min(n, 2)):
+        op = bbs.Proof(bad[i].a_bar, bad[i].b_bar, bad[i].d, bad[i].e_cap, bad[i].r1_cap, bad[i].r3_cap,
+                       bad[i].commitments, bad[i].challenge)
+        assert bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], disclosed[i], api_id) == bool(expect[i])
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def check_error_semantics(curve, lib_path=None):
+    """Err / panic / Ok(false) behaviour of the reference, per item, inside one batch."""
+    rng = random.Random(7)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    L = 10
+    gens = gens_for(suite, L + 1)
+    sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    msgs = [rng.randrange(c.r) for _ in range(L)]
+    sig = eng.core_sign(b"", msgs)
+    disclosed = [0, 1, 5]
+    rnd = [rng.randrange(1, c.r) for _ in range(5 + L - 3)]
+    proof = eng.core_proof_gen(sig, b"", b"", msgs, disclosed, rnd)
+    dm = [msgs[i] for i in disclosed]
+    default = Proof()
+    zero7 = Proof(commitments=[0] * 7)
+    items = [
+        (proof, dm, disclosed),                                  # valid                       -> 1
+        (default, dm, disclosed),                                # Proof::default(): l = 3, index 5 >= l -> Err (bbs_over_bls_tests.rs:137-152)
+        (zero7, dm, disclosed),                                  # 7 zero commitments          -> Ok(false) (:172-186)
+        (proof, dm, [1, 0, 5]),                                  # caller order matters        -> Ok(false) (proof_verify.rs:18)
+        (proof, dm[:2], disclosed),                              # messages != indexes         -> Err -6
+        (proof, dm, [0, 1, 1]),                                  # duplicate -> commitments[i] out of bounds -> panic
+        (Proof(proof.a_bar, proof.b_bar, proof.d, proof.e_cap, proof.r1_cap, proof.r3_cap, proof.commitments[:-1],
+               proof.challenge), dm, disclosed),                 # l = 9 != generators - 1     -> Err -1
+    ]
+    st = eng.core_proof_verify_batch([x[0] for x in items], [x[1] for x in items], [x[2] for x in items])
+    assert list(st) == [1, -3, 0, 0, -6, -22, -1], list(st)
+    for (p, m, d), s in zip(items, st):
+        op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+        try:
+            want = int(bbs.core_proof_verify(suite, pk, op, gens, b"", b"", m, d, api_id))
+        except bbs.BbsError as e:
+            want = {"InvalidDisclosedIndex": -3, "InvalidIndicesAndMessagesLength": -6,
+                    "InvalidMessageAndGeneratorsLength": -1}[e.variant]
+        except bbs.BbsPanic:
+            want = -22
+        assert want == int(s), (want, int(s))
+    # forged public key = default (identity) -> Ok(false), never an error (:156-169)
+    eng2 = make_engine(curve, gens, api_id, lib_path, pk=None)
+    assert eng2.core_proof_verify(proof, b"", b"", dm, disclosed) is False
+    assert eng2.core_verify(sig, b"", msgs) is False
+    # sign / verify length errors (sign.rs:77-79, verify.rs:69-71)
+    sigs, st = eng.core_sign_batch([msgs, msgs[:-1]], [b"", b""])
+    assert list(st) == [1, -1] and sigs[1] is None
+    st = eng.core_verify_batch([sig, sig], [msgs, msgs + [1]], [b"", b""])
+    assert list(st) == [1, -1]
+    # proof_gen errors (proof_gen.rs:133-143, 233-235)
+    def pg(ms, d, nr):
+        try:
+            eng.core_proof_gen(sig, b"", b"", ms, d, [1] * nr)
+            return 1
+        except BbsError as e:
+            return e.status
+    assert pg(msgs, list(range(L)) + [0], 4) == -2          # r > l
+    assert pg(msgs, [0, L], 5 + L - 2) == -3                # index >= l
+    assert pg(msgs, [2, 2], 5 + L - 2) == -4                # duplicates: scalars sized from the un-deduped length
+    assert pg(msgs[:-1], [0], 5 + L - 2) == -1              # generators length
+    # unsorted disclosed indexes are sorted by proof_gen (proof_gen.rs:151-161)
+    p2 = eng.core_proof_gen(sig, b"", b"", msgs, [5, 0, 1], rnd)
+    assert proof_eq(p2, proof)
+    eng.close()
+    eng2.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def check_primitives(curve, lib_path=None):
+    rng = random.Random(11)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    L = 3
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, b"x", lib_path, sk=sk)
+    # hash_to_scalar: empty / short / block-boundary / long inputs
+    msgs = [b"", b"a", bytes(55), bytes(56), bytes(range(64)), bytes(rng.randrange(256) for _ in range(300))]
+    for dst in (b"", b"QUUX-V01-CS02", bytes(255)):
+        got = eng.hash_to_scalar_batch(msgs, dst)
+        from oracle.hashing import hash_to_scalar
+        assert got == [hash_to_scalar(c, m, dst) for m in msgs]
+    # MSM: fixed bases [P1, Q1, H1..], variable bases, edge scalars
+    bases = [suite.p1] + gens
+    n = 5
+    fs = [[rng.randrange(c.r) for _ in range(L + 2)] for _ in range(n)]
+    fs[0] = [0] * (L + 2)
+    fs[1] = [c.r - 1] * (L + 2)
+    vpts = [[c.g1_mul(c.g1, rng.randrange(1, c.r)), c.g1_mul(c.g1, rng.randrange(1, c.r))] for _ in range(n)]
+    vsc = [[rng.randrange(c.r), rng.randrange(c.r)] for _ in range(n)]
+    vpts[2][0] = None
+    vpts[3][1] = vpts[3][0]; vsc[3][1] = (c.r - vsc[3][0]) % c.r          # cancels to the identity
+    vpts[4] = [bases[0], bases[1]]                                         # equal to fixed bases (doubling path)
+    out, st = eng.g1_msm_batch(fs, vpts, vsc)
+    assert list(st) == [1] * n
+    for i in range(n):
+        want = None
+        for k in range(L + 2):
+            want = c.g1_add(want, c.g1_mul(bases[k], fs[i][k]))
+        for k in range(2):
+            want = c.g1_add(want, c.g1_mul(vpts[i][k], vsc[i][k]))
+        assert out[i] == want, (curve, i)
+    # pairing product e(Pa, pk) * e(Pb, BP2) == 1
+    a = rng.randrange(1, c.r)
+    Pa = [c.g1_mul(c.g1, a), c.g1_mul(c.g1, a), None, None, c.g1]
+    Pb = [c.g1_neg(c.g1_mul(c.g1, a * sk % c.r)), c.g1_mul(c.g1, a * sk % c.r), None, c.g1, None]
+    st = eng.pairing_product2_is_one_batch(Pa, Pb)
+    want = [int(c.pairing_product_is_one([(Pa[i], pk), (Pb[i], c.g2)])) for i in range(5)]
+    assert list(st) == want == [1, 0, 1, 0, 0]
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0):
+    """SURVEY 8d synthetic workload: one issuer key (IKM [1u8;32]), item b has L 32-byte messages
+    derived from (b, j), empty header / ph, disclosed 0..R, proof_gen scalars from the seeded
+    expander.  Signatures and proofs are produced by the engine itself (checked by the caller)."""
+    suite = bbs.SUITES[curve]
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    raw = [expand_message(b"bbs-bench-msg" + i2osp(b, 8) + i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32)
+           for b in range(n) for j in range(L)]
+    flat = eng.hash_to_scalar_batch(raw, api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
+    msgs = [flat[b * L:(b + 1) * L] for b in range(n)]
+    disclosed = [list(range(R))] * n
+    rnds = [bbs.seeded_random_scalars(suite, b"bbs-bench-rnd" + i2osp(b, 8), api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + L - R)
+            for b in range(n)]
+    return suite, eng, gens, sk, msgs, disclosed, rnds
+
+
+def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2):
+    """Full-size batch through size-independent properties: sign -> verify all true -> proof_gen ->
+    proof_verify all true; every 16th item corrupted -> exactly those false; a few items spot-checked
+    against the oracle."""
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, L, R, lib_path)
+    c = suite.curve
+    pk = bbs.sk_to_pk(suite, sk)
+    sigs, st = eng.core_sign_batch(msgs)
+    assert (st == 1).all()
+    st = eng.core_verify_batch(sigs, msgs)
+    assert (st == 1).all()
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    dm = [m[:R] for m in msgs]
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+    assert (st == 1).all()
+    for i in range(0, n, 16):
+        proofs[i].commitments[0] = (proofs[i].commitments[0] + 1) % c.r
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+    assert [int(x) for x in st] == [0 if i % 16 == 0 else 1 for i in range(n)]
+    for i in ([1, n - 1][:spot]):
+        want_sig = bbs.core_sign(suite, sk, gens, b"", msgs[i], suite.api_id)
+        assert (sigs[i].a, sigs[i].e) == (want_sig.a, want_sig.e)
+        want = bbs.core_proof_gen(suite, pk, want_sig, b"", gens, b"", msgs[i], disclosed[i], suite.api_id, rnds[i])
+        assert proof_eq(proofs[i], want)
+    eng.close()

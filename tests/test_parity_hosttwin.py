@@ -1,0 +1,43 @@
+"""Host-logic checks through the TEST-ONLY host twin (same stage code compiled for x86): validation
+order, packing, index bookkeeping, byte formats.  NOT a parity claim about the GPU product -- that is
+tests/test_parity_gpu.py (-m gpu)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import parity_cases as pc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def twin():
+    sys.path.insert(0, ROOT)
+    from bbs_sign_amd import build as b
+    return b.build(twin=True, verbose=False)
+
+
+def test_kat_vectors(twin):
+    pc.check_kat_vectors(twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_golden_small(twin, curve):
+    pc.check_golden(curve, twin, max_L=10)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_random_batch(twin, curve):
+    pc.check_random_batch(curve, twin, n=6, L=5, seed=1)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_error_semantics(twin, curve):
+    pc.check_error_semantics(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_primitives(twin, curve):
+    pc.check_primitives(curve, twin)
