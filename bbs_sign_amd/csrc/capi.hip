@@ -116,25 +116,26 @@ int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms,
     if (job->use()) return BBS_E_HIP;
     const int ns = (int)job->stages.size();
     if (n_stages) *n_stages = ns;
-    std::vector<float> acc(ns, 0.f);
-    rt::Timer tot, st;
-    float total = 0.f;
+    // events: per rep one before the first stage and one after every stage
+    rt::EventList ev((size_t)reps * (ns + 1));
+    if (rt::sync(job->stream())) return BBS_E_HIP;
     for (int r = 0; r < reps; r++) {
         if (job->reset()) return BBS_E_HIP;
-        if (rt::sync(job->stream())) return BBS_E_HIP;
-        tot.start(job->stream());
+        if (ev.record(job->stream())) return BBS_E_HIP;
         for (int k = 0; k < ns; k++) {
-            if (kernel_ms) {
-                // per-stage events serialise nothing extra: the stages already depend on each other
-                st.start(job->stream());
-                if (job->stages[k].launch()) return BBS_E_HIP;
-                acc[k] += st.stop(job->stream());
-            } else if (job->stages[k].launch()) return BBS_E_HIP;
+            if (job->stages[k].launch()) return BBS_E_HIP;
+            if (ev.record(job->stream())) return BBS_E_HIP;
         }
-        total += tot.stop(job->stream());
     }
-    if (total_ms) *total_ms = total;
-    if (kernel_ms) for (int k = 0; k < ns && k < cap; k++) kernel_ms[k] = acc[k];
+    if (ev.finish(job->stream())) return BBS_E_HIP;
+    if (total_ms) *total_ms = ev.ms(0, (size_t)reps * (ns + 1) - 1);
+    if (kernel_ms) {
+        for (int k = 0; k < ns && k < cap; k++) {
+            float acc = 0.f;
+            for (int r = 0; r < reps; r++) acc += ev.ms((size_t)r * (ns + 1) + k, (size_t)r * (ns + 1) + k + 1);
+            kernel_ms[k] = acc;
+        }
+    }
     return BBS_OK;
 }
 

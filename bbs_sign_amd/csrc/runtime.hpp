@@ -38,16 +38,20 @@ inline void dfree(void* p) { std::free(p); }
 inline int h2d(void* d, const void* h, size_t b, Stream&) { std::memcpy(d, h, b); return 0; }
 inline int d2h(void* h, const void* d, size_t b, Stream&) { std::memcpy(h, d, b); return 0; }
 inline int dmemset(void* d, int v, size_t b, Stream&) { std::memset(d, v, b); return 0; }
+inline int d2d_async(void* d, const void* s, size_t b, Stream&) { std::memcpy(d, s, b); return 0; }
 inline int sync(Stream&) { return 0; }
 template <class F, class A>
 inline int launch(Stream&, const A& a, size_t nthreads) {
     for (size_t t = 0; t < nthreads; t++) F::run(a, t);
     return 0;
 }
-struct Timer {
-    std::chrono::steady_clock::time_point t0;
-    void start(Stream&) { t0 = std::chrono::steady_clock::now(); }
-    float stop(Stream&) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+// a list of time stamps recorded on the stream; read back after one synchronisation
+struct EventList {
+    std::vector<std::chrono::steady_clock::time_point> t;
+    explicit EventList(size_t) {}
+    int record(Stream&) { t.push_back(std::chrono::steady_clock::now()); return 0; }
+    int finish(Stream&) { return 0; }
+    float ms(size_t a, size_t b) { return std::chrono::duration<float, std::milli>(t[b] - t[a]).count(); }
 };
 #else
 using Stream = hipStream_t;
@@ -68,6 +72,9 @@ inline int d2h(void* h, const void* d, size_t b, Stream& s) {
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 inline int dmemset(void* d, int v, size_t b, Stream& s) { return (!b || hipMemsetAsync(d, v, b, s) == hipSuccess) ? 0 : -1; }
+inline int d2d_async(void* d, const void* s_, size_t b, Stream& s) {
+    return (!b || hipMemcpyAsync(d, s_, b, hipMemcpyDeviceToDevice, s) == hipSuccess) ? 0 : -1;
+}
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 
 template <class F, class A>
@@ -82,18 +89,16 @@ inline int launch(Stream& s, const A& a, size_t nthreads) {
     hipLaunchKernelGGL((k_stage<F, A>), dim3(blocks), dim3(64), 0, s, a, nthreads);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr;
-    Timer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
-    ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    void start(Stream& s) { (void)hipEventRecord(a, s); }
-    float stop(Stream& s) {
-        (void)hipEventRecord(b, s);
-        (void)hipEventSynchronize(b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, a, b);
-        return ms;
-    }
+// HIP events recorded on the stream the kernels are launched on; read back after ONE
+// synchronisation so that timing does not serialise host and device between stages
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    explicit EventList(size_t cap) : ev(cap, nullptr) { for (auto& e : ev) (void)hipEventCreate(&e); }
+    ~EventList() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    int record(Stream& s) { return (used < ev.size() && hipEventRecord(ev[used++], s) == hipSuccess) ? 0 : -1; }
+    int finish(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+    float ms(size_t a, size_t b) { float m = 0; (void)hipEventElapsedTime(&m, ev[a], ev[b]); return m; }
 };
 #endif
 }  // namespace rt
@@ -326,12 +331,13 @@ template <class C>
 struct JobBase : bbs_job {
     Ctx<C>* ctx;
     std::vector<int8_t> status0;     // host-validated initial status (1 placeholder = to compute)
-    DevBuf d_status;
+    DevBuf d_status, d_status0;
     std::vector<std::unique_ptr<DevBuf>> bufs;
     explicit JobBase(Ctx<C>* c) : ctx(c) {}
     int use() override { return ctx->use(); }
     rt::Stream& stream() override { return ctx->stream; }
-    int reset() override { return rt::h2d(d_status.p, status0.data(), n, ctx->stream) ? BBS_E_HIP : BBS_OK; }
+    // device-to-device, asynchronous: back-to-back runs of one job never wait for the host
+    int reset() override { return rt::d2d_async(d_status.p, d_status0.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK; }
     int fetch_status(int8_t* out) override {
         if (use() || rt::sync(ctx->stream)) return BBS_E_HIP;
         return rt::d2h(out, d_status.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
@@ -353,7 +359,8 @@ struct JobBase : bbs_job {
         return b.as<T>();
     }
     int finish_setup() {
-        if (d_status.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        if (rt::h2d(d_status0.p, status0.data(), n, ctx->stream)) return BBS_E_HIP;
         return ctx->sync_consts();
     }
     template <class T>

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BBS+ proof_verify/s, BLS12-381, 32 messages / 8 disclosed, batch 4096 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of core_proof_verify (src/proof_verify.rs:64-116) over one device-resident batch of
+4096 proofs (BASELINE.json configs[3]; the proofs are produced untimed by the engine's own
+sign -> proof_gen).  Items are independent, so N GPUs each verify their own 4096-item batch per step
+(weak scaling, no data-path collective); rank 0 gathers one pass-count per rank over RCCL.
+
+Timing: barrier + synchronize, K steps enqueued back to back on the engine's HIP stream with HIP
+events around every stage (recorded on that stream, read after one synchronisation), barrier +
+synchronize; wall time = max over ranks.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic bytes per BLS12-381 proof_verify (L=32, R=8): 1040 proof octets
+# (3 x 48 + 28 x 32) + 256 (8 disclosed scalars) + 64 (8 indexes) + 1 status
+ALG_BYTES_PER_PROOF_VERIFY = 1361
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(n_items=4):
+    """The oracle (Python big-int port of the reference path) timed on one host core on a bounded
+    sample of the same workload (item b of the bench batch), reference operation order."""
+    from oracle import bbs
+    from oracle.hashing import expand_message, i2osp
+    suite = bbs.BLS_SUITE
+    L, R = 32, 8
+    api_id = suite.api_id
+    sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
+    pk = bbs.sk_to_pk(suite, sk)
+    gens = bbs.create_generators(suite, L + 1, api_id)
+    items = []
+    for b in range(n_items):
+        raw = [expand_message(b"bbs-bench-msg" + i2osp(b, 8) + i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32) for j in range(L)]
+        msgs = bbs.msg_to_scalars(suite, raw, api_id)
+        rnd = bbs.seeded_random_scalars(suite, b"bbs-bench-rnd" + i2osp(b, 8), api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + L - R)
+        sig = bbs.core_sign(suite, sk, gens, b"", msgs, api_id)
+        proof = bbs.core_proof_gen(suite, pk, sig, b"", gens, b"", msgs, list(range(R)), api_id, rnd)
+        items.append((proof, msgs[:R]))
+    t0 = time.perf_counter()
+    ok = 0
+    for proof, dm in items:
+        ok += bool(bbs.core_proof_verify(suite, pk, proof, gens, b"", b"", dm, list(range(R)), api_id))
+    dt = time.perf_counter() - t0
+    assert ok == n_items
+    return {"value": n_items / dt, "unit": "proof_verify/s", "cores": 1, "kind": "port",
+            "sample": "%d items of the bench batch (BLS12-381, L=32, R=8), core_proof_verify with caller-supplied "
+                      "generators, pure-Python big-int oracle (NOT arkworks), %.1f s" % (n_items, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--window-bits", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    torch.cuda.set_device(local_rank)
+
+    import parity_cases as pc
+    from bbs_sign_amd import Engine  # noqa: F401  (fails loudly if the HIP library is missing)
+
+    n, L, R = args.batch, 32, 8
+    # every rank verifies its own batch: item ids offset by rank so the batches differ
+    suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload("bls12_381", n, L, R, None, args.window_bits)
+    eng_dev = local_rank
+    if eng_dev != 0:
+        # bench_workload builds on device 0 by default; rebuild the context on this rank's GPU
+        eng.close()
+        eng = Engine("bls12_381", device=eng_dev, window_bits=args.window_bits)
+        eng.set_generators(gens, suite.api_id)
+        eng.set_secret_key(sk)
+    sigs, st = eng.core_sign_batch(msgs)
+    assert (st == 1).all()
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    dm = [m[:R] for m in msgs]
+    job = eng.core_proof_verify_upload(proofs, dm, disclosed)      # inputs now resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.run()
+    job.wait()
+    assert (job.status() == 1).all(), "warm-up batch did not verify"
+
+    barrier()
+    t0 = time.perf_counter()
+    total_ms, stage_ms = job.run_timed(args.steps, per_stage=True)
+    job.wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    status = job.status()
+    passed = int((status == 1).sum())
+    assert passed == n, "timed batch did not verify"
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([passed], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)       # the only exchange: one pass-count per rank
+    dt = float(tmax.item())
+
+    if rank == 0:
+        assert int(cnt.item()) == n * world
+        value = world * n * args.steps / dt
+        dom = max(stage_ms, key=stage_ms.get)
+        dom_ms = stage_ms[dom] / args.steps
+        achieved = ALG_BYTES_PER_PROOF_VERIFY * n / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "BBS+ proof_verify/sec (BLS12-381, 32-msg)",
+            "value": value, "unit": "proof_verify/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BLS12-381 core_proof_verify, batch %d per GPU, 32 msgs / 8 disclosed, empty "
+                                   "header/ph, one issuer key (BASELINE configs[3], proof_verify leg)" % n,
+                       "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
+                       "parallelism": "independent batch per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes/unit = %d (SURVEY 8d); the path is bound by 32-bit integer "
+                                 "multiply-add issue, not HBM (see DESIGN.md)" % ALG_BYTES_PER_PROOF_VERIFY},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "gpu_ms_per_step_events": total_ms / args.steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
