@@ -1,0 +1,44 @@
+"""Static sharding of a global batch of independent items over the GPUs of one node.
+
+Items of the BBS+ hot path share no mutable state, so multi-GPU is a partition, not
+a collective: every rank verifies a contiguous range and only a per-rank pass count (or the status
+bytes) is exchanged.  Mixed batches are split by curve first (a BLS12-381 item costs ~2.5x a BN254
+item), then evenly inside each curve, so every rank gets the same cost."""
+from typing import Dict, List, Sequence, Tuple
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of `n_items` for `rank` of `world`; sizes differ by at most one."""
+    if world < 1 or not (0 <= rank < world) or n_items < 0:
+        raise ValueError("bad shard request")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_plan(curve_of_item: Sequence[str], world: int) -> List[Dict[str, List[int]]]:
+    """For a mixed batch (curve name per item) return, per rank, {curve: [global item ids]}."""
+    by_curve: Dict[str, List[int]] = {}
+    for i, c in enumerate(curve_of_item):
+        by_curve.setdefault(c, []).append(i)
+    plan: List[Dict[str, List[int]]] = [dict() for _ in range(world)]
+    for c, ids in sorted(by_curve.items()):
+        for r in range(world):
+            lo, hi = shard_range(len(ids), world, r)
+            plan[r][c] = ids[lo:hi]
+    return plan
+
+
+def merge_status(plan: List[Dict[str, List[int]]], per_rank_status: List[Dict[str, Sequence[int]]], n_items: int) -> List[int]:
+    """Inverse of shard_plan for the gathered per-rank status lists."""
+    out = [None] * n_items
+    for r, shard in enumerate(plan):
+        for c, ids in shard.items():
+            st = per_rank_status[r][c]
+            if len(st) != len(ids):
+                raise ValueError("rank %d returned %d statuses for %d items" % (r, len(st), len(ids)))
+            for i, s in zip(ids, st):
+                out[i] = int(s)
+    if any(s is None for s in out):
+        raise ValueError("items without a status")
+    return out

@@ -1,0 +1,39 @@
+"""The product library builds for gfx950, loads, and exports every symbol include/bbs_sign_amd.h
+declares (no compute calls: there is no GPU in the CPU test tier)."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_library_exports_header_symbols():
+    from bbs_sign_amd import _lib, build
+    path = build.build(twin=False, verbose=False)
+    lib = _lib.load_library(path)
+    header = open(os.path.join(ROOT, "include", "bbs_sign_amd.h")).read()
+    declared = set(re.findall(r"\b(bbs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.bbs_version()
+
+
+def test_product_has_no_cpu_fallback():
+    """Without a GPU a context cannot be created: the call fails loudly instead of computing on the CPU."""
+    import ctypes
+    from bbs_sign_amd import _lib, build
+    lib = _lib.load_library(build.build(twin=False, verbose=False))
+    if lib.bbs_device_count() > 0:
+        return                      # running on a GPU box
+    h = ctypes.c_void_p()
+    assert lib.bbs_ctx_create(0, 0, ctypes.byref(h)) == -104      # BBS_E_NO_DEVICE
+
+
+def test_missing_library_raises():
+    import pytest
+    from bbs_sign_amd import _lib
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.load_library("/nonexistent/libbbs_sign_amd.so")
