@@ -129,39 +129,66 @@ BBS_HD Fe<P> fe_dbl(const Fe<P>& a) {
     return fe_add<P>(a, a);
 }
 
-// Montgomery product a*b/R mod p (CIOS, 32-bit limbs, 64-bit accumulation = v_mad_u64_u32)
+}  // namespace bbs
+#include "fe_mul_asm_gen.hpp"
+namespace bbs {
+
+// 96-bit accumulator (lo:64, hi:32) += a*b.  On gfx950 this is exactly two instructions:
+// v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) and v_addc_co_u32 folding the carry into hi.
+// Measured on MI355X (tools/ubench/valu_int.hip): every VALU instruction of this mix issues at the
+// same ~2 ns per wave-instruction per SIMD, so the instruction COUNT is the cost -- product scanning
+// with an explicit carry word (2 instr / MAC) replaces the CIOS form (4.3 instr / MAC as compiled).
+BBS_HD void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+    const uint64_t p = (uint64_t)a * b;
+    lo += p;
+    hi += (lo < p) ? 1u : 0u;
+}
+// 96-bit accumulator += x (32-bit)
+BBS_HD void acc96_add32(uint64_t& lo, uint32_t& hi, uint32_t x) {
+    const uint64_t o = lo;
+    lo += x;
+    hi += (lo < o) ? 1u : 0u;
+}
+
+// Montgomery product a*b/R mod p: product scanning (column-wise, "FIPS"), 32-bit limbs.
+//   columns 0..N-1 : acc += sum_{i+j=c} a_i b_j + sum_{i+j=c, i<c} m_i p_j ; m_c = acc_lo * INV ;
+//                    acc += m_c p_0 (low word becomes 0) ; acc >>= 32
+//   columns N..2N-1: acc += sum a_i b_j + sum m_i p_j ; r_{c-N} = acc_lo ; acc >>= 32
 template <class P>
 BBS_HD void fe_mul_raw(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // device: the generated asm-block form of exactly this algorithm (fe_mul_asm_gen.hpp)
+    if constexpr (P::N == 12) { fe_mul_ps12<P>(r, a, b); return; }
+    else if constexpr (P::N == 8) { fe_mul_ps8<P>(r, a, b); return; }
+#endif
     constexpr int N = P::N;
-    uint32_t t[N + 2];
+    uint32_t m[N];
+    uint32_t t[N + 1];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
 #pragma unroll
-    for (int i = 0; i < N + 2; i++) t[i] = 0;
+    for (int c = 0; c < N; c++) {
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t c = 0;
-        const uint32_t bi = b[i];
+        for (int i = 0; i <= c; i++) mac96(lo, hi, a[i], b[c - i]);
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            c += (uint64_t)a[j] * bi + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[N];
-        t[N] = (uint32_t)c;
-        t[N + 1] = (uint32_t)(c >> 32);
-        const uint32_t m = t[0] * P::INV;
-        c = (uint64_t)m * P::MOD[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < N; j++) {
-            c += (uint64_t)m * P::MOD[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[N];
-        t[N - 1] = (uint32_t)c;
-        t[N] = t[N + 1] + (uint32_t)(c >> 32);
+        for (int i = 0; i < c; i++) mac96(lo, hi, m[i], P::MOD[c - i]);
+        m[c] = (uint32_t)lo * P::INV;
+        mac96(lo, hi, m[c], P::MOD[0]);
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
     }
+#pragma unroll
+    for (int c = N; c < 2 * N - 1; c++) {
+#pragma unroll
+        for (int i = c - N + 1; i < N; i++) mac96(lo, hi, a[i], b[c - i]);
+#pragma unroll
+        for (int i = c - N + 1; i < N; i++) mac96(lo, hi, m[i], P::MOD[c - i]);
+        t[c - N] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    t[N - 1] = (uint32_t)lo;
+    t[N] = (uint32_t)(lo >> 32);
     fe_cond_sub_mod<P>(t, t[N]);
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = t[i];
