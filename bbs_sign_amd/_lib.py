@@ -56,6 +56,7 @@ SIGNATURES = {
     "bbs_hash_to_scalar_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, sz, c_u8p]),
     "bbs_g1_msm_batch": (ci, [vp, sz, c_u8p, sz, c_u8p, c_u8p, sz, c_u8p, c_i8p]),
     "bbs_pairing_product2_is_one_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
+    "bbs_selftest_f12": (ci, [vp, ci, c_u8p, c_u8p, c_u8p, c_u8p]),
 }
 
 _cache = {}

@@ -198,6 +198,11 @@ int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fs, size_t nf, const
     return DISPATCH(ctx, msm_batch<BlsCurve>(AS_BLS(ctx), n, fs, nf, vp, vs, nv, out, status), msm_batch<BnCurve>(AS_BN(ctx), n, fs, nf, vp, vs, nv, out, status));
 }
 
+int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single, uint8_t* out_dist) {
+    if (!ctx || !a || !b || !out_single || !out_dist) return BBS_E_ARG;
+    return DISPATCH(ctx, selftest_f12<BlsCurve>(AS_BLS(ctx), op, a, b, out_single, out_dist), selftest_f12<BnCurve>(AS_BN(ctx), op, a, b, out_single, out_dist));
+}
+
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
     if (!ctx) return BBS_E_ARG;
     return DISPATCH(ctx, pairing_batch<BlsCurve>(AS_BLS(ctx), n, pa, pb, status), pairing_batch<BnCurve>(AS_BN(ctx), n, pa, pb, status));

@@ -129,7 +129,47 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     PairArgs<C> a;
     a.n = n; a.cc = ctx->d_consts.template as<CtxConsts<C>>(); a.pa = dAm.as<uint32_t>(); a.pb = dBm.as<uint32_t>();
     a.negate_b = 0; a.status = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
+#ifdef BBS_HOST_TWIN
     if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) || rt::launch<PairMiller<C>>(ctx->stream, a, n * 2) ||
         rt::launch<PairFinal<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+#else
+    if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) ||
+        rt::launch<PairDist<C>>(ctx->stream, a, ((n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64) || rt::sync(ctx->stream)) return BBS_E_HIP;
+#endif
     return rt::d2h(status, dSt.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
+}
+
+// GPU self-test of the lane-sliced Fp12 against the one-lane code (product build only)
+template <class C>
+int selftest_f12(Ctx<C>* ctx, int op, const uint8_t* a_le, const uint8_t* b_le, uint8_t* out_single, uint8_t* out_dist) {
+#ifdef BBS_HOST_TWIN
+    (void)ctx; (void)op; (void)a_le; (void)b_le; (void)out_single; (void)out_dist;
+    return BBS_E_ARG;
+#else
+    constexpr int N = C::FpP::N;
+    constexpr int FPB = 4 * N;
+    if (ctx->use()) return BBS_E_HIP;
+    std::vector<uint32_t> A(12 * N), B(12 * N);
+    for (int k = 0; k < 12; k++) {
+        Fe<typename C::FpP> x, y;
+        if (!fe_from_le_bytes<typename C::FpP>(a_le + k * FPB, x) || !fe_from_le_bytes<typename C::FpP>(b_le + k * FPB, y)) return BBS_E_ARG;
+        for (int j = 0; j < N; j++) { A[k * N + j] = x.v[j]; B[k * N + j] = y.v[j]; }
+    }
+    DevBuf dA, dB, dS, dD;
+    if (dA.alloc(A.size() * 4) || dB.alloc(B.size() * 4) || dS.alloc(A.size() * 4) || dD.alloc(A.size() * 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dA.p, A.data(), A.size() * 4, ctx->stream) || rt::h2d(dB.p, B.data(), B.size() * 4, ctx->stream)) return BBS_E_HIP;
+    int rc = ctx->sync_consts();
+    if (rc) return rc;
+    SelfTestArgs<C> a{op, ctx->d_consts.template as<CtxConsts<C>>(), dA.as<uint32_t>(), dB.as<uint32_t>(), dS.as<uint32_t>(), dD.as<uint32_t>()};
+    if (rt::launch<SelfTestF12<C>>(ctx->stream, a, 64) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> S(12 * N), D(12 * N);
+    if (rt::d2h(S.data(), dS.p, S.size() * 4, ctx->stream) || rt::d2h(D.data(), dD.p, D.size() * 4, ctx->stream)) return BBS_E_HIP;
+    for (int k = 0; k < 12; k++) {
+        Fe<typename C::FpP> x, y;
+        for (int j = 0; j < N; j++) { x.v[j] = S[k * N + j]; y.v[j] = D[k * N + j]; }
+        fe_to_le_bytes<typename C::FpP>(x, out_single + k * FPB);
+        fe_to_le_bytes<typename C::FpP>(y, out_dist + k * FPB);
+    }
+    return BBS_OK;
+#endif
 }

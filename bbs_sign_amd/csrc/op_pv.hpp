@@ -98,8 +98,12 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->ctx->stream, j->a, j->n); }});
     j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->ctx->stream, j->a, j->n * PV_NPARTS); }});
     j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->ctx->stream, j->a, j->n); }});
+#ifdef BBS_HOST_TWIN
     j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->ctx->stream, j->pa, j->n * 2); }});
     j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->ctx->stream, j->pa, j->n); }});
+#else
+    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->ctx->stream, j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
+#endif
     *out = job.release();
     return BBS_OK;
 }

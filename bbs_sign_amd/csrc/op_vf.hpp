@@ -58,8 +58,12 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->ctx->stream, j->a, j->n); }});
     j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->ctx->stream, j->a, j->n * VF_NPARTS); }});
     j->stages.push_back({"vf_combine", [j]() { return rt::launch<VfCombine<C>>(j->ctx->stream, j->a, j->n); }});
+#ifdef BBS_HOST_TWIN
     j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->ctx->stream, j->pa, j->n * 2); }});
     j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->ctx->stream, j->pa, j->n); }});
+#else
+    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->ctx->stream, j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
+#endif
     *out = job.release();
     return BBS_OK;
 }

@@ -7,6 +7,7 @@ template <class C> int sg_upload(Ctx<C>*, size_t, const uint8_t*, const uint64_t
 template <class C> int pg_upload(Ctx<C>*, size_t, const uint8_t*, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, bbs_job**);
 template <class C> int h2s_batch(Ctx<C>*, size_t, const uint8_t*, const uint64_t*, const uint8_t*, size_t, uint8_t*);
 template <class C> int msm_batch(Ctx<C>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
+template <class C> int selftest_f12(Ctx<C>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
 template <class C> int pairing_batch(Ctx<C>*, size_t, const uint8_t*, const uint8_t*, int8_t*);
 extern template int pv_upload<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, bbs_job**);
 extern template int pv_upload<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, bbs_job**);
@@ -24,3 +25,5 @@ extern template int Ctx<BnCurve>::set_generators(const uint8_t*, size_t, const u
 extern template int h2s_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint64_t*, const uint8_t*, size_t, uint8_t*);
 extern template int msm_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
 extern template int pairing_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, int8_t*);
+extern template int selftest_f12<BlsCurve>(Ctx<BlsCurve>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+extern template int selftest_f12<BnCurve>(Ctx<BnCurve>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);

@@ -1,0 +1,238 @@
+// Wavefront-cooperative pairing check: ONE Fp12 value is spread over SIX lanes.
+//
+// A batch of 4096 pairing checks with one item per lane is 64 wavefronts on a chip with 1024
+// SIMDs, and an Fp12 value is 144 VGPRs, so the one-lane form (pairing.hpp) runs at 6 % of the
+// SIMDs and spills 8 KB per lane.  Here f = sum_{m<6} g_m w^m (w^6 = xi) and lane m of a
+// six-lane group holds only g_m in Fp2 (24 VGPRs for BLS12-381); operands move between the lanes
+// of a group with ds_bpermute (__shfl).  Ten groups share one wavefront (lanes 60..63 idle).
+//
+//   mul        : lane m multiplies its g_m by every h_j (broadcast), the products are rotated to
+//                lane (m+j) mod 6 (times xi when m+j >= 6) and summed        6 Fp2 mul per lane
+//   line (M/D) : sparse, 3 non-zero coefficients                              3 Fp2-ish mul
+//   cyclotomic square (Granger-Scott over Fp4 pairs (m, m+3))                 2 Fp2 sqr
+//   conj, frob : lane-local
+//   inverse    : gathered on every lane (once per item)
+//
+// Same group elements / booleans as pairing.hpp; selftest entry points compare the two on the GPU.
+#pragma once
+#include "pairing.hpp"
+
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(BBS_HOST_TWIN)
+namespace bbs {
+
+constexpr int GRP = 6;                 // lanes per item
+constexpr int GRP_PER_WAVE = 10;
+
+struct Lane6 {
+    int base;     // first lane of the group inside the wavefront
+    int m;        // coefficient index 0..5 held by this lane
+};
+
+template <class P>
+__device__ __forceinline__ Fe<P> fe_shfl(const Fe<P>& v, int src_lane) {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.v[i] = (uint32_t)__shfl((int)v.v[i], src_lane, 64);
+    return r;
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> f2_shfl(const Fp2<C>& v, int src_lane) {
+    return {fe_shfl<typename C::FpP>(v.c0, src_lane), fe_shfl<typename C::FpP>(v.c1, src_lane)};
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> f2_sel(bool c, const Fp2<C>& a, const Fp2<C>& b) {
+    return {fe_select<typename C::FpP>(c, a.c0, b.c0), fe_select<typename C::FpP>(c, a.c1, b.c1)};
+}
+
+// value of coefficient `src` (0..5) of the group's element
+template <class C>
+__device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int src) { return f2_shfl<C>(g, L.base + src); }
+
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
+    Fp2<C> acc = f2_zero<C>();
+    for (int j = 0; j < GRP; j++) {
+        Fp2<C> hj = d_coef<C>(L, h, j);
+        Fp2<C> p = f2_mul<C>(g, hj);                       // g_m h_j -> w^(m+j)
+        p = f2_sel<C>(L.m + j >= GRP, f2_mul_xi<C>(p), p);
+        int src = L.m - j;                                  // lane k receives from lane (k - j) mod 6
+        if (src < 0) src += GRP;
+        acc = f2_add<C>(acc, f2_shfl<C>(p, L.base + src));
+    }
+    return acc;
+}
+
+template <class C>
+__device__ __forceinline__ Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) { return d_mul<C>(L, g, g); }
+
+template <class C>
+__device__ __forceinline__ Fp2<C> d_conj(const Lane6& L, const Fp2<C>& g) {   // w -> -w
+    return f2_sel<C>((L.m & 1) != 0, f2_neg<C>(g), g);
+}
+
+// multiply by the line through the twist point evaluated at P (see pairing.hpp for the forms)
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEntry<C>& le, const G1Aff<C>& P) {
+    using FPp = typename C::FpP;
+    Fp2<C> lx = f2_mul_fp<C>(le.nl, P.x);
+    int s1, s2;
+    Fp2<C> t0, t1, t2;
+    if constexpr (C::K::TWIST_M) {
+        // l = c + lx w^2 + yP w^3 :  c_k = g_k c + xi^[k<2] g_{k-2} lx + xi^[k<3] g_{k-3} yP
+        s1 = L.m - 2; s2 = L.m - 3;
+        t0 = f2_mul<C>(g, le.c);
+        Fp2<C> a = d_coef<C>(L, g, s1 < 0 ? s1 + GRP : s1);
+        Fp2<C> b = d_coef<C>(L, g, s2 < 0 ? s2 + GRP : s2);
+        t1 = f2_mul<C>(a, lx);
+        t2 = f2_mul_fp<C>(b, P.y);
+    } else {
+        // l = yP + lx w + c w^3    :  c_k = g_k yP + xi^[k<1] g_{k-1} lx + xi^[k<3] g_{k-3} c
+        s1 = L.m - 1; s2 = L.m - 3;
+        t0 = f2_mul_fp<C>(g, P.y);
+        Fp2<C> a = d_coef<C>(L, g, s1 < 0 ? s1 + GRP : s1);
+        Fp2<C> b = d_coef<C>(L, g, s2 < 0 ? s2 + GRP : s2);
+        t1 = f2_mul<C>(a, lx);
+        t2 = f2_mul<C>(b, le.c);
+    }
+    t1 = f2_sel<C>(s1 < 0, f2_mul_xi<C>(t1), t1);
+    t2 = f2_sel<C>(s2 < 0, f2_mul_xi<C>(t2), t2);
+    (void)sizeof(FPp);
+    return f2_add<C>(f2_add<C>(t0, t1), t2);
+}
+
+// Granger-Scott squaring of a cyclotomic element: Fp4 pairs (g_m, g_{m+3}), m = 0,1,2
+//   X = (x0, x1):  X^2 = (x0^2 + xi x1^2, 2 x0 x1)
+//   g0' = 3 A2[0] - 2 g0   g3' = 3 A2[1] + 2 g3
+//   g1' = 3 xi C2[1] + 2 g1   g4' = 3 C2[0] - 2 g4
+//   g2' = 3 B2[0] - 2 g2   g5' = 3 B2[1] + 2 g5
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
+    const bool hi = L.m >= 3;
+    const int partner = hi ? L.m - 3 : L.m + 3;
+    Fp2<C> px = d_coef<C>(L, g, partner);
+    Fp2<C> u = f2_sqr<C>(g);                                // x0^2 on the low lane, x1^2 on the high lane
+    Fp2<C> v = f2_sqr<C>(f2_add<C>(g, px));                 // (x0 + x1)^2 on both
+    Fp2<C> pu = d_coef<C>(L, u, partner);
+    Fp2<C> lo_val = f2_add<C>(u, f2_mul_xi<C>(pu));         // x0^2 + xi x1^2   (valid on the low lane)
+    Fp2<C> hi_val = f2_sub<C>(f2_sub<C>(v, u), pu);         // 2 x0 x1          (valid on the high lane)
+    Fp2<C> sq = f2_sel<C>(hi, hi_val, lo_val);              // lane m<3: X2[0] of pair m ; m>=3: X2[1] of pair m-3
+    // pull pattern: 0<-0, 3<-3, 1<-5, 4<-2, 2<-1, 5<-4
+    const int src = (L.m == 0) ? 0 : (L.m == 3) ? 3 : (L.m == 1) ? 5 : (L.m == 4) ? 2 : (L.m == 2) ? 1 : 4;
+    Fp2<C> t = d_coef<C>(L, sq, src);
+    t = f2_sel<C>(L.m == 1, f2_mul_xi<C>(t), t);
+    Fp2<C> t3 = f2_add<C>(f2_dbl<C>(t), t);
+    Fp2<C> g2 = f2_dbl<C>(g);
+    return f2_sel<C>((L.m & 1) != 0, f2_add<C>(t3, g2), f2_sub<C>(t3, g2));
+}
+
+template <class C, int K>
+__device__ __attribute__((noinline)) Fp2<C> d_frob(const Lane6& L, const Fp2<C>& g, const uint32_t* frob_tab) {
+    // frob_tab: [3][6][2][N] Montgomery constants xi^(m (p^K - 1)/6)
+    constexpr int N = C::FpP::N;
+    Fp2<C> co;
+    const uint32_t* t = frob_tab + ((size_t)(K - 1) * 6 + L.m) * 2 * N;
+#pragma unroll
+    for (int j = 0; j < N; j++) { co.c0.v[j] = t[j]; co.c1.v[j] = t[N + j]; }
+    Fp2<C> x = (K & 1) ? f2_conj<C>(g) : g;
+    return f2_mul<C>(x, co);
+}
+
+// gather the whole element on every lane (tower layout: c0 = (g0, g2, g4), c1 = (g1, g3, g5))
+template <class C>
+__device__ __attribute__((noinline)) Fp12<C> d_gather(const Lane6& L, const Fp2<C>& g) {
+    Fp12<C> f;
+    f.c0.c0 = d_coef<C>(L, g, 0); f.c1.c0 = d_coef<C>(L, g, 1);
+    f.c0.c1 = d_coef<C>(L, g, 2); f.c1.c1 = d_coef<C>(L, g, 3);
+    f.c0.c2 = d_coef<C>(L, g, 4); f.c1.c2 = d_coef<C>(L, g, 5);
+    return f;
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> d_scatter(const Lane6& L, const Fp12<C>& f) {
+    Fp2<C> r = f.c0.c0;
+    r = f2_sel<C>(L.m == 1, f.c1.c0, r);
+    r = f2_sel<C>(L.m == 2, f.c0.c1, r);
+    r = f2_sel<C>(L.m == 3, f.c1.c1, r);
+    r = f2_sel<C>(L.m == 4, f.c0.c2, r);
+    r = f2_sel<C>(L.m == 5, f.c1.c2, r);
+    return r;
+}
+
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_inv(const Lane6& L, const Fp2<C>& g) {
+    return d_scatter<C>(L, f12_inv<C>(d_gather<C>(L, g)));
+}
+
+template <class C>
+__device__ __forceinline__ Fp2<C> d_one(const Lane6& L) { return f2_sel<C>(L.m == 0, f2_one<C>(), f2_zero<C>()); }
+
+template <class C>
+__device__ __forceinline__ bool d_is_one(const Lane6& L, const Fp2<C>& g) {
+    int ok = f2_eq<C>(g, d_one<C>(L)) ? 1 : 0;
+    int all = 1;
+    for (int j = 0; j < GRP; j++) all &= __shfl(ok, L.base + j, 64);
+    return all != 0;
+}
+
+// f^|x| (f cyclotomic)
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_pow_xabs(const Lane6& L, const Fp2<C>& f) {
+    Fp2<C> r = f;
+    const uint64_t x = C::K::X_ABS;
+    int top = 63;
+    while (!((x >> top) & 1)) top--;
+    for (int i = top - 1; i >= 0; i--) {
+        r = d_cyclo_sqr<C>(L, r);
+        if ((x >> i) & 1) r = d_mul<C>(L, r, f);
+    }
+    return r;
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> d_pow_x(const Lane6& L, const Fp2<C>& f) {
+    Fp2<C> r = d_pow_xabs<C>(L, f);
+    if constexpr (C::K::X_NEG) r = d_conj<C>(L, r);
+    return r;
+}
+
+// same exponent as final_exponentiation() in pairing.hpp
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_final_exp(const Lane6& L, const Fp2<C>& f_in, const uint32_t* frob_tab) {
+    Fp2<C> f = d_mul<C>(L, d_conj<C>(L, f_in), d_inv<C>(L, f_in));
+    f = d_mul<C>(L, d_frob<C, 2>(L, f, frob_tab), f);
+    if constexpr (C::ID == 0) {
+        Fp2<C> a = d_mul<C>(L, d_pow_x<C>(L, f), d_conj<C>(L, f));
+        a = d_mul<C>(L, d_pow_x<C>(L, a), d_conj<C>(L, a));
+        Fp2<C> b = d_mul<C>(L, d_pow_x<C>(L, a), d_frob<C, 1>(L, a, frob_tab));
+        Fp2<C> c = d_pow_x<C>(L, d_pow_x<C>(L, b));
+        c = d_mul<C>(L, c, d_frob<C, 2>(L, b, frob_tab));
+        c = d_mul<C>(L, c, d_conj<C>(L, b));
+        Fp2<C> f3 = d_mul<C>(L, d_cyclo_sqr<C>(L, f), f);
+        return d_mul<C>(L, c, f3);
+    } else {
+        Fp2<C> fu = d_pow_x<C>(L, f);
+        Fp2<C> fu2 = d_pow_x<C>(L, fu);
+        Fp2<C> fu3 = d_pow_x<C>(L, fu2);
+        Fp2<C> y0 = d_mul<C>(L, d_mul<C>(L, d_frob<C, 1>(L, f, frob_tab), d_frob<C, 2>(L, f, frob_tab)), d_frob<C, 3>(L, f, frob_tab));
+        Fp2<C> y1 = d_conj<C>(L, f);
+        Fp2<C> y2 = d_frob<C, 2>(L, fu2, frob_tab);
+        Fp2<C> y3 = d_conj<C>(L, d_frob<C, 1>(L, fu, frob_tab));
+        Fp2<C> y4 = d_conj<C>(L, d_mul<C>(L, fu, d_frob<C, 1>(L, fu2, frob_tab)));
+        Fp2<C> y5 = d_conj<C>(L, fu2);
+        Fp2<C> y6 = d_conj<C>(L, d_mul<C>(L, fu3, d_frob<C, 1>(L, fu3, frob_tab)));
+        Fp2<C> t0 = d_cyclo_sqr<C>(L, y6);
+        t0 = d_mul<C>(L, t0, y4);
+        t0 = d_mul<C>(L, t0, y5);
+        Fp2<C> t1 = d_mul<C>(L, y3, y5);
+        t1 = d_mul<C>(L, t1, t0);
+        t0 = d_mul<C>(L, t0, y2);
+        t1 = d_cyclo_sqr<C>(L, t1);
+        t1 = d_mul<C>(L, t1, t0);
+        t1 = d_cyclo_sqr<C>(L, t1);
+        t0 = d_mul<C>(L, t1, y1);
+        t1 = d_mul<C>(L, t1, y0);
+        t0 = d_cyclo_sqr<C>(L, t0);
+        return d_mul<C>(L, t0, t1);
+    }
+}
+
+}  // namespace bbs
+#endif

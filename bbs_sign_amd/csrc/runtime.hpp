@@ -209,6 +209,8 @@ struct Ctx : bbs_ctx {
         if (rt::stream_create(&stream)) return BBS_E_HIP;
         std::memset(&hc, 0, sizeof(hc));
         for (int j = 0; j < N; j++) { hc.p1.x.v[j] = C::K::P1X_M[j]; hc.p1.y.v[j] = C::K::P1Y_M[j]; }
+        for (int k = 0; k < 3; k++) for (int m = 0; m < 6; m++) for (int c2 = 0; c2 < 2; c2++)
+            for (int j = 0; j < N; j++) hc.frob[k][m][c2][j] = C::K::FROB[k][m][c2][j];
         build_schedule<C>(hc.sched);
         if (!build_line_table<C>(g2_generator<C>(), hc.tab_bp2)) return BBS_E_ARG;
         hc.tab_pk.q_is_identity = 1;

@@ -24,6 +24,7 @@
 //                 terms plus scalar multiples of the signature point A.
 #pragma once
 #include "pairing.hpp"
+#include "pairing_dist.hpp"
 #include "sha256.hpp"
 
 namespace bbs {
@@ -50,6 +51,7 @@ struct CtxConsts {
     int win_bits;                // c
     int n_windows;               // ceil(256 / c)
     const uint32_t* tables;      // [base][window][digit-1][2N] affine Montgomery
+    uint32_t frob[3][6][2][C::FpP::N];   // xi^(m (p^k - 1)/6), Montgomery (for the lane-sliced Fp12)
     MillerSchedule sched;
     LineTable<C> tab_pk;         // lines of W = pk
     LineTable<C> tab_bp2;        // lines of BP2
@@ -914,5 +916,102 @@ struct PairPrep {
         a.status[i] = 2;
     }
 };
+
+#if !defined(BBS_HOST_TWIN)
+// =============================================================================================
+// wavefront-cooperative pairing check (pairing_dist.hpp): six lanes per item, Miller loop of both
+// pairs (shared squarings) and the final exponentiation fused in one kernel, nothing spilled to HBM.
+// Thread index: wave = t / 64 ; group = (t % 64) / 6 ; item = wave * 10 + group.
+// =============================================================================================
+template <class C>
+struct PairDist {
+    static __device__ void run(const PairArgs<C>& a, size_t t) {
+        const int lane = (int)(t & 63);
+        const int grp = lane / GRP;
+        if (grp >= GRP_PER_WAVE) return;
+        const size_t i = (t >> 6) * GRP_PER_WAVE + grp;
+        if (i >= a.n) return;
+        if (a.status[i] != 2) return;
+        Lane6 L{grp * GRP, lane - grp * GRP};
+        const size_t n = a.n;
+        G1Aff<C> Pa = g1a_load_mont<C>(a.pa, n, i);
+        G1Aff<C> Pb = g1a_load_mont<C>(a.pb, n, i);
+        if (a.negate_b) Pb = g1a_neg<C>(Pb);
+        const CtxConsts<C>* cc = a.cc;
+        const bool skipA = g1a_is_inf<C>(Pa) | (cc->tab_pk.q_is_identity != 0);
+        const bool skipB = g1a_is_inf<C>(Pb) | (cc->tab_bp2.q_is_identity != 0);
+        Fp2<C> f = d_one<C>(L);
+        if (!(skipA & skipB)) {
+            int li = 0;
+            const int nops = cc->sched.n_ops;
+            for (int k = 0; k < nops; k++) {
+                if (cc->sched.op[k] == 0) {
+                    f = d_sqr<C>(L, f);
+                } else {
+                    if (!skipA) f = d_mul_line<C>(L, f, cc->tab_pk.e[li], Pa);
+                    if (!skipB) f = d_mul_line<C>(L, f, cc->tab_bp2.e[li], Pb);
+                    li++;
+                }
+            }
+            if constexpr (C::K::X_NEG) f = d_conj<C>(L, f);
+            f = d_final_exp<C>(L, f, &cc->frob[0][0][0][0]);
+        }
+        const bool one = d_is_one<C>(L, f);
+        if (L.m == 0) a.status[i] = one ? 1 : 0;
+    }
+};
+
+// self-test: one Fp12 operation computed by the one-lane code and by the six-lane code
+template <class C>
+struct SelfTestArgs {
+    int op;
+    const CtxConsts<C>* cc;
+    const uint32_t* a;      // 12 Fp (tower order c0.c0.c0, c0.c0.c1, c0.c1.c0 ... ), Montgomery
+    const uint32_t* b;
+    uint32_t* out_single;   // 12 Fp
+    uint32_t* out_dist;     // 12 Fp
+};
+template <class C>
+struct SelfTestF12 {
+    static __device__ void run(const SelfTestArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const int lane = (int)(t & 63);
+        if (lane >= GRP) return;
+        Lane6 L{0, lane};
+        Fp12<C> x, y;
+        Fp<C>* xe = reinterpret_cast<Fp<C>*>(&x);
+        Fp<C>* ye = reinterpret_cast<Fp<C>*>(&y);
+        for (int k = 0; k < 12; k++) for (int j = 0; j < N; j++) { xe[k].v[j] = a.a[k * N + j]; ye[k].v[j] = a.b[k * N + j]; }
+        if (a.op >= 10) {   // make x cyclotomic first
+            x = f12_mul<C>(f12_conj<C>(x), f12_inv<C>(x));
+            x = f12_mul<C>(f12_frob<C, 2>(x), x);
+        }
+        Fp2<C> gx = d_scatter<C>(L, x), gy = d_scatter<C>(L, y);
+        const uint32_t* ft = &a.cc->frob[0][0][0][0];
+        G1Aff<C> P = {ye[0], ye[1]};
+        Fp12<C> rs;
+        Fp2<C> rd;
+        switch (a.op) {
+            case 0: rs = f12_mul<C>(x, y); rd = d_mul<C>(L, gx, gy); break;
+            case 1: rs = f12_frob<C, 1>(x); rd = d_frob<C, 1>(L, gx, ft); break;
+            case 2: rs = f12_frob<C, 2>(x); rd = d_frob<C, 2>(L, gx, ft); break;
+            case 3: rs = f12_frob<C, 3>(x); rd = d_frob<C, 3>(L, gx, ft); break;
+            case 4: rs = f12_inv<C>(x); rd = d_inv<C>(L, gx); break;
+            case 5: rs = f12_conj<C>(x); rd = d_conj<C>(L, gx); break;
+            case 6: rs = f12_mul_line<C>(x, a.cc->tab_bp2.e[3], P); rd = d_mul_line<C>(L, gx, a.cc->tab_bp2.e[3], P); break;
+            case 7: rs = final_exponentiation<C>(x); rd = d_final_exp<C>(L, gx, ft); break;
+            case 10: rs = f12_sqr<C>(x); rd = d_cyclo_sqr<C>(L, gx); break;
+            case 11: rs = f12_pow_x<C>(x); rd = d_pow_x<C>(L, gx); break;
+            default: rs = x; rd = gx;
+        }
+        Fp12<C> rdg = d_gather<C>(L, rd);
+        if (lane == 0) {
+            const Fp<C>* se = reinterpret_cast<const Fp<C>*>(&rs);
+            const Fp<C>* de = reinterpret_cast<const Fp<C>*>(&rdg);
+            for (int k = 0; k < 12; k++) for (int j = 0; j < N; j++) { a.out_single[k * N + j] = se[k].v[j]; a.out_dist[k * N + j] = de[k].v[j]; }
+        }
+    }
+};
+#endif
 
 }  // namespace bbs

@@ -4,3 +4,4 @@ template int Ctx<BnCurve>::set_generators(const uint8_t*, size_t, const uint8_t*
 template int h2s_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint64_t*, const uint8_t*, size_t, uint8_t*);
 template int msm_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
 template int pairing_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, int8_t*);
+template int selftest_f12<BnCurve>(Ctx<BnCurve>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);

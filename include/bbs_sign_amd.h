@@ -189,6 +189,13 @@ int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fixed_scalars, size_
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_affine,
                                       const uint8_t* pb_affine, int8_t* status);
 
+/* GPU self-test: one Fp12 operation (12 Fp values a, b, canonical LE, tower order) computed by the
+ * one-lane code and by the six-lane wavefront-cooperative code; the caller compares the outputs.
+ * op: 0 mul, 1..3 Frobenius^k, 4 inverse, 5 conjugate, 6 line multiplication, 7 final
+ * exponentiation, 10 cyclotomic square, 11 power by the curve parameter. */
+int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single,
+                     uint8_t* out_dist);
+
 #ifdef __cplusplus
 }
 #endif
