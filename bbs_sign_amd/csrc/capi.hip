@@ -116,23 +116,34 @@ int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms,
     if (job->use()) return BBS_E_HIP;
     const int ns = (int)job->stages.size();
     if (n_stages) *n_stages = ns;
-    // events: per rep one before the first stage and one after every stage
-    rt::EventList ev((size_t)reps * (ns + 1));
+    // per rep: one event before the first stage, then a (start, stop) pair around every stage, each
+    // recorded on the stream that stage is launched on; read back after one synchronisation
+    const size_t per_rep = 1 + 2 * (size_t)ns;
+    rt::EventList ev((size_t)reps * per_rep);
     if (rt::sync(job->stream())) return BBS_E_HIP;
+    bool any_aux = false;
     for (int r = 0; r < reps; r++) {
         if (job->reset()) return BBS_E_HIP;
         if (ev.record(job->stream())) return BBS_E_HIP;
+        bool forked = false;
         for (int k = 0; k < ns; k++) {
-            if (job->stages[k].launch()) return BBS_E_HIP;
-            if (ev.record(job->stream())) return BBS_E_HIP;
+            auto& s = job->stages[k];
+            if (s.aux && !forked) { if (job->fork_aux()) return BBS_E_HIP; forked = true; any_aux = true; }
+            if (s.join && forked) { if (job->join_aux()) return BBS_E_HIP; }
+            rt::Stream& st = s.aux ? job->stream_aux() : job->stream();
+            if (ev.record(st)) return BBS_E_HIP;
+            if (s.launch()) return BBS_E_HIP;
+            if (ev.record(st)) return BBS_E_HIP;
         }
     }
     if (ev.finish(job->stream())) return BBS_E_HIP;
-    if (total_ms) *total_ms = ev.ms(0, (size_t)reps * (ns + 1) - 1);
+    if (any_aux && rt::sync(job->stream_aux())) return BBS_E_HIP;
+    // the last stage of a rep is on the main stream: total = first event .. last stop
+    if (total_ms) *total_ms = ev.ms(0, (size_t)reps * per_rep - 1);
     if (kernel_ms) {
         for (int k = 0; k < ns && k < cap; k++) {
             float acc = 0.f;
-            for (int r = 0; r < reps; r++) acc += ev.ms((size_t)r * (ns + 1) + k, (size_t)r * (ns + 1) + k + 1);
+            for (int r = 0; r < reps; r++) acc += ev.ms((size_t)r * per_rep + 1 + 2 * k, (size_t)r * per_rep + 2 + 2 * k);
             kernel_ms[k] = acc;
         }
     }

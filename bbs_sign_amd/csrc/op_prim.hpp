@@ -128,7 +128,7 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     PairPrep<C> pp{dA.as<uint32_t>(), dB.as<uint32_t>(), dAm.as<uint32_t>(), dBm.as<uint32_t>(), dSt.as<int8_t>(), n};
     PairArgs<C> a;
     a.n = n; a.cc = ctx->d_consts.template as<CtxConsts<C>>(); a.pa = dAm.as<uint32_t>(); a.pb = dBm.as<uint32_t>();
-    a.negate_b = 0; a.status = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
+    a.negate_b = 0; a.canonical = 0; a.gate_arr = dSt.as<int8_t>(); a.gate = 2; a.out = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
 #ifdef BBS_HOST_TWIN
     if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) || rt::launch<PairMiller<C>>(ctx->stream, a, n * 2) ||
         rt::launch<PairFinal<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;

@@ -9,6 +9,7 @@ struct PvJob : JobBase<C> {
     using JobBase<C>::JobBase;
     PvArgs<C> a{};
     PairArgs<C> pa{};
+    PvFinishArgs fin{};
 };
 
 template <class C>
@@ -91,19 +92,26 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     if (rc) return rc;
     if ((rc = job->finish_setup())) return rc;
     a.status = job->d_status.template as<int8_t>();
+    // pairing runs on the job's second stream, concurrently with the MSM / challenge stages: it needs
+    // only the proof's own points (canonical, converted in the kernel) and the host-validated flag
+    int8_t* pair_ok = job->template scratch<int8_t>(n ? n : 1, rc);
+    if (rc) return rc;
     PairArgs<C>& pa = job->pa;
-    pa.n = n; pa.cc = a.cc; pa.pa = a.aff; pa.pb = a.aff + (size_t)2 * N * n; pa.negate_b = 1;
-    pa.status = a.status; pa.fmiller = a.fmiller;
+    pa.n = n; pa.cc = a.cc; pa.pa = a.pts; pa.pb = a.pts + (size_t)2 * N * n; pa.negate_b = 1;
+    pa.canonical = 1; pa.gate_arr = job->d_status0.template as<int8_t>(); pa.gate = 1; pa.out = pair_ok;
+    pa.fmiller = a.fmiller;
+    job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
     j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->ctx->stream, j->a, j->n); }});
+#ifdef BBS_HOST_TWIN
+    j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->stream_aux(), j->pa, j->n * 2); }, 1, 0});
+    j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->stream_aux(), j->pa, j->n); }, 1, 0});
+#else
+    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->stream_aux(), j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, 1, 0});
+#endif
     j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->ctx->stream, j->a, j->n * PV_NPARTS); }});
     j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->ctx->stream, j->a, j->n); }});
-#ifdef BBS_HOST_TWIN
-    j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->ctx->stream, j->pa, j->n * 2); }});
-    j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->ctx->stream, j->pa, j->n); }});
-#else
-    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->ctx->stream, j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
-#endif
+    j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->ctx->stream, j->fin, j->n); }, 0, 1});
     *out = job.release();
     return BBS_OK;
 }

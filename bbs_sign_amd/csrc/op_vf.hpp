@@ -53,7 +53,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.status = job->d_status.template as<int8_t>();
     PairArgs<C>& pa = job->pa;
     pa.n = n; pa.cc = a.cc; pa.pa = a.aff; pa.pb = a.aff + (size_t)2 * N * n; pa.negate_b = 0;
-    pa.status = a.status; pa.fmiller = a.fmiller;
+    pa.canonical = 0; pa.gate_arr = a.status; pa.gate = 2; pa.out = a.status; pa.fmiller = a.fmiller;
     VfJob<C>* j = job.get();
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->ctx->stream, j->a, j->n); }});
     j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->ctx->stream, j->a, j->n * VF_NPARTS); }});

@@ -40,6 +40,11 @@ inline int d2h(void* h, const void* d, size_t b, Stream&) { std::memcpy(h, d, b)
 inline int dmemset(void* d, int v, size_t b, Stream&) { std::memset(d, v, b); return 0; }
 inline int d2d_async(void* d, const void* s, size_t b, Stream&) { std::memcpy(d, s, b); return 0; }
 inline int sync(Stream&) { return 0; }
+struct Event { };
+inline int event_create(Event*) { return 0; }
+inline void event_destroy(Event&) {}
+inline int event_record(Event&, Stream&) { return 0; }
+inline int stream_wait(Stream&, Event&) { return 0; }
 template <class F, class A>
 inline int launch(Stream&, const A& a, size_t nthreads) {
     for (size_t t = 0; t < nthreads; t++) F::run(a, t);
@@ -76,6 +81,11 @@ inline int d2d_async(void* d, const void* s_, size_t b, Stream& s) {
     return (!b || hipMemcpyAsync(d, s_, b, hipMemcpyDeviceToDevice, s) == hipSuccess) ? 0 : -1;
 }
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+using Event = hipEvent_t;
+inline int event_create(Event* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
+inline void event_destroy(Event& e) { (void)hipEventDestroy(e); }
+inline int event_record(Event& e, Stream& s) { return hipEventRecord(e, s) == hipSuccess ? 0 : -1; }
+inline int stream_wait(Stream& s, Event& e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
 
 template <class F, class A>
 __global__ void __launch_bounds__(64) k_stage(A a, size_t nthreads) {
@@ -312,10 +322,16 @@ struct Ctx : bbs_ctx {
 struct bbs_job {
     size_t n = 0;
     virtual ~bbs_job() {}
-    struct Stage { const char* name; std::function<int()> launch; };
+    // aux = 1: the stage runs on the job's second stream, concurrently with the main-stream stages
+    // that follow the fork point (start of the run); join = 1: the main stream first waits for
+    // everything issued on the second stream
+    struct Stage { const char* name; std::function<int()> launch; int aux = 0; int join = 0; };
     std::vector<Stage> stages;
     virtual int use() = 0;
     virtual rt::Stream& stream() = 0;
+    virtual rt::Stream& stream_aux() = 0;
+    virtual int fork_aux() = 0;                  // aux stream waits for what the main stream has issued
+    virtual int join_aux() = 0;                  // main stream waits for what the aux stream has issued
     virtual int reset() = 0;                     // restore the pre-run status so the job can run again
     virtual int fetch_status(int8_t*) = 0;
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
@@ -323,7 +339,12 @@ struct bbs_job {
     int run() {
         if (use()) return BBS_E_HIP;
         if (reset()) return BBS_E_HIP;
-        for (auto& s : stages) if (s.launch()) return BBS_E_HIP;
+        bool forked = false;
+        for (auto& s : stages) {
+            if (s.aux && !forked) { if (fork_aux()) return BBS_E_HIP; forked = true; }
+            if (s.join && forked) { if (join_aux()) return BBS_E_HIP; }
+            if (s.launch()) return BBS_E_HIP;
+        }
         return BBS_OK;
     }
     int wait() { return (use() || rt::sync(stream())) ? BBS_E_HIP : BBS_OK; }
@@ -335,9 +356,29 @@ struct JobBase : bbs_job {
     std::vector<int8_t> status0;     // host-validated initial status (1 placeholder = to compute)
     DevBuf d_status, d_status0;
     std::vector<std::unique_ptr<DevBuf>> bufs;
+    rt::Stream aux{};
+    rt::Event ev_fork{}, ev_join{};
+    bool aux_ready = false;
     explicit JobBase(Ctx<C>* c) : ctx(c) {}
+    ~JobBase() override {
+        if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
+    }
     int use() override { return ctx->use(); }
     rt::Stream& stream() override { return ctx->stream; }
+    int ensure_aux() {
+        if (aux_ready) return 0;
+        if (rt::stream_create(&aux) || rt::event_create(&ev_fork) || rt::event_create(&ev_join)) return -1;
+        aux_ready = true;
+        return 0;
+    }
+    rt::Stream& stream_aux() override { ensure_aux(); return aux; }
+    int fork_aux() override {
+        if (ensure_aux()) return -1;
+        return (rt::event_record(ev_fork, ctx->stream) || rt::stream_wait(aux, ev_fork)) ? -1 : 0;
+    }
+    int join_aux() override {
+        return (rt::event_record(ev_join, aux) || rt::stream_wait(ctx->stream, ev_join)) ? -1 : 0;
+    }
     // device-to-device, asynchronous: back-to-back runs of one job never wait for the host
     int reset() override { return rt::d2d_async(d_status.p, d_status0.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK; }
     int fetch_status(int8_t* out) override {

@@ -29,7 +29,7 @@
 
 namespace bbs {
 
-constexpr int NFIX = 2;          // fixed-base chunks per MSM
+constexpr int NFIX = 8;          // fixed-base chunks per MSM (one lane each)
 constexpr int MAX_DST = 255;
 
 // ---- context constants resident in HBM ------------------------------------------------------
@@ -349,8 +349,26 @@ struct PairArgs {
     const uint32_t* pa;       // [2N][n] Montgomery affine
     const uint32_t* pb;       // [2N][n]
     int negate_b;             // use -Pb (e(P, -Q) = e(-P, Q))
-    int8_t* status;
+    int canonical;            // pa/pb hold canonical limbs (converted here) instead of Montgomery
+    const int8_t* gate_arr;   // item i is processed iff gate_arr[i] == gate
+    int gate;
+    int8_t* out;              // result 1 / 0 per item (may alias the status array)
     uint32_t* fmiller;        // [2][12N][n]
+};
+
+template <class C>
+BBS_HD G1Aff<C> pair_load_point(const PairArgs<C>& a, const uint32_t* base, size_t i) {
+    return a.canonical ? g1a_load_canon_to_mont<C>(base, a.n, i) : g1a_load_mont<C>(base, a.n, i);
+}
+
+// proof_verify runs the pairing concurrently with the MSM/challenge stages (the pairing needs only
+// the proof's own points); this joins the two results.  proof_verify.rs:108-115: challenge
+// mismatch -> Ok(false), otherwise the pairing boolean.
+struct PvFinishArgs { size_t n; int8_t* status; const int8_t* pair_ok; };
+struct PvFinish {
+    static __host__ __device__ void run(const PvFinishArgs& a, size_t i) {
+        if (a.status[i] == 2) a.status[i] = a.pair_ok[i];
+    }
 };
 
 template <class C>
@@ -376,8 +394,8 @@ struct PairMiller {
         const size_t n = a.n;
         const int pair = (int)(t / n);
         const size_t i = t - (size_t)pair * n;
-        if (a.status[i] != 2) return;
-        G1Aff<C> P = g1a_load_mont<C>(pair == 0 ? a.pa : a.pb, n, i);
+        if (a.gate_arr[i] != a.gate) return;
+        G1Aff<C> P = pair_load_point<C>(a, pair == 0 ? a.pa : a.pb, i);
         if (pair == 1 && a.negate_b) P = g1a_neg<C>(P);
         const LineTable<C>* tab = pair == 0 ? &a.cc->tab_pk : &a.cc->tab_bp2;
         Fp12<C> f = f12_one<C>();
@@ -401,9 +419,9 @@ struct PairFinal {
     static __host__ __device__ void run(const PairArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] != 2) return;
+        if (a.gate_arr[i] != a.gate) return;
         Fp12<C> f = f12_mul<C>(f12_load<C>(a.fmiller, n, i), f12_load<C>(a.fmiller + (size_t)12 * N * n, n, i));
-        a.status[i] = f12_is_one<C>(final_exponentiation<C>(f)) ? 1 : 0;
+        a.out[i] = f12_is_one<C>(final_exponentiation<C>(f)) ? 1 : 0;
     }
 };
 
@@ -931,11 +949,10 @@ struct PairDist {
         if (grp >= GRP_PER_WAVE) return;
         const size_t i = (t >> 6) * GRP_PER_WAVE + grp;
         if (i >= a.n) return;
-        if (a.status[i] != 2) return;
+        if (a.gate_arr[i] != a.gate) return;
         Lane6 L{grp * GRP, lane - grp * GRP};
-        const size_t n = a.n;
-        G1Aff<C> Pa = g1a_load_mont<C>(a.pa, n, i);
-        G1Aff<C> Pb = g1a_load_mont<C>(a.pb, n, i);
+        G1Aff<C> Pa = pair_load_point<C>(a, a.pa, i);
+        G1Aff<C> Pb = pair_load_point<C>(a, a.pb, i);
         if (a.negate_b) Pb = g1a_neg<C>(Pb);
         const CtxConsts<C>* cc = a.cc;
         const bool skipA = g1a_is_inf<C>(Pa) | (cc->tab_pk.q_is_identity != 0);
@@ -957,7 +974,7 @@ struct PairDist {
             f = d_final_exp<C>(L, f, &cc->frob[0][0][0][0]);
         }
         const bool one = d_is_one<C>(L, f);
-        if (L.m == 0) a.status[i] = one ? 1 : 0;
+        if (L.m == 0) a.out[i] = one ? 1 : 0;
     }
 };
 
