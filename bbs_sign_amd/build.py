@@ -36,7 +36,7 @@ def build(twin=False, force=False, jobs=None, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     tus = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     if twin:
-        flags = ["-O2", "--offload-host-only", "-x", "hip", "-DBBS_HOST_TWIN", "-fPIC"]
+        flags = ["-O2", "--offload-host-only", "-x", "hip", "-DBBS_HOST_TWIN", "-DBBS_CHECK_BOUNDS", "-fPIC"]
     else:
         flags = ["-O3", "--offload-arch=gfx950", "-fPIC"]
     jobs = jobs or min(8, os.cpu_count() or 1)

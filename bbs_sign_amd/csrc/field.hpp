@@ -1,17 +1,24 @@
-// Prime-field arithmetic on 32-bit limbs, Montgomery form, one element per GPU lane.
+// Prime-field arithmetic for the GPU lanes, Montgomery form, two limb layouts.
 //
-// CDNA4 has no 64x64 multiplier: the native wide multiply is v_mad_u64_u32
-// (32x32+64 -> 64).  Elements are therefore N little-endian 32-bit limbs
-// (N = 12 for the BLS12-381 base field, 8 for BN254's base field and for both
-// scalar fields) and the Montgomery radix is 2^(32 N).  All values handed
-// between functions are fully reduced (in [0, p)).
+// Measured on MI355X (tools/ubench/valu_int.hip): v_mad_u64_u32 (32x32+64 -> 64) issues at the same
+// ~2 ns per wave-instruction per SIMD as a plain add, while every carry that goes through VCC/SGPR
+// costs two extra wait states (hipcc pads `v_addc` chains with `s_nop 1`).  So on CDNA4 multiplies
+// are cheap and carries are expensive.  The BASE fields (Fp of BLS12-381 and BN254: >99 % of the
+// work) therefore use a CARRY-FREE layout:
 //
-// Every function is __host__ __device__: the very same code is compiled for
-// gfx950 (product) and for x86 (tests/hosttwin, logic tests without a GPU).
+//   W = 28 : N limbs of 28 bits in 32-bit words (N = 14 for BLS12-381, 10 for BN254), radix
+//            R = 2^(28 N).  A product column sums up to 28 limb products (< 2^58 each) in ONE
+//            64-bit accumulator with no carry instruction at all: one v_mad_u64_u32 per
+//            multiply-accumulate, then `& mask` and `>> 28` per column.  Values are kept
+//            "normal": limbs < 2^28 and value < BOUND * p (BOUND = 2 / 3); the only lazy form is
+//            fe_add_nr (limbs < 2^29), legal only as a direct multiplier operand.
+//            add/sub are one signed limb chain with a quotient estimate from the top limb.
+//   W = 32 : N = 8 limbs of 32 bits, fully reduced, plain CIOS -- the scalar fields Fr (hashing
+//            glue and a few dozen products per item).
 //
-// Replaces, for the hot path, what the reference gets from ark-ff 0.4.2
-// (`Fp<MontBackend<..>>`): every `*`, `+`, `-`, `.inverse()` on field elements in
-// /root/reference/src/{sign,verify,proof_gen,proof_verify}.rs.
+// Every function is __host__ __device__: the same code is compiled for gfx950 (product) and for
+// x86 (tests/hosttwin).  Replaces what the reference gets from ark-ff 0.4.2 (`Fp<MontBackend>`):
+// every `*`, `+`, `-`, `.inverse()` in /root/reference/src/{sign,verify,proof_gen,proof_verify}.rs.
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime.h>
@@ -26,6 +33,18 @@ struct Fe {
     static constexpr int N = P::N;
     uint32_t v[N];
 };
+
+constexpr uint32_t MASK28 = 0x0FFFFFFFu;
+
+// Host-only invariant checks of the lazy-reduction bounds (tests/hosttwin builds with
+// -DBBS_CHECK_BOUNDS run the whole parity suite with them; never compiled for the device).
+#if defined(BBS_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#define BBS_BOUND_ASSERT(cond, what) do { if (!(cond)) { std::fprintf(stderr, "bound violated: %s (%s:%d)\n", what, __FILE__, __LINE__); std::abort(); } } while (0)
+#else
+#define BBS_BOUND_ASSERT(cond, what) do { } while (0)
+#endif
 
 template <class P>
 BBS_HD Fe<P> fe_zero() {
@@ -44,22 +63,6 @@ BBS_HD Fe<P> fe_one() {   // Montgomery 1
 }
 
 template <class P>
-BBS_HD bool fe_is_zero(const Fe<P>& a) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; i++) acc |= a.v[i];
-    return acc == 0;
-}
-
-template <class P>
-BBS_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; i++) acc |= (a.v[i] ^ b.v[i]);
-    return acc == 0;
-}
-
-template <class P>
 BBS_HD Fe<P> fe_select(bool c, const Fe<P>& a, const Fe<P>& b) {   // c ? a : b
     Fe<P> r;
 #pragma unroll
@@ -67,9 +70,13 @@ BBS_HD Fe<P> fe_select(bool c, const Fe<P>& a, const Fe<P>& b) {   // c ? a : b
     return r;
 }
 
-// r = a - MOD if a >= MOD (a given with an extra carry bit), else a
+// =============================================================================================
+// W = 32 : fully reduced, carry chains
+// =============================================================================================
+namespace r32 {
+
 template <class P>
-BBS_HD void fe_cond_sub_mod(uint32_t* t, uint32_t carry) {
+BBS_HD void cond_sub_mod(uint32_t* t, uint32_t carry) {
     uint32_t d[P::N];
     uint64_t bw = 0;
 #pragma unroll
@@ -78,14 +85,13 @@ BBS_HD void fe_cond_sub_mod(uint32_t* t, uint32_t carry) {
         d[i] = (uint32_t)x;
         bw = (x >> 63) & 1;
     }
-    // take the difference when there was a carry out of a, or no borrow
     bool take = (carry != 0) | (bw == 0);
 #pragma unroll
     for (int i = 0; i < P::N; i++) t[i] = take ? d[i] : t[i];
 }
 
 template <class P>
-BBS_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+BBS_HD Fe<P> add(const Fe<P>& a, const Fe<P>& b) {
     Fe<P> r;
     uint64_t c = 0;
 #pragma unroll
@@ -94,12 +100,12 @@ BBS_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
         r.v[i] = (uint32_t)c;
         c >>= 32;
     }
-    fe_cond_sub_mod<P>(r.v, (uint32_t)c);
+    cond_sub_mod<P>(r.v, (uint32_t)c);
     return r;
 }
 
 template <class P>
-BBS_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+BBS_HD Fe<P> sub(const Fe<P>& a, const Fe<P>& b) {
     Fe<P> r;
     uint64_t bw = 0;
 #pragma unroll
@@ -119,135 +125,363 @@ BBS_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     return r;
 }
 
+// CIOS Montgomery product, result fully reduced; a < 2^(32N) arbitrary, b < p
 template <class P>
-BBS_HD Fe<P> fe_neg(const Fe<P>& a) {
-    return fe_sub<P>(fe_zero<P>(), a);
-}
-
-template <class P>
-BBS_HD Fe<P> fe_dbl(const Fe<P>& a) {
-    return fe_add<P>(a, a);
-}
-
-}  // namespace bbs
-#include "fe_mul_asm_gen.hpp"
-namespace bbs {
-
-// 96-bit accumulator (lo:64, hi:32) += a*b.  On gfx950 this is exactly two instructions:
-// v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) and v_addc_co_u32 folding the carry into hi.
-// Measured on MI355X (tools/ubench/valu_int.hip): every VALU instruction of this mix issues at the
-// same ~2 ns per wave-instruction per SIMD, so the instruction COUNT is the cost -- product scanning
-// with an explicit carry word (2 instr / MAC) replaces the CIOS form (4.3 instr / MAC as compiled).
-BBS_HD void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
-    const uint64_t p = (uint64_t)a * b;
-    lo += p;
-    hi += (lo < p) ? 1u : 0u;
-}
-// 96-bit accumulator += x (32-bit)
-BBS_HD void acc96_add32(uint64_t& lo, uint32_t& hi, uint32_t x) {
-    const uint64_t o = lo;
-    lo += x;
-    hi += (lo < o) ? 1u : 0u;
-}
-
-// Montgomery product a*b/R mod p: product scanning (column-wise, "FIPS"), 32-bit limbs.
-//   columns 0..N-1 : acc += sum_{i+j=c} a_i b_j + sum_{i+j=c, i<c} m_i p_j ; m_c = acc_lo * INV ;
-//                    acc += m_c p_0 (low word becomes 0) ; acc >>= 32
-//   columns N..2N-1: acc += sum a_i b_j + sum m_i p_j ; r_{c-N} = acc_lo ; acc >>= 32
-template <class P>
-BBS_HD void fe_mul_raw(uint32_t* r, const uint32_t* a, const uint32_t* b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // device: the generated asm-block form of exactly this algorithm (fe_mul_asm_gen.hpp)
-    if constexpr (P::N == 12) { fe_mul_ps12<P>(r, a, b); return; }
-    else if constexpr (P::N == 8) { fe_mul_ps8<P>(r, a, b); return; }
-#endif
+BBS_HD void mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
     constexpr int N = P::N;
-    uint32_t m[N];
-    uint32_t t[N + 1];
-    uint64_t lo = 0;
-    uint32_t hi = 0;
+    uint32_t t[N + 2];
 #pragma unroll
-    for (int c = 0; c < N; c++) {
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
 #pragma unroll
-        for (int i = 0; i <= c; i++) mac96(lo, hi, a[i], b[c - i]);
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b[i];
 #pragma unroll
-        for (int i = 0; i < c; i++) mac96(lo, hi, m[i], P::MOD[c - i]);
-        m[c] = (uint32_t)lo * P::INV;
-        mac96(lo, hi, m[c], P::MOD[0]);
-        lo = (lo >> 32) | ((uint64_t)hi << 32);
-        hi = 0;
+        for (int j = 0; j < N; j++) {
+            c += (uint64_t)a[j] * bi + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[N];
+        t[N] = (uint32_t)c;
+        t[N + 1] = (uint32_t)(c >> 32);
+        const uint32_t m = t[0] * P::INV;
+        c = (uint64_t)m * P::MOD[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            c += (uint64_t)m * P::MOD[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[N];
+        t[N - 1] = (uint32_t)c;
+        t[N] = t[N + 1] + (uint32_t)(c >> 32);
     }
-#pragma unroll
-    for (int c = N; c < 2 * N - 1; c++) {
-#pragma unroll
-        for (int i = c - N + 1; i < N; i++) mac96(lo, hi, a[i], b[c - i]);
-#pragma unroll
-        for (int i = c - N + 1; i < N; i++) mac96(lo, hi, m[i], P::MOD[c - i]);
-        t[c - N] = (uint32_t)lo;
-        lo = (lo >> 32) | ((uint64_t)hi << 32);
-        hi = 0;
-    }
-    t[N - 1] = (uint32_t)lo;
-    t[N] = (uint32_t)(lo >> 32);
-    fe_cond_sub_mod<P>(t, t[N]);
+    cond_sub_mod<P>(t, t[N]);
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = t[i];
 }
 
-// The multiplier is deliberately NOT inlined on the device: one unrolled 12-limb CIOS body is
-// ~4-5 KB of ISA and the pairing kernel has thousands of call sites; keeping one copy keeps the
-// kernel inside the instruction cache.
-template <class P>
-BBS_HD_NOINLINE Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
-    Fe<P> r;
-    fe_mul_raw<P>(r.v, a.v, b.v);
-    return r;
-}
+}  // namespace r32
 
-template <class P>
-BBS_HD_NOINLINE Fe<P> fe_sqr(const Fe<P>& a) {
-    Fe<P> r;
-    fe_mul_raw<P>(r.v, a.v, a.v);
-    return r;
-}
+// =============================================================================================
+// W = 28 : carry-free columns
+// =============================================================================================
+namespace r28 {
 
+// a * b / R mod p.  Operands: limbs < 2^29 (normal or fe_add_nr), values < 2*BOUND*p.
+// Column bound: 14 * 2^58 + 14 * 2^56 + carry < 2^62.  Result: normal, value < p * (1 + 2^-5).
 template <class P>
-BBS_HD Fe<P> fe_from_limbs(const uint32_t* limbs) {   // canonical limbs -> Montgomery
-    Fe<P> a, r2;
+BBS_HD void mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    constexpr int N = P::N;
+    uint32_t m[N];
+    uint64_t acc = 0;
+    for (int i = 0; i < N; i++) BBS_BOUND_ASSERT(a[i] < (1u << 29) && b[i] < (1u << 29), "mul operand limb < 2^29");
+    BBS_BOUND_ASSERT(a[N - 1] <= 2 * P::MODB[N - 1] + 2 && b[N - 1] <= 2 * P::MODB[N - 1] + 2, "mul operand value < 2*BOUND*p");
 #pragma unroll
-    for (int i = 0; i < P::N; i++) { a.v[i] = limbs[i]; r2.v[i] = P::R2[i]; }
-    return fe_mul<P>(a, r2);
+    for (int c = 0; c < N; c++) {
+#pragma unroll
+        for (int i = 0; i <= c; i++) acc += (uint64_t)a[i] * b[c - i];
+#pragma unroll
+        for (int i = 0; i < c; i++) acc += (uint64_t)m[i] * P::MOD[c - i];
+        m[c] = ((uint32_t)acc * P::INV) & MASK28;
+        acc += (uint64_t)m[c] * P::MOD[0];
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int c = N; c < 2 * N - 1; c++) {
+#pragma unroll
+        for (int i = c - N + 1; i < N; i++) acc += (uint64_t)a[i] * b[c - i];
+#pragma unroll
+        for (int i = c - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::MOD[c - i];
+        r[c - N] = (uint32_t)acc & MASK28;
+        acc >>= 28;
+    }
+    r[N - 1] = (uint32_t)acc;
+    BBS_BOUND_ASSERT(acc <= P::MOD2[N - 1], "mul result < 2p");
 }
 
+// a^2 / R mod p: off-diagonal products once with a doubled operand (2 a_i < 2^30).
 template <class P>
-BBS_HD Fe<P> fe_to_canonical(const Fe<P>& a) {        // Montgomery -> canonical limbs
-    Fe<P> one = fe_zero<P>();
-    one.v[0] = 1;
-    return fe_mul<P>(a, one);
+BBS_HD void sqr(uint32_t* r, const uint32_t* a) {
+    constexpr int N = P::N;
+    uint32_t m[N], a2[N];
+    for (int i = 0; i < N; i++) BBS_BOUND_ASSERT(a[i] < (1u << 29), "sqr operand limb < 2^29");
+    BBS_BOUND_ASSERT(a[N - 1] <= 2 * P::MODB[N - 1] + 2, "sqr operand value < 2*BOUND*p");
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 2 * N - 1; c++) {
+        const int lo = (c < N) ? 0 : c - N + 1;
+#pragma unroll
+        for (int i = lo; 2 * i < c; i++) acc += (uint64_t)a2[i] * a[c - i];
+        if ((c & 1) == 0) acc += (uint64_t)a[c >> 1] * a[c >> 1];
+        if (c < N) {
+#pragma unroll
+            for (int i = 0; i < c; i++) acc += (uint64_t)m[i] * P::MOD[c - i];
+            m[c] = ((uint32_t)acc * P::INV) & MASK28;
+            acc += (uint64_t)m[c] * P::MOD[0];
+        } else {
+#pragma unroll
+            for (int i = c - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::MOD[c - i];
+            r[c - N] = (uint32_t)acc & MASK28;
+        }
+        acc >>= 28;
+    }
+    r[N - 1] = (uint32_t)acc;
 }
 
-// canonical a < MOD ?
+// One signed limb chain:  r = x - q*p  with limbs renormalised; x given limb-wise (may be out of
+// [0, 2^28) per limb), q < 8.  The caller guarantees 0 <= x - q*p < 2^(28 N).
 template <class P>
-BBS_HD bool limbs_lt_mod(const uint32_t* a) {
-    uint64_t bw = 0;
+BBS_HD void chain_reduce(uint32_t* r, const int32_t* x, uint32_t q) {
+    constexpr int N = P::N;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int32_t t = x[i] - (int32_t)(q * P::MOD[i]) + c;
+        if (i < N - 1) {
+            r[i] = (uint32_t)t & MASK28;
+            c = t >> 28;
+        } else {
+            r[i] = (uint32_t)t;
+            BBS_BOUND_ASSERT(t >= 0 && (uint32_t)t <= P::MODB[N - 1], "add/sub result in [0, BOUND*p)");
+        }
+    }
+}
+
+// a + b for normal a, b.  s = a + b < 2*BOUND*p; q = (top limbs) >> QSHIFT <= floor(s / 2^BITS)
+// so s - q p >= 0, and s - q p < 2^BITS + q (2^BITS - p) + eps < BOUND * p (checked numerically
+// by tools/gen_params.py for each field).
+template <class P>
+BBS_HD Fe<P> add(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    int32_t x[N];
+    for (int i = 0; i < N; i++) BBS_BOUND_ASSERT(a.v[i] <= MASK28 && b.v[i] <= MASK28, "add operands normal");
+    BBS_BOUND_ASSERT(a.v[N - 1] <= P::MODB[N - 1] && b.v[N - 1] <= P::MODB[N - 1], "add operands < BOUND*p");
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = (int32_t)(a.v[i] + b.v[i]);
+    const uint32_t q = (uint32_t)x[N - 1] >> P::QSHIFT;
+    Fe<P> r;
+    chain_reduce<P>(r.v, x, q);
+    return r;
+}
+
+// a - b for normal a, b:  s = a - b + BOUND*p in (0, 2*BOUND*p); the limb-wise top may over-state
+// floor(s / 2^(28(N-1))) by one borrow, hence (top - 1).
+template <class P>
+BBS_HD Fe<P> sub(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    int32_t x[N];
+    for (int i = 0; i < N; i++) BBS_BOUND_ASSERT(a.v[i] <= MASK28 && b.v[i] <= MASK28, "sub operands normal");
+    BBS_BOUND_ASSERT(a.v[N - 1] <= P::MODB[N - 1] && b.v[N - 1] <= P::MODB[N - 1], "sub operands < BOUND*p");
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)P::MODB[i];
+    const int32_t top = x[N - 1] - 1;
+    const uint32_t q = (top > 0 ? (uint32_t)top : 0u) >> P::QSHIFT;
+    Fe<P> r;
+    chain_reduce<P>(r.v, x, q);
+    return r;
+}
+
+// value == 0 mod p for a normal a  (a in {0, p, .., (BOUND-1) p})
+template <class P>
+BBS_HD bool is_zero(const Fe<P>& a) {
+    uint32_t z0 = 0, z1 = 0, z2 = 0;
 #pragma unroll
     for (int i = 0; i < P::N; i++) {
-        uint64_t x = (uint64_t)a[i] - P::MOD[i] - bw;
+        z0 |= a.v[i];
+        z1 |= a.v[i] ^ P::MOD[i];
+        if constexpr (P::BOUND > 2) z2 |= a.v[i] ^ P::MOD2[i];
+    }
+    bool z = (z0 == 0) | (z1 == 0);
+    if constexpr (P::BOUND > 2) z |= (z2 == 0);
+    return z;
+}
+
+// normal -> the unique representative in [0, p)
+template <class P>
+BBS_HD Fe<P> canon(const Fe<P>& a) {
+    constexpr int N = P::N;
+    Fe<P> r = a;
+#pragma unroll
+    for (int rep = 1; rep < P::BOUND; rep++) {
+        uint32_t d[N];
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int32_t t = (int32_t)r.v[i] - (int32_t)P::MOD[i] + c;
+            d[i] = (uint32_t)t & MASK28;
+            c = t >> 28;
+        }
+        const bool ge = c >= 0;                 // no borrow out of the top: r >= p
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = ge ? d[i] : r.v[i];
+    }
+    return r;
+}
+
+// 28-bit limbs (value < 2^(32 NC)) <-> 32-bit words
+template <class P>
+BBS_HD void pack32(const uint32_t* l28, uint32_t* w) {
+#pragma unroll
+    for (int k = 0; k < P::NC; k++) {
+        const int bit = 32 * k;
+        const int i = bit / 28, sh = bit % 28;
+        uint64_t x = (uint64_t)l28[i] >> sh;
+        if (i + 1 < P::N) x |= (uint64_t)l28[i + 1] << (28 - sh);
+        if (i + 2 < P::N) x |= (uint64_t)l28[i + 2] << (56 - sh);
+        w[k] = (uint32_t)x;
+    }
+}
+template <class P>
+BBS_HD void unpack32(const uint32_t* w, uint32_t* l28) {
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        const int bit = 28 * i;
+        const int k = bit / 32, sh = bit % 32;
+        uint64_t x = 0;
+        if (k < P::NC) x = (uint64_t)w[k] >> sh;
+        if (k + 1 < P::NC) x |= (uint64_t)w[k + 1] << (32 - sh);
+        l28[i] = (uint32_t)x & MASK28;
+    }
+}
+
+}  // namespace r28
+
+// =============================================================================================
+// dispatch
+// =============================================================================================
+template <class P>
+BBS_HD bool fe_is_zero(const Fe<P>& a) {
+    if constexpr (P::W == 28) return r28::is_zero<P>(a);
+    else {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < P::N; i++) acc |= a.v[i];
+        return acc == 0;
+    }
+}
+
+template <class P>
+BBS_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::W == 28) return r28::add<P>(a, b);
+    else return r32::add<P>(a, b);
+}
+template <class P>
+BBS_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::W == 28) return r28::sub<P>(a, b);
+    else return r32::sub<P>(a, b);
+}
+template <class P> BBS_HD Fe<P> fe_neg(const Fe<P>& a) { return fe_sub<P>(fe_zero<P>(), a); }
+template <class P> BBS_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a); }
+
+// lazy sum, limbs < 2^29: ONLY as an operand of fe_mul / fe_sqr (W = 28); plain add otherwise
+template <class P>
+BBS_HD Fe<P> fe_add_nr(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::W == 28) {
+        Fe<P> r;
+#pragma unroll
+        for (int i = 0; i < P::N; i++) r.v[i] = a.v[i] + b.v[i];
+        return r;
+    } else return r32::add<P>(a, b);
+}
+
+template <class P>
+BBS_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::W == 28) return r28::is_zero<P>(r28::sub<P>(a, b));
+    else {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < P::N; i++) acc |= (a.v[i] ^ b.v[i]);
+        return acc == 0;
+    }
+}
+
+// The multiplier is deliberately NOT inlined on the device: one unrolled body is 2-4 KB of ISA and
+// the pairing kernel has thousands of call sites; one copy keeps the kernels in the instruction
+// cache.
+template <class P>
+BBS_HD_NOINLINE Fe<P> fe_mul(const Fe<P> a, const Fe<P> b) {   // by value: operands travel in VGPRs, not through scratch
+    Fe<P> r;
+    if constexpr (P::W == 28) r28::mul<P>(r.v, a.v, b.v);
+    else r32::mul<P>(r.v, a.v, b.v);
+    return r;
+}
+template <class P>
+BBS_HD_NOINLINE Fe<P> fe_sqr(const Fe<P> a) {
+    Fe<P> r;
+    if constexpr (P::W == 28) r28::sqr<P>(r.v, a.v);
+    else r32::mul<P>(r.v, a.v, a.v);
+    return r;
+}
+
+// ---- canonical 32-bit words (ABI / hashing side) <-> field elements ------------------------
+// words: NC little-endian 32-bit words of the canonical value in [0, p)
+template <class P>
+BBS_HD Fe<P> fe_from_words(const uint32_t* w) {      // canonical (or any value < 2^(32 NC)) -> Montgomery
+    Fe<P> a, r2;
+    if constexpr (P::W == 28) r28::unpack32<P>(w, a.v);
+    else {
+#pragma unroll
+        for (int i = 0; i < P::N; i++) a.v[i] = w[i];
+    }
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r2.v[i] = P::R2[i];
+    return fe_mul<P>(a, r2);
+}
+template <class P>
+BBS_HD void fe_to_words(const Fe<P>& a, uint32_t* w) {   // Montgomery -> canonical words
+    Fe<P> one = fe_zero<P>();
+    one.v[0] = 1;
+    Fe<P> c = fe_mul<P>(a, one);
+    if constexpr (P::W == 28) {
+        c = r28::canon<P>(c);
+        r28::pack32<P>(c.v, w);
+    } else {
+#pragma unroll
+        for (int i = 0; i < P::N; i++) w[i] = c.v[i];
+    }
+}
+
+// W = 32 helpers used by the scalar-field glue: canonical limbs live in an Fe<P>
+template <class P>
+BBS_HD Fe<P> fe_from_limbs(const uint32_t* limbs) {
+    static_assert(P::W == 32, "scalar-field helper");
+    return fe_from_words<P>(limbs);
+}
+template <class P>
+BBS_HD Fe<P> fe_to_canonical(const Fe<P>& a) {
+    static_assert(P::W == 32, "scalar-field helper");
+    Fe<P> r;
+    fe_to_words<P>(a, r.v);
+    return r;
+}
+
+// canonical words w < p ?
+template <class P>
+BBS_HD bool limbs_lt_mod(const uint32_t* w) {
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < P::NC; i++) {
+        uint64_t x = (uint64_t)w[i] - P::MODC[i] - bw;
         bw = (x >> 63) & 1;
     }
     return bw != 0;
 }
 
-// canonical value > (p-1)/2  ("lexicographically largest" / ark "negative" y)
+// canonical words > (p-1)/2  ("lexicographically largest" / ark "negative" y)
 template <class P>
-BBS_HD bool canonical_gt_half(const Fe<P>& c) {
+BBS_HD bool words_gt_half(const uint32_t* w) {
     uint64_t bw = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; i++) {
-        uint64_t x = (uint64_t)P::HALF[i] - c.v[i] - bw;
+    for (int i = 0; i < P::NC; i++) {
+        uint64_t x = (uint64_t)P::HALF[i] - w[i] - bw;
         bw = (x >> 63) & 1;
     }
-    return bw != 0;   // HALF - c underflows  <=>  c > HALF
+    return bw != 0;
 }
 
 // a^(p-2) (Fermat inversion, square-and-multiply over the constant exponent); 0 -> 0
@@ -256,7 +490,7 @@ BBS_HD_NOINLINE Fe<P> fe_inv(const Fe<P>& a) {
     Fe<P> r = fe_one<P>();
     bool started = false;
 #pragma unroll
-    for (int i = P::N - 1; i >= 0; i--) {
+    for (int i = P::NC - 1; i >= 0; i--) {
         const uint32_t w = P::MOD_M2[i];
         for (int b = 31; b >= 0; b--) {
             if (started) r = fe_sqr<P>(r);

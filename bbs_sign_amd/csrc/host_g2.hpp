@@ -154,49 +154,57 @@ inline bool build_line_table(const G2Aff<C>& Q, LineTable<C>& tab) {
 // ABI field elements are little-endian canonical bytes (NB = 4*N).
 template <class P>
 inline bool fe_from_le_bytes(const uint8_t* b, Fe<P>& out) {
-    uint32_t l[P::N];
-    for (int i = 0; i < P::N; i++)
+    uint32_t l[P::NC];
+    for (int i = 0; i < P::NC; i++)
         l[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
     if (!limbs_lt_mod<P>(l)) return false;
-    out = fe_from_limbs<P>(l);
+    out = fe_from_words<P>(l);
     return true;
 }
 
 template <class P>
 inline void fe_to_le_bytes(const Fe<P>& a, uint8_t* b) {
-    Fe<P> c = fe_to_canonical<P>(a);
-    for (int i = 0; i < P::N; i++) {
-        b[4 * i] = (uint8_t)c.v[i]; b[4 * i + 1] = (uint8_t)(c.v[i] >> 8);
-        b[4 * i + 2] = (uint8_t)(c.v[i] >> 16); b[4 * i + 3] = (uint8_t)(c.v[i] >> 24);
+    uint32_t c[P::NC];
+    fe_to_words<P>(a, c);
+    for (int i = 0; i < P::NC; i++) {
+        b[4 * i] = (uint8_t)c[i]; b[4 * i + 1] = (uint8_t)(c[i] >> 8);
+        b[4 * i + 2] = (uint8_t)(c[i] >> 16); b[4 * i + 3] = (uint8_t)(c[i] >> 24);
     }
 }
 
 template <class P>
 inline void fe_to_be_bytes(const Fe<P>& a, uint8_t* b) {
-    uint8_t le[4 * P::N];
+    uint8_t le[4 * P::NC];
     fe_to_le_bytes<P>(a, le);
-    for (int i = 0; i < 4 * P::N; i++) b[i] = le[4 * P::N - 1 - i];
+    for (int i = 0; i < 4 * P::NC; i++) b[i] = le[4 * P::NC - 1 - i];
+}
+
+template <class P>
+inline bool fe_gt_half(const Fe<P>& a) {      // canonical value > (p-1)/2
+    uint32_t c[P::NC];
+    fe_to_words<P>(a, c);
+    return words_gt_half<P>(c);
 }
 
 // ark-serialize compressed G2 (see oracle/bbs.py g2_compress for the format notes)
 template <class C>
 inline void g2_compress(const G2Aff<C>& q, uint8_t* out) {
-    constexpr int NB = 4 * C::FpP::N;
+    constexpr int NB = 4 * C::FpP::NC;
     using P = typename C::FpP;
     if (C::ID == 0) {
         if (q.inf) { std::memset(out, 0, 2 * NB); out[0] = 0xC0; return; }
         fe_to_be_bytes<P>(q.x.c1, out);
         fe_to_be_bytes<P>(q.x.c0, out + NB);
         out[0] |= 0x80;
-        bool largest = fe_is_zero<P>(q.y.c1) ? canonical_gt_half<P>(fe_to_canonical<P>(q.y.c0))
-                                              : canonical_gt_half<P>(fe_to_canonical<P>(q.y.c1));
+        bool largest = fe_is_zero<P>(q.y.c1) ? fe_gt_half<P>(q.y.c0)
+                                              : fe_gt_half<P>(q.y.c1);
         if (largest) out[0] |= 0x20;
     } else {
         if (q.inf) { std::memset(out, 0, 2 * NB); out[2 * NB - 1] = 0x40; return; }
         fe_to_le_bytes<P>(q.x.c0, out);
         fe_to_le_bytes<P>(q.x.c1, out + NB);
-        bool largest = fe_is_zero<P>(q.y.c1) ? canonical_gt_half<P>(fe_to_canonical<P>(q.y.c0))
-                                              : canonical_gt_half<P>(fe_to_canonical<P>(q.y.c1));
+        bool largest = fe_is_zero<P>(q.y.c1) ? fe_gt_half<P>(q.y.c0)
+                                              : fe_gt_half<P>(q.y.c1);
         if (largest) out[2 * NB - 1] |= 0x80;
     }
 }
@@ -204,18 +212,18 @@ inline void g2_compress(const G2Aff<C>& q, uint8_t* out) {
 // ark-serialize compressed G1 from an affine point (host twin of the device compressor)
 template <class C>
 inline void g1_compress_host(const G1Aff<C>& p, uint8_t* out) {
-    constexpr int NB = 4 * C::FpP::N;
+    constexpr int NB = 4 * C::FpP::NC;
     using P = typename C::FpP;
     const bool inf = g1a_is_inf<C>(p);
     if (C::ID == 0) {
         if (inf) { std::memset(out, 0, NB); out[0] = 0xC0; return; }
         fe_to_be_bytes<P>(p.x, out);
         out[0] |= 0x80;
-        if (canonical_gt_half<P>(fe_to_canonical<P>(p.y))) out[0] |= 0x20;
+        if (fe_gt_half<P>(p.y)) out[0] |= 0x20;
     } else {
         if (inf) { std::memset(out, 0, NB); out[NB - 1] = 0x40; return; }
         fe_to_le_bytes<P>(p.x, out);
-        if (canonical_gt_half<P>(fe_to_canonical<P>(p.y))) out[NB - 1] |= 0x80;
+        if (fe_gt_half<P>(p.y)) out[NB - 1] |= 0x80;
     }
 }
 

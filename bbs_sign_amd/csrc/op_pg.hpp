@@ -10,15 +10,15 @@ struct PgJob : JobBase<C> {
     PgArgs<C> a{};
     std::vector<std::vector<uint32_t>> undisclosed;     // per item, sorted
     int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
-        constexpr int N = C::FpP::N;
+        constexpr int N = C::FpP::NC;       // canonical words
         constexpr int FPB = 4 * N;
-        if (this->use() || rt::sync(this->ctx->stream)) return BBS_E_HIP;
+        if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
         const int L = a.L;
         std::vector<uint32_t> P((size_t)3 * 2 * N * n), S((size_t)4 * 8 * n), M((size_t)std::max(L, 1) * 8 * n);
         if (this->down(P, a.out_pts) || this->down(S, a.out_sc) || this->down(M, a.out_mhat)) return BBS_E_HIP;
         std::vector<int8_t> st(n);
-        if (rt::d2h(st.data(), this->d_status.p, n, this->ctx->stream)) return BBS_E_HIP;
+        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
         const size_t rec = 6 * FPB + 128;
         uint64_t off = 0;
         for (size_t i = 0; i < n; i++) {
@@ -44,7 +44,8 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
                      const uint8_t* headers, const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off,
                      bbs_job** out) {
     constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int NC = C::FpP::NC;
+    constexpr int FPB = 4 * NC;
     using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!sigs || !msg_off || !didx_off || !rnd_off || !rnd))) return BBS_E_ARG;
@@ -58,7 +59,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     size_t rmax = 1;
     for (size_t i = 0; i < n; i++) rmax = std::max<size_t>(rmax, (size_t)(didx_off[i + 1] - didx_off[i]));
     Soa sa, se, sm, dmask, didx_s, rcount, rnd5, mt;
-    sa.init(2 * N, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
+    sa.init(2 * NC, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
     dmask.init((size_t)(std::max(L, 1) + 31) / 32, n); didx_s.init(rmax, n); rcount.init(1, n);
     rnd5.init(5 * 8, n); mt.init((size_t)std::max(L, 1) * 8, n);
     std::vector<uint8_t> seen;
@@ -117,18 +118,18 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.bpart = job->template scratch<uint32_t>((size_t)NFIX * 3 * N * n, rc);
     a.baff = job->template scratch<uint32_t>((size_t)2 * 2 * N * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)PG_NPARTS * 3 * N * n, rc);
-    a.out_pts = job->template scratch<uint32_t>((size_t)3 * 2 * N * n, rc);
+    a.out_pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * n, rc);
     a.out_sc = job->template scratch<uint32_t>((size_t)4 * 8 * n, rc);
     a.out_mhat = job->template scratch<uint32_t>((size_t)std::max(L, 1) * 8 * n, rc);
     if (rc) return rc;
     if ((rc = job->finish_setup())) return rc;
     a.status = job->d_status.template as<int8_t>();
     PgJob<C>* j = job.get();
-    j->stages.push_back({"pg_scalars", [j]() { return rt::launch<PgScalars<C>>(j->ctx->stream, j->a, j->n); }});
-    j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->ctx->stream, j->a, j->n * NFIX); }});
-    j->stages.push_back({"pg_b_combine", [j]() { return rt::launch<PgBCombine<C>>(j->ctx->stream, j->a, j->n); }});
-    j->stages.push_back({"pg_msm_parts", [j]() { return rt::launch<PgMsmPart<C>>(j->ctx->stream, j->a, j->n * PG_NPARTS); }});
-    j->stages.push_back({"pg_finalize", [j]() { return rt::launch<PgFinalize<C>>(j->ctx->stream, j->a, j->n); }});
+    j->stages.push_back({"pg_scalars", [j]() { return rt::launch<PgScalars<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->stream(), j->a, j->n * NFIX); }});
+    j->stages.push_back({"pg_b_combine", [j]() { return rt::launch<PgBCombine<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"pg_msm_parts", [j]() { return rt::launch<PgMsmPart<C>>(j->stream(), j->a, j->n * PG_NPARTS); }});
+    j->stages.push_back({"pg_finalize", [j]() { return rt::launch<PgFinalize<C>>(j->stream(), j->a, j->n); }});
     *out = job.release();
     return BBS_OK;
 }

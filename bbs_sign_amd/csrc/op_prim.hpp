@@ -67,26 +67,27 @@ template <class C>
 int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t* vp, const uint8_t* vs, size_t nv,
                      uint8_t* out, int8_t* status) {
     constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int NC = C::FpP::NC;
+    constexpr int FPB = 4 * NC;
     using R = typename C::FrP;
     if (!ctx->gens_set) return BBS_E_STATE;
     if (nf > (size_t)ctx->L + 2 || !out || !status || (nf && !fs) || (nv && (!vp || !vs))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
     Soa F, VP, VS;
-    F.init(std::max<size_t>(nf, 1) * 8, n); VP.init(std::max<size_t>(nv, 1) * 2 * N, n); VS.init(std::max<size_t>(nv, 1) * 8, n);
+    F.init(std::max<size_t>(nf, 1) * 8, n); VP.init(std::max<size_t>(nv, 1) * 2 * NC, n); VS.init(std::max<size_t>(nv, 1) * 8, n);
     std::vector<int8_t> st0(n, 1);
     for (size_t i = 0; i < n; i++) {
         bool ok = true;
         for (size_t k = 0; k < nf; k++) ok &= pack_fe<R>(F, k * 8, i, fs + (i * nf + k) * 32);
         for (size_t k = 0; k < nv; k++) {
-            ok &= pack_g1<C>(VP, k * 2 * N, i, vp + (i * nv + k) * 2 * FPB);
+            ok &= pack_g1<C>(VP, k * 2 * NC, i, vp + (i * nv + k) * 2 * FPB);
             ok &= pack_fe<R>(VS, k * 8, i, vs + (i * nv + k) * 32);
         }
         if (!ok) st0[i] = BBS_ST_NONCANONICAL;
     }
     DevBuf dF, dVP, dVS, dSt, dPart, dOut;
     if (dF.alloc(F.bytes()) || dVP.alloc(VP.bytes()) || dVS.alloc(VS.bytes()) || dSt.alloc(n + 4) ||
-        dPart.alloc((nv + NFIX) * 3 * N * n * 4 + 4) || dOut.alloc((size_t)2 * N * n * 4 + 4)) return BBS_E_NOMEM;
+        dPart.alloc((nv + NFIX) * 3 * N * n * 4 + 4) || dOut.alloc((size_t)2 * NC * n * 4 + 4)) return BBS_E_NOMEM;
     if (rt::h2d(dF.p, F.v.data(), F.bytes(), ctx->stream) || rt::h2d(dVP.p, VP.v.data(), VP.bytes(), ctx->stream) ||
         rt::h2d(dVS.p, VS.v.data(), VS.bytes(), ctx->stream) || rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
     int rc = ctx->sync_consts();
@@ -96,10 +97,10 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     a.fscal = dF.as<uint32_t>(); a.vpts = dVP.as<uint32_t>(); a.vscal = dVS.as<uint32_t>();
     a.status = dSt.as<int8_t>(); a.partials = dPart.as<uint32_t>(); a.out = dOut.as<uint32_t>();
     if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
-    std::vector<uint32_t> w((size_t)2 * N * n);
+    std::vector<uint32_t> w((size_t)2 * NC * n);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
     for (size_t i = 0; i < n; i++) {
-        if (status[i] == 1) unpack_words_le(w, n, 0, i, 2 * N, out + i * 2 * FPB);
+        if (status[i] == 1) unpack_words_le(w, n, 0, i, 2 * NC, out + i * 2 * FPB);
         else std::memset(out + i * 2 * FPB, 0, 2 * FPB);
     }
     return BBS_OK;
@@ -107,19 +108,20 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
 template <class C>
 int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
     constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int NC = C::FpP::NC;
+    constexpr int FPB = 4 * NC;
     if (!ctx->pk_set) return BBS_E_STATE;
     if (!status || (n && (!pa || !pb))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
     Soa A, B;
-    A.init(2 * N, n); B.init(2 * N, n);
+    A.init(2 * NC, n); B.init(2 * NC, n);
     std::vector<int8_t> st0(n, 1);
     for (size_t i = 0; i < n; i++) {
         bool ok = pack_g1<C>(A, 0, i, pa + i * 2 * FPB) & pack_g1<C>(B, 0, i, pb + i * 2 * FPB);
         if (!ok) st0[i] = BBS_ST_NONCANONICAL;
     }
     DevBuf dA, dB, dAm, dBm, dSt, dF;
-    if (dA.alloc(A.bytes()) || dB.alloc(B.bytes()) || dAm.alloc(A.bytes()) || dBm.alloc(B.bytes()) || dSt.alloc(n + 4) ||
+    if (dA.alloc(A.bytes()) || dB.alloc(B.bytes()) || dAm.alloc((size_t)2 * N * n * 4 + 4) || dBm.alloc((size_t)2 * N * n * 4 + 4) || dSt.alloc(n + 4) ||
         dF.alloc((size_t)2 * 12 * N * n * 4 + 4)) return BBS_E_NOMEM;
     if (rt::h2d(dA.p, A.v.data(), A.bytes(), ctx->stream) || rt::h2d(dB.p, B.v.data(), B.bytes(), ctx->stream) ||
         rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
@@ -139,7 +141,24 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     return rt::d2h(status, dSt.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
 }
 
-// GPU self-test of the lane-sliced Fp12 against the one-lane code (product build only)
+// GPU self-test of the lane-sliced Fp12: the reference result is computed by the SAME one-lane
+// tower code compiled for the host (tower.hpp / pairing.hpp, validated against the oracle by the
+// host-twin tests); only the six-lane version runs on the device.
+template <class C, int OP>
+static Fp12<C> selftest_ref(const Fp12<C>& x, const Fp12<C>& y, const CtxConsts<C>& hc, const G1Aff<C>& P) {
+    if constexpr (OP == 0) return f12_mul<C>(x, y);
+    else if constexpr (OP == 1) return f12_frob<C, 1>(x);
+    else if constexpr (OP == 2) return f12_frob<C, 2>(x);
+    else if constexpr (OP == 3) return f12_frob<C, 3>(x);
+    else if constexpr (OP == 4) return f12_inv<C>(x);
+    else if constexpr (OP == 5) return f12_conj<C>(x);
+    else if constexpr (OP == 6) return f12_mul_line<C>(x, hc.tab_bp2.e[3], P);
+    else if constexpr (OP == 7) return final_exponentiation<C>(x);
+    else if constexpr (OP == 10) return f12_sqr<C>(x);
+    else if constexpr (OP == 11) return f12_pow_x<C>(x);
+    else return x;
+}
+
 template <class C>
 int selftest_f12(Ctx<C>* ctx, int op, const uint8_t* a_le, const uint8_t* b_le, uint8_t* out_single, uint8_t* out_dist) {
 #ifdef BBS_HOST_TWIN
@@ -147,28 +166,46 @@ int selftest_f12(Ctx<C>* ctx, int op, const uint8_t* a_le, const uint8_t* b_le, 
     return BBS_E_ARG;
 #else
     constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int FPB = 4 * C::FpP::NC;
+    using P = typename C::FpP;
     if (ctx->use()) return BBS_E_HIP;
-    std::vector<uint32_t> A(12 * N), B(12 * N);
-    for (int k = 0; k < 12; k++) {
-        Fe<typename C::FpP> x, y;
-        if (!fe_from_le_bytes<typename C::FpP>(a_le + k * FPB, x) || !fe_from_le_bytes<typename C::FpP>(b_le + k * FPB, y)) return BBS_E_ARG;
-        for (int j = 0; j < N; j++) { A[k * N + j] = x.v[j]; B[k * N + j] = y.v[j]; }
+    Fp<C> xe[12], ye[12];
+    for (int k = 0; k < 12; k++)
+        if (!fe_from_le_bytes<P>(a_le + k * FPB, xe[k]) || !fe_from_le_bytes<P>(b_le + k * FPB, ye[k])) return BBS_E_ARG;
+    Fp12<C> x = f12_from_array<C>(xe), y = f12_from_array<C>(ye);
+    if (op >= 10) {   // cyclotomic input
+        x = f12_mul<C>(f12_conj<C>(x), f12_inv<C>(x));
+        x = f12_mul<C>(f12_frob<C, 2>(x), x);
     }
-    DevBuf dA, dB, dS, dD;
-    if (dA.alloc(A.size() * 4) || dB.alloc(B.size() * 4) || dS.alloc(A.size() * 4) || dD.alloc(A.size() * 4)) return BBS_E_NOMEM;
-    if (rt::h2d(dA.p, A.data(), A.size() * 4, ctx->stream) || rt::h2d(dB.p, B.data(), B.size() * 4, ctx->stream)) return BBS_E_HIP;
+    G1Aff<C> Pt = {ye[0], ye[1]};
+    Fp12<C> rs;
+    int lrc = -1;
+    std::vector<uint32_t> X(12 * N), B(12 * N);
+    f12_to_array<C>(x, xe);
+    for (int k = 0; k < 12; k++) for (int j = 0; j < N; j++) { X[k * N + j] = xe[k].v[j]; B[k * N + j] = ye[k].v[j]; }
+    DevBuf dB, dD;
+    if (dB.alloc(B.size() * 4) || dD.alloc(X.size() * 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dB.p, B.data(), B.size() * 4, ctx->stream) || rt::h2d(dD.p, X.data(), X.size() * 4, ctx->stream)) return BBS_E_HIP;
     int rc = ctx->sync_consts();
     if (rc) return rc;
-    SelfTestArgs<C> a{op, ctx->d_consts.template as<CtxConsts<C>>(), dA.as<uint32_t>(), dB.as<uint32_t>(), dS.as<uint32_t>(), dD.as<uint32_t>()};
-    if (rt::launch<SelfTestF12<C>>(ctx->stream, a, 64) || rt::sync(ctx->stream)) return BBS_E_HIP;
-    std::vector<uint32_t> S(12 * N), D(12 * N);
-    if (rt::d2h(S.data(), dS.p, S.size() * 4, ctx->stream) || rt::d2h(D.data(), dD.p, D.size() * 4, ctx->stream)) return BBS_E_HIP;
+    SelfTestArgs<C> a{op, ctx->d_consts.template as<CtxConsts<C>>(), nullptr, dB.as<uint32_t>(), nullptr, dD.as<uint32_t>()};
+#define BBS_ST_CASE(K) case K: rs = selftest_ref<C, K>(x, y, ctx->hc, Pt); lrc = rt::launch<SelfTestDist<C, K>>(ctx->stream, a, 64); break;
+    switch (op) {
+        BBS_ST_CASE(0) BBS_ST_CASE(1) BBS_ST_CASE(2) BBS_ST_CASE(3) BBS_ST_CASE(4) BBS_ST_CASE(5)
+        BBS_ST_CASE(6) BBS_ST_CASE(7) BBS_ST_CASE(10) BBS_ST_CASE(11)
+        default: return BBS_E_ARG;
+    }
+#undef BBS_ST_CASE
+    if (lrc || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> D(12 * N);
+    if (rt::d2h(D.data(), dD.p, D.size() * 4, ctx->stream)) return BBS_E_HIP;
+    Fp<C> se[12];
+    f12_to_array<C>(rs, se);
     for (int k = 0; k < 12; k++) {
-        Fe<typename C::FpP> x, y;
-        for (int j = 0; j < N; j++) { x.v[j] = S[k * N + j]; y.v[j] = D[k * N + j]; }
-        fe_to_le_bytes<typename C::FpP>(x, out_single + k * FPB);
-        fe_to_le_bytes<typename C::FpP>(y, out_dist + k * FPB);
+        Fe<P> yv;
+        for (int j = 0; j < N; j++) yv.v[j] = D[k * N + j];
+        fe_to_le_bytes<P>(se[k], out_single + k * FPB);
+        fe_to_le_bytes<P>(yv, out_dist + k * FPB);
     }
     return BBS_OK;
 #endif

@@ -17,8 +17,9 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
                      const uint64_t* commit_off, const uint8_t* dmsgs, const uint64_t* dmsg_off,
                      const uint64_t* didx, const uint64_t* didx_off, const uint8_t* headers,
                      const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off, bbs_job** out) {
-    constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int N = C::FpP::N;        // internal limbs
+    constexpr int NC = C::FpP::NC;      // canonical 32-bit words
+    constexpr int FPB = 4 * NC;
     using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!proofs_fixed || !commit_off || !dmsg_off || !didx_off))) return BBS_E_ARG;
@@ -32,7 +33,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     for (size_t i = 0; i < n; i++) rmax = std::max<size_t>(rmax, (size_t)(didx_off[i + 1] - didx_off[i]));
     if (rmax > 0xFFFFFF) return BBS_E_ARG;
     Soa pts, sc, slots, dmask, didx_s, rcount;
-    pts.init(3 * 2 * N, n); sc.init(4 * 8, n); slots.init((size_t)std::max(L, 1) * 8, n);
+    pts.init(3 * 2 * NC, n); sc.init(4 * 8, n); slots.init((size_t)std::max(L, 1) * 8, n);
     dmask.init((size_t)(std::max(L, 1) + 31) / 32, n); didx_s.init(rmax, n); rcount.init(1, n);
     std::vector<uint8_t> seen;
     for (size_t i = 0; i < n; i++) {
@@ -57,7 +58,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         if (distinct != r) { st = BBS_ST_PANIC_INDEX_OUT_OF_BOUNDS; continue; }
         const uint8_t* pf = proofs_fixed + i * rec;
         bool ok = true;
-        for (int p = 0; p < 3; p++) ok &= pack_g1<C>(pts, (size_t)p * 2 * N, i, pf + (size_t)p * 2 * FPB);
+        for (int p = 0; p < 3; p++) ok &= pack_g1<C>(pts, (size_t)p * 2 * NC, i, pf + (size_t)p * 2 * FPB);
         for (int k = 0; k < 4; k++) ok &= pack_fe<R>(sc, (size_t)k * 8, i, pf + 6 * FPB + 32 * k);
         // slots: disclosed messages at their index, commitments at the sorted undisclosed indexes
         for (size_t k = 0; k < r; k++) {
@@ -97,21 +98,21 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     int8_t* pair_ok = job->template scratch<int8_t>(n ? n : 1, rc);
     if (rc) return rc;
     PairArgs<C>& pa = job->pa;
-    pa.n = n; pa.cc = a.cc; pa.pa = a.pts; pa.pb = a.pts + (size_t)2 * N * n; pa.negate_b = 1;
+    pa.n = n; pa.cc = a.cc; pa.pa = a.pts; pa.pb = a.pts + (size_t)2 * NC * n; pa.negate_b = 1;
     pa.canonical = 1; pa.gate_arr = job->d_status0.template as<int8_t>(); pa.gate = 1; pa.out = pair_ok;
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
-    j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->ctx->stream, j->a, j->n); }});
+    j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
 #ifdef BBS_HOST_TWIN
     j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->stream_aux(), j->pa, j->n * 2); }, 1, 0});
     j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->stream_aux(), j->pa, j->n); }, 1, 0});
 #else
     j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->stream_aux(), j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, 1, 0});
 #endif
-    j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->ctx->stream, j->a, j->n * PV_NPARTS); }});
-    j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->ctx->stream, j->a, j->n); }});
-    j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->ctx->stream, j->fin, j->n); }, 0, 1});
+    j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
+    j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     *out = job.release();
     return BBS_OK;
 }

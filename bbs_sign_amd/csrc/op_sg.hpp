@@ -9,13 +9,13 @@ struct SgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     SgArgs<C> a{};
     int fetch_signatures(uint8_t* out) override {
-        constexpr int N = C::FpP::N;
-        if (this->use() || rt::sync(this->ctx->stream)) return BBS_E_HIP;
+        constexpr int N = C::FpP::NC;       // canonical words
+        if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
         std::vector<uint32_t> A((size_t)2 * N * n), E((size_t)8 * n);
         if (this->down(A, a.out_a) || this->down(E, a.out_e)) return BBS_E_HIP;
         std::vector<int8_t> st(n);
-        if (rt::d2h(st.data(), this->d_status.p, n, this->ctx->stream)) return BBS_E_HIP;
+        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
         const size_t rec = 8 * N + 32;
         for (size_t i = 0; i < n; i++) {
             if (st[i] != 1) { std::memset(out + i * rec, 0, rec); continue; }
@@ -59,15 +59,15 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)NFIX * 3 * N * n, rc);
-    a.out_a = job->template scratch<uint32_t>((size_t)2 * N * n, rc);
+    a.out_a = job->template scratch<uint32_t>((size_t)2 * C::FpP::NC * n, rc);
     a.out_e = job->template scratch<uint32_t>((size_t)8 * n, rc);
     if (rc) return rc;
     if ((rc = job->finish_setup())) return rc;
     a.status = job->d_status.template as<int8_t>();
     SgJob<C>* j = job.get();
-    j->stages.push_back({"sg_scalars", [j]() { return rt::launch<SgScalars<C>>(j->ctx->stream, j->a, j->n); }});
-    j->stages.push_back({"sg_msm_parts", [j]() { return rt::launch<SgMsmPart<C>>(j->ctx->stream, j->a, j->n * NFIX); }});
-    j->stages.push_back({"sg_combine", [j]() { return rt::launch<SgCombine<C>>(j->ctx->stream, j->a, j->n); }});
+    j->stages.push_back({"sg_scalars", [j]() { return rt::launch<SgScalars<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"sg_msm_parts", [j]() { return rt::launch<SgMsmPart<C>>(j->stream(), j->a, j->n * NFIX); }});
+    j->stages.push_back({"sg_combine", [j]() { return rt::launch<SgCombine<C>>(j->stream(), j->a, j->n); }});
     *out = job.release();
     return BBS_OK;
 }

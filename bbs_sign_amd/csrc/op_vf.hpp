@@ -15,7 +15,8 @@ template <class C>
 int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, const uint64_t* msg_off,
                      const uint8_t* headers, const uint64_t* hdr_off, bbs_job** out) {
     constexpr int N = C::FpP::N;
-    constexpr int FPB = 4 * N;
+    constexpr int NC = C::FpP::NC;
+    constexpr int FPB = 4 * NC;
     using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!sigs || !msg_off))) return BBS_E_ARG;
@@ -26,7 +27,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     job->n = n;
     job->status0.assign(n, 1);
     Soa sa, se, sm;
-    sa.init(2 * N, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
+    sa.init(2 * NC, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
     for (size_t i = 0; i < n; i++) {
         int8_t& st = job->status0[i];
         const size_t l = (size_t)(msg_off[i + 1] - msg_off[i]);
@@ -55,14 +56,14 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     pa.n = n; pa.cc = a.cc; pa.pa = a.aff; pa.pb = a.aff + (size_t)2 * N * n; pa.negate_b = 0;
     pa.canonical = 0; pa.gate_arr = a.status; pa.gate = 2; pa.out = a.status; pa.fmiller = a.fmiller;
     VfJob<C>* j = job.get();
-    j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->ctx->stream, j->a, j->n); }});
-    j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->ctx->stream, j->a, j->n * VF_NPARTS); }});
-    j->stages.push_back({"vf_combine", [j]() { return rt::launch<VfCombine<C>>(j->ctx->stream, j->a, j->n); }});
+    j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->stream(), j->a, j->n * VF_NPARTS); }});
+    j->stages.push_back({"vf_combine", [j]() { return rt::launch<VfCombine<C>>(j->stream(), j->a, j->n); }});
 #ifdef BBS_HOST_TWIN
-    j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->ctx->stream, j->pa, j->n * 2); }});
-    j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->ctx->stream, j->pa, j->n); }});
+    j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->stream(), j->pa, j->n * 2); }});
+    j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->stream(), j->pa, j->n); }});
 #else
-    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->ctx->stream, j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
+    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->stream(), j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
 #endif
     *out = job.release();
     return BBS_OK;

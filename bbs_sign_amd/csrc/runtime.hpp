@@ -148,16 +148,16 @@ struct Soa {
 // canonical scalar (32 B LE) into SoA words [w0, w0+8); returns false if >= r
 template <class P>
 inline bool pack_fe(Soa& s, size_t w0, size_t i, const uint8_t* le) {
-    uint32_t l[P::N];
-    for (int k = 0; k < P::N; k++) l[k] = le32(le + 4 * k);
-    for (int k = 0; k < P::N; k++) s.at(w0 + k, i) = l[k];
+    uint32_t l[P::NC];
+    for (int k = 0; k < P::NC; k++) l[k] = le32(le + 4 * k);
+    for (int k = 0; k < P::NC; k++) s.at(w0 + k, i) = l[k];
     return limbs_lt_mod<P>(l);
 }
 template <class C>
 inline bool pack_g1(Soa& s, size_t w0, size_t i, const uint8_t* xy) {
-    constexpr int N = C::FpP::N;
+    constexpr int NC = C::FpP::NC;
     bool a = pack_fe<typename C::FpP>(s, w0, i, xy);
-    bool b = pack_fe<typename C::FpP>(s, w0 + N, i, xy + 4 * N);
+    bool b = pack_fe<typename C::FpP>(s, w0 + NC, i, xy + 4 * NC);
     return a && b;
 }
 inline void unpack_words_le(const std::vector<uint32_t>& v, size_t n, size_t w0, size_t i, int words, uint8_t* out) {
@@ -196,8 +196,8 @@ struct bbs_ctx {
 
 template <class C>
 struct Ctx : bbs_ctx {
-    static constexpr int N = C::FpP::N;
-    static constexpr int FPB = 4 * N;
+    static constexpr int N = C::FpP::N;          // internal limbs
+    static constexpr int FPB = 4 * C::FpP::NC;   // bytes of a canonical field element
     int device = 0;
     rt::Stream stream{};
     int win_bits = 8;
@@ -356,15 +356,17 @@ struct JobBase : bbs_job {
     std::vector<int8_t> status0;     // host-validated initial status (1 placeholder = to compute)
     DevBuf d_status, d_status0;
     std::vector<std::unique_ptr<DevBuf>> bufs;
-    rt::Stream aux{};
+    // every job owns its streams: independent jobs (batches) of one context overlap on the GPU
+    rt::Stream main{}, aux{};
     rt::Event ev_fork{}, ev_join{};
-    bool aux_ready = false;
-    explicit JobBase(Ctx<C>* c) : ctx(c) {}
+    bool main_ready = false, aux_ready = false;
+    explicit JobBase(Ctx<C>* c) : ctx(c) { main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); }
     ~JobBase() override {
         if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
+        if (main_ready) { rt::sync(main); rt::stream_destroy(main); }
     }
     int use() override { return ctx->use(); }
-    rt::Stream& stream() override { return ctx->stream; }
+    rt::Stream& stream() override { return main_ready ? main : ctx->stream; }
     int ensure_aux() {
         if (aux_ready) return 0;
         if (rt::stream_create(&aux) || rt::event_create(&ev_fork) || rt::event_create(&ev_join)) return -1;
@@ -374,16 +376,16 @@ struct JobBase : bbs_job {
     rt::Stream& stream_aux() override { ensure_aux(); return aux; }
     int fork_aux() override {
         if (ensure_aux()) return -1;
-        return (rt::event_record(ev_fork, ctx->stream) || rt::stream_wait(aux, ev_fork)) ? -1 : 0;
+        return (rt::event_record(ev_fork, stream()) || rt::stream_wait(aux, ev_fork)) ? -1 : 0;
     }
     int join_aux() override {
-        return (rt::event_record(ev_join, aux) || rt::stream_wait(ctx->stream, ev_join)) ? -1 : 0;
+        return (rt::event_record(ev_join, aux) || rt::stream_wait(stream(), ev_join)) ? -1 : 0;
     }
     // device-to-device, asynchronous: back-to-back runs of one job never wait for the host
-    int reset() override { return rt::d2d_async(d_status.p, d_status0.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK; }
+    int reset() override { return rt::d2d_async(d_status.p, d_status0.p, n, stream()) ? BBS_E_HIP : BBS_OK; }
     int fetch_status(int8_t* out) override {
-        if (use() || rt::sync(ctx->stream)) return BBS_E_HIP;
-        return rt::d2h(out, d_status.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
+        if (use() || rt::sync(stream())) return BBS_E_HIP;
+        return rt::d2h(out, d_status.p, n, stream()) ? BBS_E_HIP : BBS_OK;
     }
     // upload a host vector, return device pointer (owned by the job)
     template <class T>
@@ -391,7 +393,7 @@ struct JobBase : bbs_job {
         bufs.emplace_back(new DevBuf());
         DevBuf& b = *bufs.back();
         if (b.alloc(v.size() * sizeof(T))) { rc = BBS_E_NOMEM; return nullptr; }
-        if (rt::h2d(b.p, v.data(), v.size() * sizeof(T), ctx->stream)) { rc = BBS_E_HIP; return nullptr; }
+        if (rt::h2d(b.p, v.data(), v.size() * sizeof(T), stream())) { rc = BBS_E_HIP; return nullptr; }
         return b.as<T>();
     }
     template <class T>
@@ -403,12 +405,12 @@ struct JobBase : bbs_job {
     }
     int finish_setup() {
         if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
-        if (rt::h2d(d_status0.p, status0.data(), n, ctx->stream)) return BBS_E_HIP;
+        if (rt::h2d(d_status0.p, status0.data(), n, stream())) return BBS_E_HIP;
         return ctx->sync_consts();
     }
     template <class T>
     int down(std::vector<T>& v, const T* dptr) {
-        return rt::d2h(v.data(), dptr, v.size() * sizeof(T), ctx->stream) ? BBS_E_HIP : BBS_OK;
+        return rt::d2h(v.data(), dptr, v.size() * sizeof(T), stream()) ? BBS_E_HIP : BBS_OK;
     }
 };
 

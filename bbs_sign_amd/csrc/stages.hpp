@@ -78,14 +78,15 @@ BBS_HD Fr<C> fr_load_canon(const uint32_t* base, size_t n, size_t i) {   // cano
 template <class C>
 BBS_HD Fr<C> fr_to_mont(const Fr<C>& canon) { return fe_from_limbs<typename C::FrP>(canon.v); }
 
+// canonical affine point: 2 * NC 32-bit words per item (x then y)
 template <class C>
 BBS_HD G1Aff<C> g1a_load_canon_to_mont(const uint32_t* base, size_t n, size_t i) {
-    constexpr int N = C::FpP::N;
-    uint32_t w[2 * N];
-    soa_ld<2 * N>(base, n, i, w);
+    constexpr int NC = C::FpP::NC;
+    uint32_t w[2 * NC];
+    soa_ld<2 * NC>(base, n, i, w);
     G1Aff<C> p;
-    p.x = fe_from_limbs<typename C::FpP>(w);
-    p.y = fe_from_limbs<typename C::FpP>(w + N);
+    p.x = fe_from_words<typename C::FpP>(w);
+    p.y = fe_from_words<typename C::FpP>(w + NC);
     return p;
 }
 template <class C>
@@ -104,10 +105,12 @@ BBS_HD void g1a_store_mont(uint32_t* base, size_t n, size_t i, const G1Aff<C>& p
 }
 template <class C>
 BBS_HD void g1a_store_canon(uint32_t* base, size_t n, size_t i, const G1Aff<C>& p) {
-    constexpr int N = C::FpP::N;
-    Fp<C> x = fe_to_canonical<typename C::FpP>(p.x), y = fe_to_canonical<typename C::FpP>(p.y);
-    soa_st<N>(base, n, i, x.v);
-    soa_st<N>(base + (size_t)N * n, n, i, y.v);
+    constexpr int NC = C::FpP::NC;
+    uint32_t x[NC], y[NC];
+    fe_to_words<typename C::FpP>(p.x, x);
+    fe_to_words<typename C::FpP>(p.y, y);
+    soa_st<NC>(base, n, i, x);
+    soa_st<NC>(base + (size_t)NC * n, n, i, y);
 }
 template <class C>
 BBS_HD G1Jac<C> g1j_load(const uint32_t* base, size_t n, size_t i) {
@@ -131,10 +134,12 @@ BBS_HD void g1j_store(uint32_t* base, size_t n, size_t i, const G1Jac<C>& p) {
 template <class C>
 __host__ __device__ inline void sha256_g1_compressed(Sha256& s, const G1Aff<C>& p) {
     using P = typename C::FpP;
-    constexpr int N = P::N;
+    constexpr int N = P::NC;                     // canonical words
     const bool inf = g1a_is_inf<C>(p);
-    Fp<C> x = fe_to_canonical<P>(p.x);
-    const bool ybig = canonical_gt_half<P>(fe_to_canonical<P>(p.y));
+    struct { uint32_t v[P::NC]; } x, yw;
+    fe_to_words<P>(p.x, x.v);
+    fe_to_words<P>(p.y, yw.v);
+    const bool ybig = words_gt_half<P>(yw.v);
     if constexpr (C::ID == 0) {
         // 48 bytes big-endian, flags in the first byte
         uint32_t flags = inf ? 0xC0000000u : (0x80000000u | (ybig ? 0x20000000u : 0u));
@@ -229,7 +234,7 @@ struct PvArgs {
     int L, Rmax;
     const CtxConsts<C>* cc;
     // inputs (canonical limbs, SoA)
-    const uint32_t* pts;      // [3][2N][n]  a_bar, b_bar, d
+    const uint32_t* pts;      // [3][2NC][n] a_bar, b_bar, d (canonical words)
     const uint32_t* sc;       // [4][8][n]   e_cap, r1_cap, r3_cap, challenge
     const uint32_t* slots;    // [L][8][n]   slot j: disclosed message m_j or commitment m^_j
     const uint32_t* dmask;    // [ceil(L/32)][n]
@@ -285,7 +290,7 @@ struct PvMsmPart {
             // part: 0 c*Bbar | 1 e^*Abar | 2 r1^*D | 3 r3^*D
             const int pt = (part == 0) ? 1 : (part == 1) ? 0 : 2;
             const int scw = (part == 0) ? 3 : (part == 1) ? 0 : (part == 2) ? 1 : 2;
-            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * N * n, n, i);
+            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * C::FpP::NC * n, n, i);
             if (part < 3) {
                 if (!g1a_on_curve<C>(p)) { a.status[i] = -41; return; }
                 g1a_store_mont<C>(a.aff + (size_t)pt * 2 * N * n, n, i, p);
@@ -371,19 +376,34 @@ struct PvFinish {
     }
 };
 
+// Fp12 <-> 12 Fp in tower order (c0.c0.c0, c0.c0.c1, c0.c1.c0, .., c1.c2.c1), no pointer casts
+template <class C>
+BBS_HD void f12_to_array(const Fp12<C>& f, Fp<C>* e) {
+    e[0] = f.c0.c0.c0; e[1] = f.c0.c0.c1; e[2] = f.c0.c1.c0; e[3] = f.c0.c1.c1; e[4] = f.c0.c2.c0; e[5] = f.c0.c2.c1;
+    e[6] = f.c1.c0.c0; e[7] = f.c1.c0.c1; e[8] = f.c1.c1.c0; e[9] = f.c1.c1.c1; e[10] = f.c1.c2.c0; e[11] = f.c1.c2.c1;
+}
+template <class C>
+BBS_HD Fp12<C> f12_from_array(const Fp<C>* e) {
+    Fp12<C> f;
+    f.c0.c0.c0 = e[0]; f.c0.c0.c1 = e[1]; f.c0.c1.c0 = e[2]; f.c0.c1.c1 = e[3]; f.c0.c2.c0 = e[4]; f.c0.c2.c1 = e[5];
+    f.c1.c0.c0 = e[6]; f.c1.c0.c1 = e[7]; f.c1.c1.c0 = e[8]; f.c1.c1.c1 = e[9]; f.c1.c2.c0 = e[10]; f.c1.c2.c1 = e[11];
+    return f;
+}
 template <class C>
 BBS_HD void f12_store(uint32_t* base, size_t n, size_t i, const Fp12<C>& f) {
     constexpr int N = C::FpP::N;
-    const Fp<C>* e = reinterpret_cast<const Fp<C>*>(&f);
+    Fp<C> e[12];
+    f12_to_array<C>(f, e);
+#pragma unroll
     for (int k = 0; k < 12; k++) soa_st<N>(base + (size_t)k * N * n, n, i, e[k].v);
 }
 template <class C>
 BBS_HD Fp12<C> f12_load(const uint32_t* base, size_t n, size_t i) {
     constexpr int N = C::FpP::N;
-    Fp12<C> f;
-    Fp<C>* e = reinterpret_cast<Fp<C>*>(&f);
+    Fp<C> e[12];
+#pragma unroll
     for (int k = 0; k < 12; k++) soa_ld<N>(base + (size_t)k * N * n, n, i, e[k].v);
-    return f;
+    return f12_from_array<C>(e);
 }
 
 // lane per (pair, item)
@@ -505,7 +525,7 @@ struct VfArgs {
     size_t n;
     int L;
     const CtxConsts<C>* cc;
-    const uint32_t* sig_a;    // [2N][n] canonical
+    const uint32_t* sig_a;    // [2NC][n] canonical
     const uint32_t* sig_e;    // [8][n]
     const uint32_t* msgs;     // [L][8][n]
     const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
@@ -586,7 +606,7 @@ struct SgArgs {
     int8_t* status;
     uint32_t* fscal;          // [L+2][8][n]
     uint32_t* partials;       // [NFIX][3N][n]
-    uint32_t* out_a;          // [2N][n] canonical
+    uint32_t* out_a;          // [2NC][n] canonical
     uint32_t* out_e;          // [8][n] canonical
 };
 
@@ -665,7 +685,7 @@ struct PgArgs {
     size_t n;
     int L, Rmax;
     const CtxConsts<C>* cc;
-    const uint32_t* sig_a;    // [2N][n] canonical
+    const uint32_t* sig_a;    // [2NC][n] canonical
     const uint32_t* sig_e;    // [8][n]
     const uint32_t* msgs;     // [L][8][n]
     const uint32_t* dmask;    // [ceil(L/32)][n] disclosed slots
@@ -685,7 +705,7 @@ struct PgArgs {
     uint32_t* baff;           // [2][2N][n]  B, A (Montgomery affine)
     uint32_t* partials;       // [PG_NPARTS][3N][n]
     // outputs (canonical)
-    uint32_t* out_pts;        // [3][2N][n]  a_bar, b_bar, d
+    uint32_t* out_pts;        // [3][2NC][n] a_bar, b_bar, d (canonical)
     uint32_t* out_sc;         // [4][8][n]   e^, r1^, r3^, c
     uint32_t* out_mhat;       // [L][8][n]   m^_j at undisclosed slots
 };
@@ -845,7 +865,7 @@ struct PgFinalize {
             Fr<C> mh = fe_add<R>(mt, fe_mul<R>(c, m));
             soa_st<8>(a.out_mhat + (size_t)j * 8 * n, n, i, mh.v);
         }
-        for (int p = 0; p < 3; p++) g1a_store_canon<C>(a.out_pts + (size_t)p * 2 * N * n, n, i, pa[p]);
+        for (int p = 0; p < 3; p++) g1a_store_canon<C>(a.out_pts + (size_t)p * 2 * C::FpP::NC * n, n, i, pa[p]);
         a.status[i] = 1;
     }
 };
@@ -880,11 +900,11 @@ struct MsmArgs {
     int n_fixed, n_var;
     const CtxConsts<C>* cc;
     const uint32_t* fscal;    // [n_fixed][8][n]
-    const uint32_t* vpts;     // [n_var][2N][n] canonical
+    const uint32_t* vpts;     // [n_var][2NC][n] canonical
     const uint32_t* vscal;    // [n_var][8][n]
     int8_t* status;
     uint32_t* partials;       // [n_var + NFIX][3N][n]
-    uint32_t* out;            // [2N][n] canonical
+    uint32_t* out;            // [2NC][n] canonical
 };
 
 template <class C>
@@ -897,7 +917,7 @@ struct MsmPart {
         if (a.status[i] < 0) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         if (part < a.n_var) {
-            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * N * n, n, i);
+            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * C::FpP::NC * n, n, i);
             if (!g1a_on_curve<C>(p)) { a.status[i] = -41; g1j_store<C>(out, n, i, g1j_inf<C>()); return; }
             uint32_t k[8];
             soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
@@ -988,45 +1008,38 @@ struct SelfTestArgs {
     uint32_t* out_single;   // 12 Fp
     uint32_t* out_dist;     // 12 Fp
 };
-template <class C>
-struct SelfTestF12 {
+// six-lane version; input x = out_dist as prepared by the host (already cyclotomic for OP >= 10)
+template <class C, int OP>
+struct SelfTestDist {
     static __device__ void run(const SelfTestArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const int lane = (int)(t & 63);
-        if (lane >= GRP) return;
-        Lane6 L{0, lane};
-        Fp12<C> x, y;
-        Fp<C>* xe = reinterpret_cast<Fp<C>*>(&x);
-        Fp<C>* ye = reinterpret_cast<Fp<C>*>(&y);
-        for (int k = 0; k < 12; k++) for (int j = 0; j < N; j++) { xe[k].v[j] = a.a[k * N + j]; ye[k].v[j] = a.b[k * N + j]; }
-        if (a.op >= 10) {   // make x cyclotomic first
-            x = f12_mul<C>(f12_conj<C>(x), f12_inv<C>(x));
-            x = f12_mul<C>(f12_frob<C, 2>(x), x);
+        const int grp = lane / GRP;
+        if (grp >= 1) return;
+        Lane6 L{grp * GRP, lane - grp * GRP};
+        // w-basis coefficient m of a tower-ordered array: g_m = (e[2k], e[2k+1]) with k = (m & 1) * 3 + (m >> 1)
+        const int k = (L.m & 1) * 3 + (L.m >> 1);
+        Fp2<C> gx, gy;
+        for (int j = 0; j < N; j++) {
+            gx.c0.v[j] = a.out_dist[(2 * k) * N + j]; gx.c1.v[j] = a.out_dist[(2 * k + 1) * N + j];
+            gy.c0.v[j] = a.b[(2 * k) * N + j]; gy.c1.v[j] = a.b[(2 * k + 1) * N + j];
         }
-        Fp2<C> gx = d_scatter<C>(L, x), gy = d_scatter<C>(L, y);
+        G1Aff<C> P;
+        for (int j = 0; j < N; j++) { P.x.v[j] = a.b[j]; P.y.v[j] = a.b[N + j]; }
         const uint32_t* ft = &a.cc->frob[0][0][0][0];
-        G1Aff<C> P = {ye[0], ye[1]};
-        Fp12<C> rs;
         Fp2<C> rd;
-        switch (a.op) {
-            case 0: rs = f12_mul<C>(x, y); rd = d_mul<C>(L, gx, gy); break;
-            case 1: rs = f12_frob<C, 1>(x); rd = d_frob<C, 1>(L, gx, ft); break;
-            case 2: rs = f12_frob<C, 2>(x); rd = d_frob<C, 2>(L, gx, ft); break;
-            case 3: rs = f12_frob<C, 3>(x); rd = d_frob<C, 3>(L, gx, ft); break;
-            case 4: rs = f12_inv<C>(x); rd = d_inv<C>(L, gx); break;
-            case 5: rs = f12_conj<C>(x); rd = d_conj<C>(L, gx); break;
-            case 6: rs = f12_mul_line<C>(x, a.cc->tab_bp2.e[3], P); rd = d_mul_line<C>(L, gx, a.cc->tab_bp2.e[3], P); break;
-            case 7: rs = final_exponentiation<C>(x); rd = d_final_exp<C>(L, gx, ft); break;
-            case 10: rs = f12_sqr<C>(x); rd = d_cyclo_sqr<C>(L, gx); break;
-            case 11: rs = f12_pow_x<C>(x); rd = d_pow_x<C>(L, gx); break;
-            default: rs = x; rd = gx;
-        }
-        Fp12<C> rdg = d_gather<C>(L, rd);
-        if (lane == 0) {
-            const Fp<C>* se = reinterpret_cast<const Fp<C>*>(&rs);
-            const Fp<C>* de = reinterpret_cast<const Fp<C>*>(&rdg);
-            for (int k = 0; k < 12; k++) for (int j = 0; j < N; j++) { a.out_single[k * N + j] = se[k].v[j]; a.out_dist[k * N + j] = de[k].v[j]; }
-        }
+        if constexpr (OP == 0) rd = d_mul<C>(L, gx, gy);
+        else if constexpr (OP == 1) rd = d_frob<C, 1>(L, gx, ft);
+        else if constexpr (OP == 2) rd = d_frob<C, 2>(L, gx, ft);
+        else if constexpr (OP == 3) rd = d_frob<C, 3>(L, gx, ft);
+        else if constexpr (OP == 4) rd = d_inv<C>(L, gx);
+        else if constexpr (OP == 5) rd = d_conj<C>(L, gx);
+        else if constexpr (OP == 6) rd = d_mul_line<C>(L, gx, a.cc->tab_bp2.e[3], P);
+        else if constexpr (OP == 7) rd = d_final_exp<C>(L, gx, ft);
+        else if constexpr (OP == 10) rd = d_cyclo_sqr<C>(L, gx);
+        else if constexpr (OP == 11) rd = d_pow_x<C>(L, gx);
+        else rd = gx;
+        for (int j = 0; j < N; j++) { a.out_dist[(2 * k) * N + j] = rd.c0.v[j]; a.out_dist[(2 * k + 1) * N + j] = rd.c1.v[j]; }
     }
 };
 #endif

@@ -49,14 +49,14 @@ BBS_HD_NOINLINE Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
     // Karatsuba: 3 Fp multiplications
     Fp<C> t0 = fe_mul<FP>(a.c0, b.c0);
     Fp<C> t1 = fe_mul<FP>(a.c1, b.c1);
-    Fp<C> s = fe_mul<FP>(fe_add<FP>(a.c0, a.c1), fe_add<FP>(b.c0, b.c1));
+    Fp<C> s = fe_mul<FP>(fe_add_nr<FP>(a.c0, a.c1), fe_add_nr<FP>(b.c0, b.c1));   // lazy sums feed the multiplier only
     return {fe_sub<FP>(t0, t1), fe_sub<FP>(fe_sub<FP>(s, t0), t1)};
 }
 
 template <class C>
 BBS_HD_NOINLINE Fp2<C> f2_sqr(const Fp2<C>& a) {
     // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp multiplications
-    Fp<C> t = fe_mul<FP>(fe_add<FP>(a.c0, a.c1), fe_sub<FP>(a.c0, a.c1));
+    Fp<C> t = fe_mul<FP>(fe_add_nr<FP>(a.c0, a.c1), fe_sub<FP>(a.c0, a.c1));
     Fp<C> m = fe_mul<FP>(a.c0, a.c1);
     return {t, fe_dbl<FP>(m)};
 }

@@ -1,4 +1,4 @@
-"""GPU self-test: the six-lane (wavefront-cooperative) Fp12 arithmetic against the one-lane code,
+"""GPU self-test: the six-lane (wavefront-cooperative) Fp12 arithmetic on the GPU against the one-lane code (run on the host),
 operation by operation, and the one-lane multiplication against the oracle's Fp12."""
 import ctypes
 import random

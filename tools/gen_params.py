@@ -21,6 +21,58 @@ def arr(name, v, n):
     return "    static constexpr uint32_t %s[%d] = {%s};\n" % (name, n, body)
 
 
+def limbs28(v, n):
+    assert 0 <= v < (1 << (28 * n))
+    return [(v >> (28 * i)) & 0xFFFFFFF for i in range(n)]
+
+
+def arr28(name, v, n):
+    body = ", ".join("0x%07xu" % w for w in limbs28(v, n))
+    return "    static constexpr uint32_t %s[%d] = {%s};\n" % (name, n, body)
+
+
+def raw_arr(name, ws):
+    body = ", ".join("0x%08xu" % w for w in ws)
+    return "    static constexpr uint32_t %s[%d] = {%s};\n" % (name, len(ws), body)
+
+
+def field28_struct(name, mod, n, nc, bound_mult):
+    """Base field in radix 2^28 (carry-free multiply-accumulate columns, see field.hpp)."""
+    R = 1 << (28 * n)
+    inv = (-pow(mod, -1, 1 << 28)) % (1 << 28)
+    E = mod.bit_length()
+    qshift = E - 28 * (n - 1)
+    assert qshift > 0
+    # closure of the lazy add/sub: results stay < bound_mult * p (see field.hpp)
+    alpha = (1 << E) / mod
+    qmax = int(2 * bound_mult / alpha)
+    assert alpha + qmax * (alpha - 1) < bound_mult, (name, alpha, qmax)
+    # subtraction constant: SUBM = bound_mult * p with limbs adjusted so that every lower limb has
+    # 2^28 borrowed from the limb above (limbs >= 2^28 - 1 >= any normalised limb of b)
+    m = limbs28(bound_mult * mod, n)
+    adj = [m[0] + (1 << 28)] + [m[i] + (1 << 28) - 1 for i in range(1, n - 1)] + [m[n - 1] - 1]
+    assert sum(a << (28 * i) for i, a in enumerate(adj)) == bound_mult * mod
+    assert all(0 <= a < (1 << 30) for a in adj)
+    s = "struct %s {\n" % name
+    s += "    static constexpr int W = 28;            // limb width (bits)\n"
+    s += "    static constexpr int N = %d;            // internal limbs\n" % n
+    s += "    static constexpr int NC = %d;           // canonical 32-bit words\n" % nc
+    s += "    static constexpr int BITS = %d;\n" % E
+    s += "    static constexpr int BOUND = %d;        // values are kept < BOUND * p\n" % bound_mult
+    s += "    static constexpr int QSHIFT = %d;       // top limb >> QSHIFT estimates floor(v / 2^BITS)\n" % qshift
+    s += "    static constexpr uint32_t INV = 0x%07xu;   // -mod^-1 mod 2^28\n" % inv
+    s += arr28("MOD", mod, n)
+    s += arr28("MOD2", 2 * mod, n)
+    s += arr28("MODB", bound_mult * mod, n)   # BOUND * p, added before a subtraction
+    s += arr28("ONE", R % mod, n)
+    s += arr28("R2", R * R % mod, n)
+    s += arr("MODC", mod, nc)                # canonical 32-bit limbs
+    s += arr("HALF", (mod - 1) // 2, nc)
+    s += arr("MOD_M2", mod - 2, nc)
+    s += "};\n\n"
+    return s
+
+
 def f2_mul(a, b, p):
     return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
 
@@ -39,13 +91,16 @@ def field_struct(name, mod, n):
     R = 1 << (32 * n)
     inv = (-pow(mod, -1, 1 << 32)) % (1 << 32)
     s = "struct %s {\n" % name
+    s += "    static constexpr int W = 32;\n"
     s += "    static constexpr int N = %d;\n" % n
+    s += "    static constexpr int NC = %d;\n" % n
     s += "    static constexpr int BITS = %d;\n" % mod.bit_length()
     s += "    static constexpr uint32_t INV = 0x%08xu;   // -mod^-1 mod 2^32\n" % inv
     s += arr("MOD", mod, n)
     s += arr("ONE", R % mod, n)            # R mod p  (Montgomery 1)
     s += arr("R2", R * R % mod, n)         # R^2 mod p
     s += arr("R3", R * R * R % mod, n)     # R^3 mod p
+    s += arr("MODC", mod, n)
     s += arr("HALF", (mod - 1) // 2, n)    # (p-1)/2 : y > HALF <=> lexicographically largest
     s += arr("MOD_M2", mod - 2, n)         # exponent for Fermat inversion
     s += "};\n\n"
@@ -53,8 +108,10 @@ def field_struct(name, mod, n):
 
 
 def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_desc):
-    R = 1 << (32 * n)
+    R = 1 << (28 * n)
     m = lambda v: v * R % p
+    arr = arr28
+    limbs = limbs28
     s = "struct %sConsts {\n" % tag
     s += "    static constexpr int N = %d;\n" % n
     s += "    static constexpr bool TWIST_M = %s;\n" % ("true" if twist == "M" else "false")
@@ -82,8 +139,8 @@ def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_d
         for i in range(6):
             g = f2_pow(xi, i * (p ** k - 1) // 6, p)
             s += "        {{%s}, {%s}},\n" % (
-                ", ".join("0x%08xu" % w for w in limbs(m(g[0]), n)),
-                ", ".join("0x%08xu" % w for w in limbs(m(g[1]), n)))
+                ", ".join("0x%07xu" % w for w in limbs(m(g[0]), n)),
+                ", ".join("0x%07xu" % w for w in limbs(m(g[1]), n)))
         s += "      },\n"
     s += "    };\n"
     s += "};\n\n"
@@ -111,13 +168,13 @@ def main():
              8255268479661695615178834896135584953541182794935974658059743263102507888551)
 
     s = "// GENERATED by tools/gen_params.py -- do not edit.\n#pragma once\n#include <cstdint>\n\nnamespace bbs {\n\n"
-    s += field_struct("BlsFpParams", bls_p, 12)
+    s += field28_struct("BlsFpParams", bls_p, 14, 12, 2)
     s += field_struct("BlsFrParams", bls_r, 8)
-    s += field_struct("BnFpParams", bn_p, 8)
+    s += field28_struct("BnFpParams", bn_p, 10, 8, 3)
     s += field_struct("BnFrParams", bn_r, 8)
-    s += curve_struct("Bls", bls_p, bls_r, 12, 4, (1, 1), "M", bls_g1, bls_g2, bls_p1,
+    s += curve_struct("Bls", bls_p, bls_r, 14, 4, (1, 1), "M", bls_g1, bls_g2, bls_p1,
                       0xD201000000010000, True, "")
-    s += curve_struct("Bn", bn_p, bn_r, 8, 3, (9, 1), "D", (1, 2), bn_g2, bn_p1,
+    s += curve_struct("Bn", bn_p, bn_r, 10, 3, (9, 1), "D", (1, 2), bn_g2, bn_p1,
                       4965661367192848881, False, "")
     s += "}  // namespace bbs\n"
     with open(OUT, "w") as f:
