@@ -53,6 +53,7 @@ SIGNATURES = {
     "bbs_job_free": (None, [vp]),
     "bbs_job_run_timed": (ci, [vp, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
     "bbs_job_stage_name": (ctypes.c_char_p, [vp, ci]),
+    "bbs_jobs_run_timed": (ci, [ctypes.POINTER(vp), ci, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
     "bbs_hash_to_scalar_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, sz, c_u8p]),
     "bbs_g1_msm_batch": (ci, [vp, sz, c_u8p, sz, c_u8p, c_u8p, sz, c_u8p, c_i8p]),
     "bbs_pairing_product2_is_one_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
@@ -69,7 +70,8 @@ class LibraryMissing(RuntimeError):
 def load_library(path=None):
     """Load the C-ABI library.  ``path=None`` means the product library; it is an error if it has
     not been built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
-    path = os.path.abspath(path or PRODUCT_LIB)
+    # BBS_SIGN_AMD_LIB: development override (A/B builds of the same product library)
+    path = os.path.abspath(path or os.environ.get("BBS_SIGN_AMD_LIB") or PRODUCT_LIB)
     if path in _cache:
         return _cache[path]
     if not os.path.exists(path):

@@ -150,6 +150,58 @@ int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms,
     return BBS_OK;
 }
 
+// Throughput run over several device-resident jobs (batches in flight): step k runs on job
+// k % njobs, every job on its own stream pair, HIP events around every stage.  Outputs: wall time
+// from the first to the last event (ms), and per stage index the SUM of the stage durations over
+// all steps (stage lists of all jobs must be identical).
+int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, float* kernel_ms, int cap, int* n_stages) {
+    if (!jobs || njobs < 1 || steps < 1) return BBS_E_ARG;
+    for (int j = 0; j < njobs; j++) if (!jobs[j]) return BBS_E_ARG;
+    const int ns = (int)jobs[0]->stages.size();
+    for (int j = 1; j < njobs; j++) if ((int)jobs[j]->stages.size() != ns) return BBS_E_ARG;
+    if (n_stages) *n_stages = ns;
+    if (jobs[0]->use()) return BBS_E_HIP;
+    const size_t per_step = 1 + 2 * (size_t)ns;
+    rt::EventList ev((size_t)steps * per_step);
+    for (int j = 0; j < njobs; j++) if (rt::sync(jobs[j]->stream())) return BBS_E_HIP;
+    for (int k = 0; k < steps; k++) {
+        bbs_job* job = jobs[k % njobs];
+        if (job->reset()) return BBS_E_HIP;
+        if (ev.record(job->stream())) return BBS_E_HIP;
+        bool forked = false;
+        for (int s = 0; s < ns; s++) {
+            auto& st = job->stages[s];
+            if (st.aux && !forked) { if (job->fork_aux()) return BBS_E_HIP; forked = true; }
+            if (st.join && forked) { if (job->join_aux()) return BBS_E_HIP; }
+            rt::Stream& sm = st.aux ? job->stream_aux() : job->stream();
+            if (ev.record(sm)) return BBS_E_HIP;
+            if (st.launch()) return BBS_E_HIP;
+            if (ev.record(sm)) return BBS_E_HIP;
+        }
+    }
+    for (int j = 0; j < njobs; j++) {
+        if (rt::sync(jobs[j]->stream())) return BBS_E_HIP;
+        if (rt::sync(jobs[j]->stream_aux())) return BBS_E_HIP;
+    }
+    if (total_ms) {
+        // the steps end in different orders on different streams: take the latest last-stage stop
+        float best = 0.f;
+        for (int k = 0; k < steps; k++) {
+            const float m = ev.ms(0, (size_t)k * per_step + per_step - 1);
+            if (m > best) best = m;
+        }
+        *total_ms = best;
+    }
+    if (kernel_ms) {
+        for (int s = 0; s < ns && s < cap; s++) {
+            float acc = 0.f;
+            for (int k = 0; k < steps; k++) acc += ev.ms((size_t)k * per_step + 1 + 2 * s, (size_t)k * per_step + 2 + 2 * s);
+            kernel_ms[s] = acc;
+        }
+    }
+    return BBS_OK;
+}
+
 static int run_fetch_free(bbs_job* job, int8_t* status) {
     int rc = job->run();
     if (!rc && status) rc = job->fetch_status(status);

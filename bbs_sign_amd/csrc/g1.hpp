@@ -53,7 +53,7 @@ BBS_HD bool g1a_on_curve(const G1Aff<C>& p) {
 
 // dbl-2009-l (a = 0): 2M + 5S
 template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
+BBS_HD G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
     // identity (Z=0) maps to Z3 = 2*Y*0 = 0 : stays the identity.  Y = 0 cannot happen on
     // these curves (no point of order 2: x^3 = -b has no root in Fp for b = 4 / b = 3).
     Fp<C> A = fe_sqr<FP>(p.x);
@@ -73,7 +73,7 @@ BBS_HD_NOINLINE G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
 
 // madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases resolved
 template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
+BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
     if (g1a_is_inf<C>(q)) return p;
     if (g1j_is_inf<C>(p)) return {q.x, q.y, fe_one<FP>()};
     Fp<C> Z1Z1 = fe_sqr<FP>(p.z);

@@ -157,9 +157,33 @@ __device__ __forceinline__ Fp2<C> d_scatter(const Lane6& L, const Fp12<C>& f) {
     return r;
 }
 
+// 1/f = conj6(f) * N^-1 with N = f * conj6(f) in Fp6 = Fp2[v]/(v^3 - xi), v = w^2: N has only the even
+// coefficients (lanes 0, 2, 4).  Every lane fetches (n0, n1, n2), inverts the cubic extension
+// element redundantly (one Fp inversion, the only long chain), then multiplies its rotated
+// coefficients of conj6(f) by the three coefficients of N^-1.  No lane ever holds a whole Fp12.
 template <class C>
 __device__ __attribute__((noinline)) Fp2<C> d_inv(const Lane6& L, const Fp2<C>& g) {
-    return d_scatter<C>(L, f12_inv<C>(d_gather<C>(L, g)));
+    const Fp2<C> gc = d_conj<C>(L, g);
+    const Fp2<C> nn = d_mul<C>(L, g, gc);
+    const Fp2<C> n0 = d_coef<C>(L, nn, 0), n1 = d_coef<C>(L, nn, 2), n2 = d_coef<C>(L, nn, 4);
+    Fp2<C> t0 = f2_sub<C>(f2_sqr<C>(n0), f2_mul_xi<C>(f2_mul<C>(n1, n2)));
+    Fp2<C> t1 = f2_sub<C>(f2_mul_xi<C>(f2_sqr<C>(n2)), f2_mul<C>(n0, n1));
+    Fp2<C> t2 = f2_sub<C>(f2_sqr<C>(n1), f2_mul<C>(n0, n2));
+    Fp2<C> d = f2_add<C>(f2_mul<C>(n0, t0), f2_mul_xi<C>(f2_add<C>(f2_mul<C>(n2, t1), f2_mul<C>(n1, t2))));
+    const Fp2<C> di = f2_inv<C>(d);
+    t0 = f2_mul<C>(t0, di);      // N^-1 = t0 + t1 v + t2 v^2 = t0 + t1 w^2 + t2 w^4
+    t1 = f2_mul<C>(t1, di);
+    t2 = f2_mul<C>(t2, di);
+    // (gc * N^-1)_k = gc_k t0 + xi^[k<2] gc_{k-2} t1 + xi^[k<4] gc_{k-4} t2
+    const int s1 = L.m - 2, s2 = L.m - 4;
+    Fp2<C> a = d_coef<C>(L, gc, s1 < 0 ? s1 + GRP : s1);
+    Fp2<C> b = d_coef<C>(L, gc, s2 < 0 ? s2 + GRP : s2);
+    Fp2<C> r = f2_mul<C>(gc, t0);
+    Fp2<C> u = f2_mul<C>(a, t1);
+    u = f2_sel<C>(s1 < 0, f2_mul_xi<C>(u), u);
+    Fp2<C> w = f2_mul<C>(b, t2);
+    w = f2_sel<C>(s2 < 0, f2_mul_xi<C>(w), w);
+    return f2_add<C>(f2_add<C>(r, u), w);
 }
 
 template <class C>

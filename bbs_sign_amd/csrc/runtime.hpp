@@ -15,6 +15,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bbs_sign_amd.h"
@@ -87,8 +88,13 @@ inline void event_destroy(Event& e) { (void)hipEventDestroy(e); }
 inline int event_record(Event& e, Stream& s) { return hipEventRecord(e, s) == hipSuccess ? 0 : -1; }
 inline int stream_wait(Stream& s, Event& e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
 
+// stages may declare `static constexpr int WAVES_PER_EU = k;` to cap their register allocation at
+// 512 / k VGPRs so that k wavefronts fit on one SIMD
+template <class F, class = void> struct waves_of { static constexpr int v = 1; };
+template <class F> struct waves_of<F, std::void_t<decltype(F::WAVES_PER_EU)>> { static constexpr int v = F::WAVES_PER_EU; };
+
 template <class F, class A>
-__global__ void __launch_bounds__(64) k_stage(A a, size_t nthreads) {
+__global__ void __launch_bounds__(64, waves_of<F>::v) k_stage(A a, size_t nthreads) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t < nthreads) F::run(a, t);
 }

@@ -31,6 +31,9 @@ namespace bbs {
 
 constexpr int NFIX = 8;          // fixed-base chunks per MSM (one lane each)
 constexpr int MAX_DST = 255;
+#ifndef BBS_PAIR_WAVES
+#define BBS_PAIR_WAVES 4
+#endif
 
 // ---- context constants resident in HBM ------------------------------------------------------
 struct HashCtx {
@@ -963,6 +966,7 @@ struct PairPrep {
 // =============================================================================================
 template <class C>
 struct PairDist {
+    static constexpr int WAVES_PER_EU = BBS_PAIR_WAVES;      // 128 VGPRs: four wavefronts per SIMD hide each other's waits
     static __device__ void run(const PairArgs<C>& a, size_t t) {
         const int lane = (int)(t & 63);
         const int grp = lane / GRP;

@@ -45,7 +45,7 @@ template <class C> BBS_HD Fp2<C> f2_dbl(const Fp2<C>& a) { return {fe_dbl<FP>(a.
 template <class C> BBS_HD Fp2<C> f2_conj(const Fp2<C>& a) { return {a.c0, fe_neg<FP>(a.c1)}; }
 
 template <class C>
-BBS_HD_NOINLINE Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
+BBS_HD Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
     // Karatsuba: 3 Fp multiplications
     Fp<C> t0 = fe_mul<FP>(a.c0, b.c0);
     Fp<C> t1 = fe_mul<FP>(a.c1, b.c1);
@@ -54,7 +54,7 @@ BBS_HD_NOINLINE Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
 }
 
 template <class C>
-BBS_HD_NOINLINE Fp2<C> f2_sqr(const Fp2<C>& a) {
+BBS_HD Fp2<C> f2_sqr(const Fp2<C>& a) {
     // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp multiplications
     Fp<C> t = fe_mul<FP>(fe_add_nr<FP>(a.c0, a.c1), fe_sub<FP>(a.c0, a.c1));
     Fp<C> m = fe_mul<FP>(a.c0, a.c1);

@@ -444,6 +444,19 @@ class Job:
         names = [self.eng.lib.bbs_job_stage_name(self.h, k).decode() for k in range(ns.value)]
         return tot.value, ({names[k]: ks[k] for k in range(ns.value)} if per_stage else {})
 
+    @staticmethod
+    def run_many_timed(jobs, steps: int):
+        """Step k runs on jobs[k % len(jobs)], all batches in flight -> (total_ms, {stage: summed ms})."""
+        eng = jobs[0].eng
+        arr = (ctypes.c_void_p * len(jobs))(*[j.h for j in jobs])
+        tot = ctypes.c_float(0)
+        ks = (ctypes.c_float * 16)()
+        ns = ctypes.c_int(0)
+        Engine._chk(eng.lib.bbs_jobs_run_timed(arr, len(jobs), steps, ctypes.byref(tot), ks, 16, ctypes.byref(ns)),
+                    "bbs_jobs_run_timed")
+        names = [eng.lib.bbs_job_stage_name(jobs[0].h, k).decode() for k in range(ns.value)]
+        return tot.value, {names[k]: ks[k] for k in range(ns.value)}
+
     def free(self):
         if self.h:
             self.eng.lib.bbs_job_free(self.h)

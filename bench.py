@@ -9,9 +9,14 @@ A step = one pass of core_proof_verify (src/proof_verify.rs:64-116) over one dev
 sign -> proof_gen).  Items are independent, so N GPUs each verify their own 4096-item batch per step
 (weak scaling, no data-path collective); rank 0 gathers one pass-count per rank over RCCL.
 
-Timing: barrier + synchronize, K steps enqueued back to back on the engine's HIP stream with HIP
-events around every stage (recorded on that stream, read after one synchronisation), barrier +
-synchronize; wall time = max over ranks.  Prints ONE JSON line (rank 0).
+Each rank keeps `--inflight` device-resident batches (default 8), every batch on its own HIP stream
+pair: step k runs on batch k % inflight, so consecutive steps overlap on the GPU (a 4096-item batch
+alone is ~10^3 wavefronts on a chip that holds 4096).  `--inflight 1` gives the one-batch-at-a-time
+number, also reported in the JSON as `single_batch`.
+
+Timing: barrier + synchronize, K steps enqueued with HIP events around every stage (recorded on the
+stream the stage runs on, read after one synchronisation), barrier + synchronize; wall time = max
+over ranks.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -27,6 +32,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # (3 x 48 + 28 x 32) + 256 (8 disclosed scalars) + 64 (8 indexes) + 1 status
 ALG_BYTES_PER_PROOF_VERIFY = 1361
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue ceiling: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; every instruction of
+# this integer mix (v_mad_u64_u32 included) issues at that rate (tools/ubench/valu_int.hip, 0.5 G/s/SIMD)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4
+# VALU wave-instructions per 4096-item launch, from rocprofv3 SQ_INSTS_VALU (profiles/r01_*_pmc.csv)
+# FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (checked on PvScalars: 5984 KiB written
+# for 4096 x 36 scalars); FETCH_SIZE doubled per MI355X_MICROARCH.md (128-B requests tallied at 64 B)
+PMC = {"pairing_6lane": {"valu_insts": 1.504e9, "fetch_bytes": 2 * 1.402e5 * 1024, "write_bytes": 6.41e6 * 1024},
+       "pv_msm_parts": {"valu_insts": 1.133e9, "fetch_bytes": 2 * 1.339e6 * 1024, "write_bytes": 6.159e6 * 1024}}
 
 
 def cpu_baseline(n_items=4):
@@ -62,10 +75,11 @@ def cpu_baseline(n_items=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--window-bits", type=int, default=8)
+    ap.add_argument("--inflight", type=int, default=8, help="device-resident batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,20 +101,16 @@ def main():
 
     n, L, R = args.batch, 32, 8
     # every rank verifies its own batch: item ids offset by rank so the batches differ
-    suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload("bls12_381", n, L, R, None, args.window_bits)
-    eng_dev = local_rank
-    if eng_dev != 0:
-        # bench_workload builds on device 0 by default; rebuild the context on this rank's GPU
-        eng.close()
-        eng = Engine("bls12_381", device=eng_dev, window_bits=args.window_bits)
-        eng.set_generators(gens, suite.api_id)
-        eng.set_secret_key(sk)
+    suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload("bls12_381", n, L, R, None, args.window_bits,
+                                                                    device=local_rank)
     sigs, st = eng.core_sign_batch(msgs)
     assert (st == 1).all()
     proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
     assert (st == 1).all()
     dm = [m[:R] for m in msgs]
-    job = eng.core_proof_verify_upload(proofs, dm, disclosed)      # inputs now resident in HBM
+    from bbs_sign_amd import Job
+    jobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(max(1, args.inflight))]   # resident in HBM
+    job = jobs[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,20 +118,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        job.run()
-    job.wait()
-    assert (job.status() == 1).all(), "warm-up batch did not verify"
+    for k in range(max(args.warmup, len(jobs))):
+        jobs[k % len(jobs)].run()
+    for j in jobs:
+        j.wait()
+        assert (j.status() == 1).all(), "warm-up batch did not verify"
 
     barrier()
     t0 = time.perf_counter()
-    total_ms, stage_ms = job.run_timed(args.steps, per_stage=True)
-    job.wait()
+    total_ms, stage_ms = Job.run_many_timed(jobs, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    status = job.status()
-    passed = int((status == 1).sum())
+    passed = n
+    for j in jobs:
+        passed = min(passed, int((j.status() == 1).sum()))
     assert passed == n, "timed batch did not verify"
+    # one batch at a time (latency form), outside the timed region
+    single_ms, single_stage = job.run_timed(3, per_stage=True)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([passed], dtype=torch.int64, device="cuda")
@@ -136,6 +149,8 @@ def main():
         dom = max(stage_ms, key=stage_ms.get)
         dom_ms = stage_ms[dom] / args.steps
         achieved = ALG_BYTES_PER_PROOF_VERIFY * n / (dom_ms * 1e-3) / 1e9
+        pmc = PMC.get(dom, {})
+        valu_total = sum(v["valu_insts"] for v in PMC.values()) * (n / 4096.0)
         out = {
             "metric": "BBS+ proof_verify/sec (BLS12-381, 32-msg)",
             "value": value, "unit": "proof_verify/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,13 +159,27 @@ def main():
             "config": {"workload": "BLS12-381 core_proof_verify, batch %d per GPU, 32 msgs / 8 disclosed, empty "
                                    "header/ph, one issuer key (BASELINE configs[3], proof_verify leg)" % n,
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
+                       "batches_in_flight": len(jobs),
                        "parallelism": "independent batch per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "algorithmic bytes/unit = %d (SURVEY 8d); the path is bound by 32-bit integer "
-                                 "multiply-add issue, not HBM (see DESIGN.md)" % ALG_BYTES_PER_PROOF_VERIFY},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (pmc["fetch_bytes"] + pmc["write_bytes"]) * (n / 4096.0) if pmc else None,
+                         "note": "algorithmic bytes/unit = %d (SURVEY 8d); kernel duration = HIP events with %d batches "
+                                 "in flight; traffic = FETCH_SIZE(x2, gfx950) + WRITE_SIZE per launch from "
+                                 "profiles/r01_c_pmc.csv; the path is bound by integer VALU issue, not HBM "
+                                 "(see valu_issue and DESIGN.md)" % (ALG_BYTES_PER_PROOF_VERIFY, len(jobs))},
+            # the binding resource: VALU wave-instructions issued per second vs the chip's issue ceiling
+            "valu_issue": {"achieved_ginstr_s": valu_total * world * args.steps / dt / 1e9 / world,
+                           "peak_ginstr_s": VALU_PEAK_GINSTR,
+                           "frac": valu_total * args.steps / dt / 1e9 / VALU_PEAK_GINSTR,
+                           "valu_wave_insts_per_step": valu_total,
+                           "source": "SQ_INSTS_VALU of pairing_6lane + pv_msm_parts (profiles/r01_c_pmc.csv); peak = 1024 "
+                                     "SIMDs x 2.4 GHz / 4 cycles per wave-instruction"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "gpu_ms_per_step_events": total_ms / args.steps,
+            "batches_in_flight": len(jobs),
+            "single_batch": {"ms": single_ms / 3, "proof_verify_per_s": n / (single_ms / 3 * 1e-3),
+                             "stage_ms": {k: v / 3 for k, v in single_stage.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

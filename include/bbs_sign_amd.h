@@ -173,6 +173,11 @@ void bbs_job_free(bbs_job* job);
 int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms, int kernel_cap,
                       int* n_stages_out);
 const char* bbs_job_stage_name(const bbs_job* job, int stage);
+/* Throughput form: `njobs` device-resident batches in flight, step k runs on jobs[k % njobs] (every
+ * job owns a HIP stream pair, so independent batches overlap on the GPU).  total_ms = first event to
+ * the latest last-stage event; kernel_ms[s] = sum over all steps of stage s's own duration. */
+int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, float* kernel_ms,
+                       int kernel_cap, int* n_stages_out);
 
 /* ------------------------------------------------------------------------------------------
  * Unit-parity primitives (hash_to_scalar, G1 multi-scalar multiplication, pairing product).

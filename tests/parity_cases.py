@@ -42,10 +42,10 @@ def _pt2(q):
     return None if q is None else ((_i(q[0][0]), _i(q[0][1])), (_i(q[1][0]), _i(q[1][1])))
 
 
-def make_engine(curve, gens, api_id, lib_path=None, sk=None, pk="unset", window_bits=None):
+def make_engine(curve, gens, api_id, lib_path=None, sk=None, pk="unset", window_bits=None, device=0):
     if window_bits is None:
         window_bits = 4 if lib_path else 8
-    eng = Engine(curve, lib_path=lib_path, window_bits=window_bits)
+    eng = Engine(curve, device=device, lib_path=lib_path, window_bits=window_bits)
     eng.set_generators(gens, api_id)
     if sk is not None:
         eng.set_secret_key(sk)
@@ -357,7 +357,7 @@ def check_primitives(curve, lib_path=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0):
+def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0, device=0):
     """SURVEY 8d synthetic workload: one issuer key (IKM [1u8;32]), item b has L 32-byte messages
     derived from (b, j), empty header / ph, disclosed 0..R, proof_gen scalars from the seeded
     expander.  Signatures and proofs are produced by the engine itself (checked by the caller)."""
@@ -365,7 +365,7 @@ def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0)
     api_id = suite.api_id
     gens = gens_for(suite, L + 1)
     sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
-    eng = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits, device=device)
     raw = [expand_message(b"bbs-bench-msg" + i2osp(b, 8) + i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32)
            for b in range(n) for j in range(L)]
     flat = eng.hash_to_scalar_batch(raw, api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
