@@ -7,3 +7,4 @@ interface; importing it does not load the library, using it does, and there is n
 from .engine import (BLS12_381, BN254, BbsError, BbsRuntimeError, Engine, Job, Proof, Signature,  # noqa: F401
                      STATUS_NAMES)
 from ._lib import PRODUCT_LIB, LibraryMissing, load_library  # noqa: F401
+from . import api  # noqa: F401,E402

@@ -1,5 +1,6 @@
 // C ABI entry points (include/bbs_sign_amd.h) dispatching on the curve.
 #include "ops_decl.hpp"
+#include "host_h2c.hpp"
 
 // =============================================================================================
 // C ABI
@@ -259,6 +260,54 @@ int bbs_hash_to_scalar_batch(bbs_ctx* ctx, size_t n, const uint8_t* msgs, const 
 int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t* vp, const uint8_t* vs, size_t nv, uint8_t* out, int8_t* status) {
     if (!ctx) return BBS_E_ARG;
     return DISPATCH(ctx, msm_batch<BlsCurve>(AS_BLS(ctx), n, fs, nf, vp, vs, nv, out, status), msm_batch<BnCurve>(AS_BN(ctx), n, fs, nf, vp, vs, nv, out, status));
+}
+
+// ---- host-side setup helpers (once per ciphersuite / key; no GPU involved) ---------------------
+int bbs_create_generators(int curve, size_t count, const uint8_t* api_id, size_t api_id_len, uint8_t* out_affine) {
+    if ((api_id_len && !api_id) || (count && !out_affine)) return BBS_E_ARG;
+    if (curve != BBS_CURVE_BLS12_381) return BBS_E_UNSUPPORTED;      // BN254 SvdW (bn254_hash2curve) not restated
+    std::vector<G1Aff<BlsCurve>> g;
+    if (create_generators_bls(count, api_id, api_id_len, g)) return BBS_ST_PANIC_DST_TOO_LONG;
+    for (size_t k = 0; k < count; k++) {
+        if (g1a_is_inf<BlsCurve>(g[k])) { std::memset(out_affine + k * 96, 0, 96); continue; }
+        fe_to_le_bytes<BlsFpParams>(g[k].x, out_affine + k * 96);
+        fe_to_le_bytes<BlsFpParams>(g[k].y, out_affine + k * 96 + 48);
+    }
+    return BBS_OK;
+}
+
+int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out_affine) {
+    if ((msg_len && !msg) || (dst_len && !dst) || !out_affine) return BBS_E_ARG;
+    if (curve != BBS_CURVE_BLS12_381) return BBS_E_UNSUPPORTED;
+    bool ok = true;
+    G1Aff<BlsCurve> p = h2c::hash_to_g1(msg, msg_len, dst, dst_len, ok);
+    if (!ok) return BBS_ST_PANIC_DST_TOO_LONG;
+    if (g1a_is_inf<BlsCurve>(p)) { std::memset(out_affine, 0, 96); return BBS_OK; }
+    fe_to_le_bytes<BlsFpParams>(p.x, out_affine);
+    fe_to_le_bytes<BlsFpParams>(p.y, out_affine + 48);
+    return BBS_OK;
+}
+
+// SecretKey::key_gen (src/key_gen.rs:46-81)
+int bbs_key_gen(int curve, const uint8_t* key_material, size_t km_len, const uint8_t* key_info, size_t ki_len,
+                const uint8_t* key_dst, size_t dst_len, uint8_t* sk32_out) {
+    if (!sk32_out || (km_len && !key_material) || (ki_len && !key_info) || (dst_len && !key_dst)) return BBS_E_ARG;
+    if (curve != BBS_CURVE_BLS12_381 && curve != BBS_CURVE_BN254) return BBS_E_ARG;
+    if (km_len < 32) return BBS_ST_INVALID_KEY_MATERIAL_LENGTH;
+    if (ki_len > 65535) return BBS_ST_INVALID_KEY_INFO_LENGTH;
+    std::vector<uint8_t> in(key_material, key_material + km_len);
+    in.push_back((uint8_t)(ki_len >> 8));
+    in.push_back((uint8_t)(ki_len & 0xff));
+    in.insert(in.end(), key_info, key_info + ki_len);
+    uint32_t w[8];
+    const bool ok = curve == BBS_CURVE_BLS12_381 ? hash_to_scalar_host<BlsCurve>(in.data(), in.size(), key_dst, dst_len, w)
+                                                 : hash_to_scalar_host<BnCurve>(in.data(), in.size(), key_dst, dst_len, w);
+    if (!ok) return BBS_ST_PANIC_DST_TOO_LONG;
+    uint32_t any = 0;
+    for (int i = 0; i < 8; i++) any |= w[i];
+    if (!any) return BBS_ST_INVALID_SECRET_KEY;
+    for (int i = 0; i < 8; i++) put_le32(sk32_out + 4 * i, w[i]);
+    return BBS_OK;
 }
 
 int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single, uint8_t* out_dist) {

@@ -45,6 +45,10 @@ extern "C" {
 #define BBS_ST_INVALID_RANDOM_SCALARS_AND_UNDISCLOSED_INDICES_LENGTH (-4)
 #define BBS_ST_INVALID_UNDISCLOSED_INDICES_LENGTH (-5)
 #define BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH (-6)
+/* KeyGenError (src/key_gen.rs:34-42) */
+#define BBS_ST_INVALID_KEY_MATERIAL_LENGTH (-7)
+#define BBS_ST_INVALID_KEY_INFO_LENGTH (-8)
+#define BBS_ST_INVALID_SECRET_KEY (-9)
 /* reference panics */
 #define BBS_ST_PANIC_SK_PLUS_E_ZERO (-20)     /* src/sign.rs:129 unwrap on inverse of 0 */
 #define BBS_ST_PANIC_R2_ZERO (-21)            /* src/proof_gen.rs:346 unwrap on inverse of 0 */
@@ -62,6 +66,7 @@ extern "C" {
 #define BBS_E_PUBLIC_KEY (-103)  /* public key not on the twist or not of order r */
 #define BBS_E_NO_DEVICE (-104)
 #define BBS_E_NOMEM (-105)
+#define BBS_E_UNSUPPORTED (-106) /* BN254 hash-to-curve (SvdW, crate bn254_hash2curve) is not restated */
 
 typedef struct bbs_ctx bbs_ctx;
 typedef struct bbs_job bbs_job;
@@ -193,6 +198,21 @@ int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fixed_scalars, size_
 /* status[i] = ( e(Pa[i], pk) * e(Pb[i], BP2) == 1 ) */
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_affine,
                                       const uint8_t* pb_affine, int8_t* status);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side setup helpers: once per ciphersuite / key, no GPU involved.
+ * ------------------------------------------------------------------------------------------ */
+/* create_generators (src/utils/interface_utilities.rs:47-73) with the reference's BLS12-381
+ * hash-to-curve backend (:30-44); out = count affine G1 points.  The reference recomputes this on
+ * every sign / verify / proof_gen / proof_verify call; callers cache it per (api_id, count). */
+int bbs_create_generators(int curve, size_t count, const uint8_t* api_id, size_t api_id_len,
+                          uint8_t* out_affine);
+/* HashToG1::hash_to_g1 (interface_utilities.rs:17-44), BLS12-381. */
+int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len,
+                   uint8_t* out_affine);
+/* SecretKey::key_gen (src/key_gen.rs:46-81): returns 0 or the KeyGenError code. */
+int bbs_key_gen(int curve, const uint8_t* key_material, size_t key_material_len, const uint8_t* key_info,
+                size_t key_info_len, const uint8_t* key_dst, size_t key_dst_len, uint8_t* sk32_out);
 
 /* GPU self-test: one Fp12 operation (12 Fp values a, b, canonical LE, tower order) computed by the
  * one-lane code and by the six-lane wavefront-cooperative code; the caller compares the outputs.

@@ -147,6 +147,114 @@ def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_d
     return s
 
 
+def sswu_struct(p, r, n):
+    """BLS12-381 G1 simplified-SWU constants (RFC 9380 8.8.1).  The 11-isogeny E' -> E is derived with
+    Velu's formulas from the rational subgroup of order 11 of E' (kernel x-coordinates xQ with the
+    classical vQ, uQ), followed by the isomorphism (X, Y) -> (X s^-2, Y s^-3) onto y^2 = x^3 + 4 with
+    s the smallest sixth root of B''/4 -- the choice the reference's generator vectors pin
+    (src/tests/test_vector.rs:123-136)."""
+    A = 0x144698A3B8E9433D693A02C96D4982B0EA985383EE66A8D8E8981AEFD881AC98936F8DA0E0F97F5CF428082D584C1D
+    B = 0x12E2908D11688030018B12E8753EEE3B2016C1F0F24F4070A0B9C14FCEF35EF55A23215A316CEAA5D1CC48E98E172BE0
+    cof = 0x396C8C005555E1568C00AAAB0000AAAB
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        x1, y1 = P
+        x2, y2 = Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = (3 * x1 * x1 + A) * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return (x3, (lam * (x1 - x3) - y1) % p)
+
+    def mul(P, k):
+        R = None
+        for bit in bin(k)[2:]:
+            R = add(R, R)
+            if bit == "1":
+                R = add(R, P)
+        return R
+
+    n_pts = cof * r
+    x = 0
+    K = None
+    while K is None:
+        x += 1
+        y2 = (x * x * x + A * x + B) % p
+        y = pow(y2, (p + 1) // 4, p)
+        if y * y % p != y2:
+            continue
+        assert mul((x, y), n_pts) is None
+        K = mul((x, y), n_pts // 11)
+    ker = []
+    Q = K
+    v = w = 0
+    for _ in range(5):
+        xQ, yQ = Q
+        gx = (3 * xQ * xQ + A) % p
+        vQ = 2 * gx % p
+        uQ = 4 * yQ * yQ % p
+        ker.append((xQ, vQ, uQ))
+        v = (v + vQ) % p
+        w = (w + uQ + xQ * vQ) % p
+        Q = add(Q, K)
+    assert (A - 5 * v) % p == 0
+    t = (B - 7 * w) * pow(4, -1, p) % p
+    # all sixth roots of t: brute force over the 3-Sylow/2-Sylow structure via exponent search
+    roots = []
+    g = 2
+    while pow(g, (p - 1) // 2, p) == 1 or pow(g, (p - 1) // 3, p) == 1:
+        g += 1
+    z6 = pow(g, (p - 1) // 6, p)          # primitive sixth root of unity
+    # one sixth root: t^(e) with 6 e = 1 mod (p-1)/gcd..; p-1 = 2 * 3^k * m -> use Tonelli-like search
+    # simple approach: s = t^(inv6 mod m') corrected by a power of z; search small corrections
+    m = p - 1
+    e3 = 0
+    while m % 3 == 0:
+        m //= 3
+        e3 += 1
+    e2 = 0
+    while m % 2 == 0:
+        m //= 2
+        e2 += 1
+    inv6 = pow(6, -1, m)
+    s0 = pow(t, inv6, p)                   # s0^6 = t * (element of the 2,3-Sylow part)
+    gen = pow(g, m, p)                     # generates the subgroup of order 2^e2 * 3^e3
+    order = (2 ** e2) * (3 ** e3)
+    found = None
+    acc = 1
+    for k in range(order):
+        if pow(s0 * acc % p, 6, p) == t:
+            found = s0 * acc % p
+            break
+        acc = acc * gen % p
+    assert found is not None
+    roots = sorted({found * pow(z6, k, p) % p for k in range(6)})
+    assert len(roots) == 6 and all(pow(sx, 6, p) == t for sx in roots)
+    sroot = roots[0]
+    R = 1 << (28 * n)
+    mm = lambda val: val * R % p
+    s = "// BLS12-381 G1 hash-to-curve constants (simplified SWU on E', 11-isogeny by Velu, see tools/gen_params.py)\n"
+    s += "struct BlsSswu {\n"
+    s += arr28("A_M", mm(A), n) + arr28("B_M", mm(B), n) + arr28("Z_M", mm(11), n)
+    s += arr28("S2INV_M", mm(pow(sroot * sroot, -1, p)), n) + arr28("S3INV_M", mm(pow(sroot ** 3, -1, p)), n)
+    for name, idx in (("KX", 0), ("KV", 1), ("KU", 2)):
+        s += "    static constexpr uint32_t %s_M[5][%d] = {\n" % (name, n)
+        for k in ker:
+            s += "        {%s},\n" % ", ".join("0x%07xu" % wv for wv in limbs28(mm(k[idx]), n))
+        s += "    };\n"
+    s += arr("SQRT_EXP", (p + 1) // 4, 12)
+    s += "    static constexpr uint64_t H_EFF = 0xd201000000010001ull;\n"
+    s += "};\n\n"
+    return s
+
+
 def main():
     bls_p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
     bls_r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -176,6 +284,7 @@ def main():
                       0xD201000000010000, True, "")
     s += curve_struct("Bn", bn_p, bn_r, 10, 3, (9, 1), "D", (1, 2), bn_g2, bn_p1,
                       4965661367192848881, False, "")
+    s += sswu_struct(bls_p, bls_r, 14)
     s += "}  // namespace bbs\n"
     with open(OUT, "w") as f:
         f.write(s)
