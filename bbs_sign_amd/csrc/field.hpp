@@ -233,6 +233,116 @@ BBS_HD void sqr(uint32_t* r, const uint32_t* a) {
     r[N - 1] = (uint32_t)acc;
 }
 
+// Fused Fp2 product (r0 + r1 u) = (a0 + a1 u)(b0 + b1 u) / R, u^2 = -1, all operands normal.
+// Karatsuba on the UNREDUCED column sums + only two Montgomery reductions:
+//   t0 = a0 b0, t1 = a1 b1, ts = (a0+a1)(b0+b1)  column by column (3 MACs per limb pair)
+//   c1 = ts - t0 - t1   is non-negative in every column (it is sum a0_i b1_j + a1_i b0_j)
+//   c0 = t0 - t1 + K p^2 with K p^2 stored in lifted columns (WP2) so every column is non-negative
+// 5 N^2 multiply-accumulates instead of 6 N^2, no intermediate add/sub chains.  Column bounds and
+// the output bound (< 2p) are asserted numerically by tools/gen_params.py.
+template <class P>
+BBS_HD void f2mul(uint32_t* r0, uint32_t* r1, const uint32_t* a0, const uint32_t* a1, const uint32_t* b0, const uint32_t* b1) {
+    constexpr int N = P::N;
+    uint32_t sa[N], sb[N], m0[N], m1[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        BBS_BOUND_ASSERT(a0[i] <= MASK28 && a1[i] <= MASK28 && b0[i] <= MASK28 && b1[i] <= MASK28, "f2mul operands normal");
+        sa[i] = a0[i] + a1[i];
+        sb[i] = b0[i] + b1[i];
+    }
+    BBS_BOUND_ASSERT(a0[N - 1] <= P::MODB[N - 1] && a1[N - 1] <= P::MODB[N - 1] && b0[N - 1] <= P::MODB[N - 1] && b1[N - 1] <= P::MODB[N - 1], "f2mul operands < BOUND*p");
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int c = 0; c < 2 * N - 1; c++) {
+        uint64_t t0 = 0, t1 = 0, ts = 0;
+        const int lo = (c < N) ? 0 : c - N + 1;
+        const int hi = (c < N) ? c : N - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) {
+            t0 += (uint64_t)a0[i] * b0[c - i];
+            t1 += (uint64_t)a1[i] * b1[c - i];
+            ts += (uint64_t)sa[i] * sb[c - i];
+        }
+        acc0 += t0 + P::WP2[c] - t1;
+        acc1 += ts - t0 - t1;
+        if (c < N) {
+#pragma unroll
+            for (int i = 0; i < c; i++) {
+                acc0 += (uint64_t)m0[i] * P::MOD[c - i];
+                acc1 += (uint64_t)m1[i] * P::MOD[c - i];
+            }
+            m0[c] = ((uint32_t)acc0 * P::INV) & MASK28;
+            m1[c] = ((uint32_t)acc1 * P::INV) & MASK28;
+            acc0 += (uint64_t)m0[c] * P::MOD[0];
+            acc1 += (uint64_t)m1[c] * P::MOD[0];
+        } else {
+#pragma unroll
+            for (int i = c - N + 1; i < N; i++) {
+                acc0 += (uint64_t)m0[i] * P::MOD[c - i];
+                acc1 += (uint64_t)m1[i] * P::MOD[c - i];
+            }
+            r0[c - N] = (uint32_t)acc0 & MASK28;
+            r1[c - N] = (uint32_t)acc1 & MASK28;
+        }
+        acc0 >>= 28;
+        acc1 >>= 28;
+    }
+    r0[N - 1] = (uint32_t)acc0;
+    r1[N - 1] = (uint32_t)acc1;
+    BBS_BOUND_ASSERT(acc0 <= P::MOD2[N - 1] && acc1 <= P::MOD2[N - 1], "f2mul result < 2p");
+}
+
+// Fused Fp2 square: r0 = (a0 + a1)(a0 - a1), r1 = 2 a0 a1  (a0 - a1 taken as a0 + (BOUND p - a1),
+// limb-wise non-negative through the borrow-adjusted SUBM), two column products, two reductions.
+template <class P>
+BBS_HD void f2sqr(uint32_t* r0, uint32_t* r1, const uint32_t* a0, const uint32_t* a1) {
+    constexpr int N = P::N;
+    uint32_t sa[N], da[N], a2[N], m0[N], m1[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        BBS_BOUND_ASSERT(a0[i] <= MASK28 && a1[i] <= MASK28, "f2sqr operands normal");
+        sa[i] = a0[i] + a1[i];
+        da[i] = a0[i] + P::SUBM[i] - a1[i];
+        a2[i] = a0[i] << 1;
+    }
+    BBS_BOUND_ASSERT(a0[N - 1] <= P::MODB[N - 1] && a1[N - 1] <= P::MODB[N - 1], "f2sqr operands < BOUND*p");
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int c = 0; c < 2 * N - 1; c++) {
+        const int lo = (c < N) ? 0 : c - N + 1;
+        const int hi = (c < N) ? c : N - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) {
+            acc0 += (uint64_t)sa[i] * da[c - i];
+            acc1 += (uint64_t)a2[i] * a1[c - i];
+        }
+        if (c < N) {
+#pragma unroll
+            for (int i = 0; i < c; i++) {
+                acc0 += (uint64_t)m0[i] * P::MOD[c - i];
+                acc1 += (uint64_t)m1[i] * P::MOD[c - i];
+            }
+            m0[c] = ((uint32_t)acc0 * P::INV) & MASK28;
+            m1[c] = ((uint32_t)acc1 * P::INV) & MASK28;
+            acc0 += (uint64_t)m0[c] * P::MOD[0];
+            acc1 += (uint64_t)m1[c] * P::MOD[0];
+        } else {
+#pragma unroll
+            for (int i = c - N + 1; i < N; i++) {
+                acc0 += (uint64_t)m0[i] * P::MOD[c - i];
+                acc1 += (uint64_t)m1[i] * P::MOD[c - i];
+            }
+            r0[c - N] = (uint32_t)acc0 & MASK28;
+            r1[c - N] = (uint32_t)acc1 & MASK28;
+        }
+        acc0 >>= 28;
+        acc1 >>= 28;
+    }
+    r0[N - 1] = (uint32_t)acc0;
+    r1[N - 1] = (uint32_t)acc1;
+    BBS_BOUND_ASSERT(acc0 <= P::MOD2[N - 1] && acc1 <= P::MOD2[N - 1], "f2sqr result < 2p");
+}
+
 // One signed limb chain:  r = x - q*p  with limbs renormalised; x given limb-wise (may be out of
 // [0, 2^28) per limb), q < 8.  The caller guarantees 0 <= x - q*p < 2^(28 N).
 template <class P>
@@ -410,6 +520,22 @@ BBS_HD_NOINLINE Fe<P> fe_mul(const Fe<P> a, const Fe<P> b) {   // by value: oper
     else r32::mul<P>(r.v, a.v, b.v);
     return r;
 }
+// inlined forms (the caller keeps everything in VGPRs; use where the code-size cost is acceptable)
+template <class P>
+BBS_HD Fe<P> fe_mul_i(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    if constexpr (P::W == 28) r28::mul<P>(r.v, a.v, b.v);
+    else r32::mul<P>(r.v, a.v, b.v);
+    return r;
+}
+template <class P>
+BBS_HD Fe<P> fe_sqr_i(const Fe<P>& a) {
+    Fe<P> r;
+    if constexpr (P::W == 28) r28::sqr<P>(r.v, a.v);
+    else r32::mul<P>(r.v, a.v, a.v);
+    return r;
+}
+
 template <class P>
 BBS_HD_NOINLINE Fe<P> fe_sqr(const Fe<P> a) {
     Fe<P> r;

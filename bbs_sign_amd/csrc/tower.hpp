@@ -44,8 +44,30 @@ template <class C> BBS_HD Fp2<C> f2_neg(const Fp2<C>& a) { return {fe_neg<FP>(a.
 template <class C> BBS_HD Fp2<C> f2_dbl(const Fp2<C>& a) { return {fe_dbl<FP>(a.c0), fe_dbl<FP>(a.c1)}; }
 template <class C> BBS_HD Fp2<C> f2_conj(const Fp2<C>& a) { return {a.c0, fe_neg<FP>(a.c1)}; }
 
+#ifndef BBS_F2_FUSED_NOINLINE
+#define BBS_F2_FUSED_ATTR BBS_HD
+#else
+#define BBS_F2_FUSED_ATTR BBS_HD_NOINLINE
+#endif
+// the fused forms: own functions (register + stack arguments) or inlined into the caller
+template <class C>
+BBS_F2_FUSED_ATTR Fp2<C> f2_mul_fused(const Fp2<C> a, const Fp2<C> b) {
+    Fp2<C> r;
+    r28::f2mul<FP>(r.c0.v, r.c1.v, a.c0.v, a.c1.v, b.c0.v, b.c1.v);
+    return r;
+}
+template <class C>
+BBS_F2_FUSED_ATTR Fp2<C> f2_sqr_fused(const Fp2<C> a) {
+    Fp2<C> r;
+    r28::f2sqr<FP>(r.c0.v, r.c1.v, a.c0.v, a.c1.v);
+    return r;
+}
+
 template <class C>
 BBS_HD Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
+#ifndef BBS_NO_FUSED_F2
+    if constexpr (C::FpP::W == 28) return f2_mul_fused<C>(a, b);
+#endif
     // Karatsuba: 3 Fp multiplications
     Fp<C> t0 = fe_mul<FP>(a.c0, b.c0);
     Fp<C> t1 = fe_mul<FP>(a.c1, b.c1);
@@ -55,6 +77,9 @@ BBS_HD Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
 
 template <class C>
 BBS_HD Fp2<C> f2_sqr(const Fp2<C>& a) {
+#ifndef BBS_NO_FUSED_F2
+    if constexpr (C::FpP::W == 28) return f2_sqr_fused<C>(a);
+#endif
     // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp multiplications
     Fp<C> t = fe_mul<FP>(fe_add_nr<FP>(a.c0, a.c1), fe_sub<FP>(a.c0, a.c1));
     Fp<C> m = fe_mul<FP>(a.c0, a.c1);

@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--window-bits", type=int, default=8)
+    ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=8, help="device-resident batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

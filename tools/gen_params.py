@@ -64,6 +64,38 @@ def field28_struct(name, mod, n, nc, bound_mult):
     s += arr28("MOD", mod, n)
     s += arr28("MOD2", 2 * mod, n)
     s += arr28("MODB", bound_mult * mod, n)   # BOUND * p, added before a subtraction
+    # 16 p^2 in 2N-1 product columns.  Column k is lifted by L_k (a power of two >= twice the largest
+    # possible column sum of a product of two normal elements), borrowed from column k+1: added to
+    # t0 - t1 in the fused Fp2 multiplication so that every column stays non-negative.
+    ncol = 2 * n - 1
+    amax = [(1 << 28) - 1] * (n - 1) + [((bound_mult * mod) >> (28 * (n - 1))) + 1]
+    maxcol = [sum(amax[i] * amax[k - i] for i in range(n) if 0 <= k - i < n) for k in range(ncol)]
+    lift = []
+    for k in range(ncol - 1):
+        L = 1 << 28
+        while L < 2 * maxcol[k]:
+            L <<= 1
+        lift.append(L)
+    adj = None
+    for K in (16, 32, 64, 128):
+        w16 = K * mod * mod
+        cols = [(w16 >> (28 * k)) & 0xFFFFFFF for k in range(ncol - 1)] + [w16 >> (28 * (ncol - 1))]
+        cand = [cols[k] + (lift[k] if k < ncol - 1 else 0) - ((lift[k - 1] >> 28) if k > 0 else 0) for k in range(ncol)]
+        assert sum(v << (28 * k) for k, v in enumerate(cand)) == w16
+        ok = all(cand[k] >= maxcol[k] and cand[k] + maxcol[k] + n * (1 << 56) + (1 << 40) < (1 << 63) for k in range(ncol))
+        # value bound of the fused product: (t0 - t1 + K p^2) / R + p must stay below 2p
+        ok = ok and (4 * bound_mult * bound_mult + K) * mod * mod < (mod << (28 * n))
+        if ok:
+            adj = cand
+            break
+    assert adj is not None, name
+    s += "    // K p^2 (K = %d) in lifted product columns, see r28::f2mul\n" % K
+    s += "    static constexpr uint64_t WP2[%d] = {%s};\n" % (2 * n - 1, ", ".join("0x%016xull" % v for v in adj))
+    # BOUND * p with 2^28 borrowed into every lower limb: a - b + SUBM is non-negative limb by limb
+    mb = limbs28(bound_mult * mod, n)
+    sub = [mb[0] + (1 << 28)] + [mb[i] + (1 << 28) - 1 for i in range(1, n - 1)] + [mb[n - 1] - 1]
+    assert sum(a << (28 * i) for i, a in enumerate(sub)) == bound_mult * mod
+    s += raw_arr("SUBM", sub)
     s += arr28("ONE", R % mod, n)
     s += arr28("R2", R * R % mod, n)
     s += arr("MODC", mod, nc)                # canonical 32-bit limbs
