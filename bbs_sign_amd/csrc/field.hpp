@@ -396,6 +396,46 @@ BBS_HD Fe<P> sub(const Fe<P>& a, const Fe<P>& b) {
     return r;
 }
 
+// Single-chain linear combination  C0 x0 + C1 x1 + C2 x2 + C3 x3  (compile-time integer coefficients,
+// total weight sum|Ci| <= 8, operands normal): the terms are combined limb-wise, NEG * BOUND * p is
+// added to make the value positive (NEG = sum of the negative coefficients' magnitudes), the quotient
+// floor(v / p) is estimated from the top QK limbs with a reciprocal (never too large, at most one too
+// small), and ONE signed chain subtracts q p and renormalises.  Result: normal, value < p (1 + 2^-10).
+// Replaces chains of add / sub / dbl (each its own limb chain) in the point and tower formulas.
+template <class P, int C0, int C1, int C2, int C3>
+BBS_HD Fe<P> lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2, const Fe<P>& x3) {
+    constexpr int N = P::N;
+    constexpr int NEG = (C0 < 0 ? -C0 : 0) + (C1 < 0 ? -C1 : 0) + (C2 < 0 ? -C2 : 0) + (C3 < 0 ? -C3 : 0);
+    constexpr int POS = (C0 > 0 ? C0 : 0) + (C1 > 0 ? C1 : 0) + (C2 > 0 ? C2 : 0) + (C3 > 0 ? C3 : 0);
+    static_assert(NEG + POS <= 8, "fe_lin weight");
+    int32_t x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        BBS_BOUND_ASSERT(x0.v[i] <= MASK28 && x1.v[i] <= MASK28 && x2.v[i] <= MASK28 && x3.v[i] <= MASK28, "lin operands normal");
+        x[i] = C0 * (int32_t)x0.v[i] + C1 * (int32_t)x1.v[i] + C2 * (int32_t)x2.v[i] + C3 * (int32_t)x3.v[i] + NEG * (int32_t)P::MODB[i];
+    }
+    BBS_BOUND_ASSERT(x0.v[N - 1] <= P::MODB[N - 1] && x1.v[N - 1] <= P::MODB[N - 1] && x2.v[N - 1] <= P::MODB[N - 1] && x3.v[N - 1] <= P::MODB[N - 1], "lin operands < BOUND*p");
+    // top estimate, lowered by the largest possible borrow from the limbs below
+    int64_t T = x[N - 1];
+    if constexpr (P::QK == 2) T = T * (int64_t)(1 << 28) + x[N - 2];
+    T -= (NEG + POS + 1);
+    const uint32_t q = T > 0 ? (uint32_t)(((uint64_t)T * P::RECIP) >> P::RSHIFT) : 0u;
+    Fe<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int64_t tt = (int64_t)x[i] - (int64_t)q * (int64_t)P::MOD[i] + c;
+        if (i < N - 1) {
+            r.v[i] = (uint32_t)tt & MASK28;
+            c = tt >> 28;
+        } else {
+            r.v[i] = (uint32_t)tt;
+            BBS_BOUND_ASSERT(tt >= 0 && (uint64_t)tt <= P::MOD2[N - 1], "lin result in [0, 2p)");
+        }
+    }
+    return r;
+}
+
 // value == 0 mod p for a normal a  (a in {0, p, .., (BOUND-1) p})
 template <class P>
 BBS_HD bool is_zero(const Fe<P>& a) {
@@ -487,6 +527,26 @@ BBS_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
 }
 template <class P> BBS_HD Fe<P> fe_neg(const Fe<P>& a) { return fe_sub<P>(fe_zero<P>(), a); }
 template <class P> BBS_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a); }
+
+// C0 x0 + C1 x1 (+ C2 x2 + C3 x3) in one reduction chain (W = 28) or by repeated add / sub (W = 32)
+template <class P, int C0, int C1, int C2 = 0, int C3 = 0>
+BBS_HD Fe<P> fe_lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2, const Fe<P>& x3) {
+    if constexpr (P::W == 28) return r28::lin<P, C0, C1, C2, C3>(x0, x1, x2, x3);
+    else {
+        Fe<P> acc = fe_zero<P>();
+        auto term = [&](int cf, const Fe<P>& x) {
+            for (int k = 0; k < (cf < 0 ? -cf : cf); k++) acc = cf < 0 ? fe_sub<P>(acc, x) : fe_add<P>(acc, x);
+        };
+        term(C0, x0); term(C1, x1); term(C2, x2); term(C3, x3);
+        return acc;
+    }
+}
+template <class P, int C0, int C1, int C2 = 0>
+BBS_HD Fe<P> fe_lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2) { return fe_lin<P, C0, C1, C2, 0>(x0, x1, x2, x2); }
+template <class P, int C0, int C1>
+BBS_HD Fe<P> fe_lin(const Fe<P>& x0, const Fe<P>& x1) { return fe_lin<P, C0, C1, 0, 0>(x0, x1, x1, x1); }
+template <class P, int C0>
+BBS_HD Fe<P> fe_scale(const Fe<P>& x0) { return fe_lin<P, C0, 0, 0, 0>(x0, x0, x0, x0); }
 
 // lazy sum, limbs < 2^29: ONLY as an operand of fe_mul / fe_sqr (W = 28); plain add otherwise
 template <class P>

@@ -61,7 +61,7 @@ BBS_HD bool g1a_on_curve(const G1Aff<C>& p) {
     return fe_eq<FP>(lhs, rhs);
 }
 
-// dbl-2009-l (a = 0): 2M + 5S
+// dbl-2009-l (a = 0): 2M + 5S; the linear steps are single reduction chains (fe_lin)
 template <class C>
 BBS_HD G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
     // identity (Z=0) maps to Z3 = 2*Y*0 = 0 : stays the identity.  Y = 0 cannot happen on
@@ -69,15 +69,16 @@ BBS_HD G1Jac<C> g1j_dbl(const G1Jac<C>& p) {
     Fp<C> A = G1SQR<FP>(p.x);
     Fp<C> B = G1SQR<FP>(p.y);
     Fp<C> Cc = G1SQR<FP>(B);
-    Fp<C> t = fe_add<FP>(p.x, B);
-    Fp<C> D = fe_dbl<FP>(fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(t), A), Cc));
-    Fp<C> E = fe_add<FP>(fe_dbl<FP>(A), A);
+    Fp<C> t2 = G1SQR<FP>(fe_add_nr<FP>(p.x, B));              // (X + B)^2, lazy sum feeds the squarer
+    Fp<C> D = fe_lin<FP, 2, -2, -2>(t2, A, Cc);               // 2((X+B)^2 - A - C)
+    Fp<C> E = fe_scale<FP, 3>(A);
     Fp<C> F = G1SQR<FP>(E);
     G1Jac<C> r;
-    r.x = fe_sub<FP>(F, fe_dbl<FP>(D));
-    Fp<C> c8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(Cc)));
-    r.y = fe_sub<FP>(G1MUL<FP>(E, fe_sub<FP>(D, r.x)), c8);
-    r.z = fe_dbl<FP>(G1MUL<FP>(p.y, p.z));
+    r.x = fe_lin<FP, 1, -2>(F, D);
+    Fp<C> c4 = fe_scale<FP, 4>(Cc);
+    Fp<C> m = G1MUL<FP>(E, fe_sub<FP>(D, r.x));
+    r.y = fe_lin<FP, 1, -2>(m, c4);                            // E (D - X3) - 8 C
+    r.z = fe_scale<FP, 2>(G1MUL<FP>(p.y, p.z));
     return r;
 }
 
@@ -90,20 +91,20 @@ BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
     Fp<C> U2 = G1MUL<FP>(q.x, Z1Z1);
     Fp<C> S2 = G1MUL<FP>(G1MUL<FP>(q.y, p.z), Z1Z1);
     Fp<C> H = fe_sub<FP>(U2, p.x);
-    Fp<C> rr = fe_sub<FP>(S2, p.y);
+    Fp<C> rr = fe_lin<FP, 2, -2>(S2, p.y);                     // 2 (S2 - Y1); zero iff S2 == Y1 (p odd)
     if (fe_is_zero<FP>(H)) {
         if (fe_is_zero<FP>(rr)) return g1j_dbl<C>(p);
         return g1j_inf<C>();
     }
-    rr = fe_dbl<FP>(rr);
     Fp<C> HH = G1SQR<FP>(H);
-    Fp<C> I = fe_dbl<FP>(fe_dbl<FP>(HH));
+    Fp<C> I = fe_scale<FP, 4>(HH);
     Fp<C> J = G1MUL<FP>(H, I);
     Fp<C> V = G1MUL<FP>(p.x, I);
     G1Jac<C> r;
-    r.x = fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(rr), J), fe_dbl<FP>(V));
-    r.y = fe_sub<FP>(G1MUL<FP>(rr, fe_sub<FP>(V, r.x)), fe_dbl<FP>(G1MUL<FP>(p.y, J)));
-    r.z = fe_sub<FP>(fe_sub<FP>(G1SQR<FP>(fe_add<FP>(p.z, H)), Z1Z1), HH);
+    r.x = fe_lin<FP, 1, -1, -2>(G1SQR<FP>(rr), J, V);
+    Fp<C> m = G1MUL<FP>(rr, fe_sub<FP>(V, r.x));
+    r.y = fe_lin<FP, 1, -2>(m, G1MUL<FP>(p.y, J));
+    r.z = fe_lin<FP, 1, -1, -1>(G1SQR<FP>(fe_add_nr<FP>(p.z, H)), Z1Z1, HH);
     return r;
 }
 

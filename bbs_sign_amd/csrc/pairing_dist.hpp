@@ -113,16 +113,21 @@ __device__ __attribute__((noinline)) Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp
     Fp2<C> u = f2_sqr<C>(g);                                // x0^2 on the low lane, x1^2 on the high lane
     Fp2<C> v = f2_sqr<C>(f2_add<C>(g, px));                 // (x0 + x1)^2 on both
     Fp2<C> pu = d_coef<C>(L, u, partner);
-    Fp2<C> lo_val = f2_add<C>(u, f2_mul_xi<C>(pu));         // x0^2 + xi x1^2   (valid on the low lane)
-    Fp2<C> hi_val = f2_sub<C>(f2_sub<C>(v, u), pu);         // 2 x0 x1          (valid on the high lane)
+    // low lane: x0^2 + xi x1^2 ; high lane: 2 x0 x1 = (x0+x1)^2 - x0^2 - x1^2   (one chain per component)
+    Fp2<C> lo_val, hi_val;
+    if constexpr (C::K::XI_C0 == 1) {
+        lo_val = {fe_lin<typename C::FpP, 1, 1, -1>(u.c0, pu.c0, pu.c1), fe_lin<typename C::FpP, 1, 1, 1>(u.c1, pu.c0, pu.c1)};
+    } else {
+        lo_val = f2_add<C>(u, f2_mul_xi<C>(pu));
+    }
+    hi_val = f2_lin<C, 1, -1, -1>(v, u, pu);
     Fp2<C> sq = f2_sel<C>(hi, hi_val, lo_val);              // lane m<3: X2[0] of pair m ; m>=3: X2[1] of pair m-3
     // pull pattern: 0<-0, 3<-3, 1<-5, 4<-2, 2<-1, 5<-4
     const int src = (L.m == 0) ? 0 : (L.m == 3) ? 3 : (L.m == 1) ? 5 : (L.m == 4) ? 2 : (L.m == 2) ? 1 : 4;
     Fp2<C> t = d_coef<C>(L, sq, src);
     t = f2_sel<C>(L.m == 1, f2_mul_xi<C>(t), t);
-    Fp2<C> t3 = f2_add<C>(f2_dbl<C>(t), t);
-    Fp2<C> g2 = f2_dbl<C>(g);
-    return f2_sel<C>((L.m & 1) != 0, f2_add<C>(t3, g2), f2_sub<C>(t3, g2));
+    // odd lanes: 3 t + 2 g ; even lanes: 3 t - 2 g
+    return f2_sel<C>((L.m & 1) != 0, f2_lin<C, 3, 2>(t, g), f2_lin<C, 3, -2>(t, g));
 }
 
 template <class C, int K>

@@ -91,20 +91,27 @@ BBS_HD Fp2<C> f2_mul_fp(const Fp2<C>& a, const Fp<C>& s) {
     return {fe_mul<FP>(a.c0, s), fe_mul<FP>(a.c1, s)};
 }
 
-// a * xi, xi = XI_C0 + u
+// a * xi, xi = XI_C0 + u :  (c a0 - a1) + (c a1 + a0) u
 template <class C>
 BBS_HD Fp2<C> f2_mul_xi(const Fp2<C>& a) {
+    static_assert(C::K::XI_C0 == 9 || C::K::XI_C0 == 1, "xi");
     if constexpr (C::K::XI_C0 == 1) {
         return {fe_sub<FP>(a.c0, a.c1), fe_add<FP>(a.c0, a.c1)};
     } else {
-        static_assert(C::K::XI_C0 == 9 || C::K::XI_C0 == 1, "xi");
-        // 9a = 8a + a
-        Fp<C> a0_8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(a.c0)));
-        Fp<C> a1_8 = fe_dbl<FP>(fe_dbl<FP>(fe_dbl<FP>(a.c1)));
-        Fp<C> a0_9 = fe_add<FP>(a0_8, a.c0);
-        Fp<C> a1_9 = fe_add<FP>(a1_8, a.c1);
-        return {fe_sub<FP>(a0_9, a.c1), fe_add<FP>(a1_9, a.c0)};
+        // 9 a = 8 a + a : two chains per component (fe_lin weight limit is 8)
+        const Fp<C> e0 = fe_scale<FP, 8>(a.c0), e1 = fe_scale<FP, 8>(a.c1);
+        return {fe_lin<FP, 1, 1, -1>(e0, a.c0, a.c1), fe_lin<FP, 1, 1, 1>(e1, a.c1, a.c0)};
     }
+}
+
+// small linear combinations of Fp2 values, one reduction chain per component
+template <class C, int C0, int C1>
+BBS_HD Fp2<C> f2_lin(const Fp2<C>& x0, const Fp2<C>& x1) {
+    return {fe_lin<FP, C0, C1>(x0.c0, x1.c0), fe_lin<FP, C0, C1>(x0.c1, x1.c1)};
+}
+template <class C, int C0, int C1, int C2>
+BBS_HD Fp2<C> f2_lin(const Fp2<C>& x0, const Fp2<C>& x1, const Fp2<C>& x2) {
+    return {fe_lin<FP, C0, C1, C2>(x0.c0, x1.c0, x2.c0), fe_lin<FP, C0, C1, C2>(x0.c1, x1.c1, x2.c1)};
 }
 
 template <class C>

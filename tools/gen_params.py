@@ -96,6 +96,16 @@ def field28_struct(name, mod, n, nc, bound_mult):
     sub = [mb[0] + (1 << 28)] + [mb[i] + (1 << 28) - 1 for i in range(1, n - 1)] + [mb[n - 1] - 1]
     assert sum(a << (28 * i) for i, a in enumerate(sub)) == bound_mult * mod
     s += raw_arr("SUBM", sub)
+    # quotient estimate for fe_lin: q = (T * RECIP) >> RSHIFT with T = the top QK limbs of the value
+    qk = 1 if (mod >> (28 * (n - 1))) >= (1 << 12) else 2
+    unit_bits = 28 * (n - qk)
+    pt = mod / float(1 << unit_bits)
+    rshift = 40 if qk == 1 else 58
+    recip = (1 << (rshift + unit_bits)) // mod
+    assert recip < (1 << 32) and pt > 1000, (name, recip, pt)
+    s += "    static constexpr int QK = %d;               // limbs used for the quotient estimate of fe_lin\n" % qk
+    s += "    static constexpr int RSHIFT = %d;\n" % rshift
+    s += "    static constexpr uint32_t RECIP = 0x%08xu;  // floor(2^RSHIFT * 2^(28 (N - QK)) / p)\n" % recip
     s += arr28("ONE", R % mod, n)
     s += arr28("R2", R * R % mod, n)
     s += arr("MODC", mod, nc)                # canonical 32-bit limbs
