@@ -436,6 +436,32 @@ BBS_HD Fe<P> lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2, const Fe<P>&
     return r;
 }
 
+// Reduce a lazily accumulated value given limb-wise by `limb(i)` (signed 64-bit, |limb| < 2^40, total
+// value in [0, weight * BOUND * p), `weight` = number of normal terms summed, negatives already
+// compensated by multiples of BOUND*p): reciprocal quotient estimate + one signed chain.
+template <class P, class F>
+BBS_HD Fe<P> reduce_fn(F limb, int weight) {
+    constexpr int N = P::N;
+    int64_t T = limb(N - 1);
+    if constexpr (P::QK == 2) T = T * (int64_t)(1 << 28) + limb(N - 2);
+    T -= (weight + 1);
+    const uint32_t q = T > 0 ? (uint32_t)(((uint64_t)T * P::RECIP) >> P::RSHIFT) : 0u;
+    Fe<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int64_t tt = limb(i) - (int64_t)q * (int64_t)P::MOD[i] + c;
+        if (i < N - 1) {
+            r.v[i] = (uint32_t)tt & MASK28;
+            c = tt >> 28;
+        } else {
+            r.v[i] = (uint32_t)tt;
+            BBS_BOUND_ASSERT(tt >= 0 && (uint64_t)tt <= P::MOD2[N - 1], "reduce_fn result in [0, 2p)");
+        }
+    }
+    return r;
+}
+
 // value == 0 mod p for a normal a  (a in {0, p, .., (BOUND-1) p})
 template <class P>
 BBS_HD bool is_zero(const Fe<P>& a) {

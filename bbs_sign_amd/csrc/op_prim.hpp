@@ -155,6 +155,7 @@ static Fp12<C> selftest_ref(const Fp12<C>& x, const Fp12<C>& y, const CtxConsts<
     else if constexpr (OP == 6) return f12_mul_line<C>(x, hc.tab_bp2.e[3], P);
     else if constexpr (OP == 7) return final_exponentiation<C>(x);
     else if constexpr (OP == 10) return f12_sqr<C>(x);
+    else if constexpr (OP == 8) return f12_sqr<C>(x);
     else if constexpr (OP == 11) return f12_pow_x<C>(x);
     else return x;
 }
@@ -192,7 +193,7 @@ int selftest_f12(Ctx<C>* ctx, int op, const uint8_t* a_le, const uint8_t* b_le, 
 #define BBS_ST_CASE(K) case K: rs = selftest_ref<C, K>(x, y, ctx->hc, Pt); lrc = rt::launch<SelfTestDist<C, K>>(ctx->stream, a, 64); break;
     switch (op) {
         BBS_ST_CASE(0) BBS_ST_CASE(1) BBS_ST_CASE(2) BBS_ST_CASE(3) BBS_ST_CASE(4) BBS_ST_CASE(5)
-        BBS_ST_CASE(6) BBS_ST_CASE(7) BBS_ST_CASE(10) BBS_ST_CASE(11)
+        BBS_ST_CASE(6) BBS_ST_CASE(7) BBS_ST_CASE(8) BBS_ST_CASE(10) BBS_ST_CASE(11)
         default: return BBS_E_ARG;
     }
 #undef BBS_ST_CASE

@@ -1041,6 +1041,7 @@ struct SelfTestDist {
         else if constexpr (OP == 6) rd = d_mul_line<C>(L, gx, a.cc->tab_bp2.e[3], P);
         else if constexpr (OP == 7) rd = d_final_exp<C>(L, gx, ft);
         else if constexpr (OP == 10) rd = d_cyclo_sqr<C>(L, gx);
+        else if constexpr (OP == 8) rd = d_sqr<C>(L, gx);
         else if constexpr (OP == 11) rd = d_pow_x<C>(L, gx);
         else rd = gx;
         for (int j = 0; j < N; j++) { a.out_dist[(2 * k) * N + j] = rd.c0.v[j]; a.out_dist[(2 * k + 1) * N + j] = rd.c1.v[j]; }

@@ -11,7 +11,7 @@ from oracle.curves import CURVES
 
 pytestmark = pytest.mark.gpu
 
-OPS = {0: "mul", 1: "frob1", 2: "frob2", 3: "frob3", 4: "inv", 5: "conj", 6: "line", 7: "final_exp",
+OPS = {0: "mul", 1: "frob1", 2: "frob2", 3: "frob3", 4: "inv", 5: "conj", 6: "line", 7: "final_exp", 8: "sqr",
        10: "cyclo_sqr", 11: "pow_x"}
 
 
