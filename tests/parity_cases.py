@@ -402,3 +402,42 @@ def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2):
         want = bbs.core_proof_gen(suite, pk, want_sig, b"", gens, b"", msgs[i], disclosed[i], suite.api_id, rnds[i])
         assert proof_eq(proofs[i], want)
     eng.close()
+
+
+def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8):
+    """EVERY item of a BASELINE-shaped batch against the plain-C oracle (oracle/c), bit for bit:
+    signatures, proofs and proof_verify booleans incl. corrupted items."""
+    import concurrent.futures as cf
+    import os
+    from oracle import c_port
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload("bls12_381", n, L, R, lib_path)
+    c = suite.curve
+    api_id = suite.api_id
+    pk = c_port.sk_to_pk(sk)
+    sigs, st = eng.core_sign_batch(msgs)
+    assert (st == 1).all()
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    dm = [m[:R] for m in msgs]
+    for i in range(0, n, 7):
+        proofs[i].r1_cap = (proofs[i].r1_cap + 1) % c.r
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+
+    def one(i):
+        s = c_port.core_sign(sk, gens, b"", msgs[i], api_id)
+        good = bbs.Signature(sigs[i].a, sigs[i].e)
+        p = c_port.core_proof_gen(pk, good, b"", gens, b"", msgs[i], disclosed[i], api_id, rnds[i])
+        mine = bbs.Proof(proofs[i].a_bar, proofs[i].b_bar, proofs[i].d, proofs[i].e_cap, proofs[i].r1_cap, proofs[i].r3_cap,
+                         proofs[i].commitments, proofs[i].challenge)
+        v = c_port.core_proof_verify(pk, mine, gens, b"", b"", dm[i], disclosed[i], api_id)
+        if i % 7 == 0:
+            p.r1_cap = (p.r1_cap + 1) % c.r
+        return (s.a, s.e) == (sigs[i].a, sigs[i].e), p == mine, int(v) == int(st[i])
+
+    with cf.ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as ex:
+        res = list(ex.map(one, range(n)))
+    assert all(r[0] for r in res), "sign mismatch"
+    assert all(r[1] for r in res), "proof_gen mismatch"
+    assert all(r[2] for r in res), "proof_verify mismatch"
+    assert [int(x) for x in st] == [0 if i % 7 == 0 else 1 for i in range(n)]
+    eng.close()

@@ -1,0 +1,60 @@
+"""Pins the plain-C restatement (oracle/c) against the KAT-pinned Python oracle and the reference's own
+full signature / proof vectors (src/tests/test_vector.rs:163-260)."""
+import random
+
+from oracle import bbs, c_port
+from oracle.bbs import BLS_SUITE as S
+from oracle.curves import BLS12_381 as C
+
+H = bytes.fromhex
+SIG_HEX = "84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f27164657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0"
+
+
+def test_reference_vectors_through_c():
+    ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+    key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+    key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+    m1 = H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")
+    header = H("11223344556677889900aabbccddeeff")
+    ph = H("bed231d880675ed101ead304512e043ade9958dd0241ea70b4b3957fba941501")
+    sk = bbs.key_gen(S, ikm, key_info, key_dst)
+    pk = c_port.sk_to_pk(sk)
+    assert pk == bbs.sk_to_pk(S, sk)
+    gens = bbs.create_generators(S, 2, S.api_id)
+    msgs = bbs.msg_to_scalars(S, [m1], S.api_id)
+    sig = c_port.core_sign(sk, gens, header, msgs, S.api_id)
+    assert bbs.g1_compress(C, sig.a).hex() + bbs.scalar_be(C, sig.e).hex() == SIG_HEX
+    assert c_port.core_verify(pk, sig, gens, header, msgs, S.api_id) is True
+    assert c_port.core_verify(pk, sig, gens, header + b"x", msgs, S.api_id) is False
+    rnd = bbs.mocked_calculate_random_scalars(S, 5)
+    proof = c_port.core_proof_gen(pk, sig, header, gens, ph, msgs, [0], S.api_id, rnd)
+    want = bbs.core_proof_gen(S, pk, sig, header, gens, ph, msgs, [0], S.api_id, rnd)
+    assert proof == want
+    assert c_port.core_proof_verify(pk, proof, gens, header, ph, msgs, [0], S.api_id) is True
+    assert c_port.core_proof_verify(pk, proof, gens, header, ph + b"x", msgs, [0], S.api_id) is False
+
+
+def test_c_matches_python_oracle_random():
+    rng = random.Random(4)
+    L = 6
+    gens = bbs.create_generators(S, L + 1, S.api_id)
+    sk = rng.randrange(1, C.r)
+    pk = bbs.sk_to_pk(S, sk)
+    for it in range(3):
+        msgs = [rng.randrange(C.r) for _ in range(L)]
+        hdr = bytes(rng.randrange(256) for _ in range(rng.choice([0, 7, 70])))
+        ph = bytes(rng.randrange(256) for _ in range(rng.choice([0, 33])))
+        disclosed = sorted(rng.sample(range(L), rng.randrange(0, L + 1)))
+        rnd = [rng.randrange(1, C.r) for _ in range(5 + L - len(disclosed))]
+        sig = c_port.core_sign(sk, gens, hdr, msgs, S.api_id)
+        psig = bbs.core_sign(S, sk, gens, hdr, msgs, S.api_id)
+        assert (sig.a, sig.e) == (psig.a, psig.e)
+        proof = c_port.core_proof_gen(pk, sig, hdr, gens, ph, msgs, disclosed, S.api_id, rnd)
+        assert proof == bbs.core_proof_gen(S, pk, psig, hdr, gens, ph, msgs, disclosed, S.api_id, rnd)
+        dm = [msgs[i] for i in disclosed]
+        assert c_port.core_proof_verify(pk, proof, gens, hdr, ph, dm, disclosed, S.api_id) is True
+        bad = bbs.Proof(proof.a_bar, proof.b_bar, proof.d, (proof.e_cap + 1) % C.r, proof.r1_cap, proof.r3_cap, proof.commitments, proof.challenge)
+        assert c_port.core_proof_verify(pk, bad, gens, hdr, ph, dm, disclosed, S.api_id) is False
+        forged = bbs.Proof(None, proof.b_bar, proof.d, proof.e_cap, proof.r1_cap, proof.r3_cap, proof.commitments, proof.challenge)
+        want = bbs.core_proof_verify(S, pk, forged, gens, hdr, ph, dm, disclosed, S.api_id)
+        assert c_port.core_proof_verify(pk, forged, gens, hdr, ph, dm, disclosed, S.api_id) == want

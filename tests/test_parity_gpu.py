@@ -36,3 +36,7 @@ def test_primitives(curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_full_batch_4096(curve):
     pc.check_big_batch(curve, None, n=4096, L=32, R=8)
+
+
+def test_every_item_against_c_oracle():
+    pc.check_batch_vs_c_oracle(None, n=512)
