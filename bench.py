@@ -43,6 +43,18 @@ PMC = {"pairing_6lane": {"valu_insts": 1.309e9, "fetch_bytes": 2 * 2.438e4 * 102
        "pv_challenge": {"valu_insts": 2.753e7, "fetch_bytes": 2 * 7534 * 1024, "write_bytes": 7189 * 1024}}
 
 
+def host_cores():
+    """Threads this process may really use: affinity, cgroup CPU quota, and the GPU box's share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(items_per_core=24):
     """The oracle's plain-C restatement (oracle/c/bbs_oracle.c: reference operation order, per-call
     domain, 38 independent double-and-add scalar multiplications, two full pairings) timed on the host
@@ -53,7 +65,7 @@ def cpu_baseline(items_per_core=24):
     suite = bbs.BLS_SUITE
     L, R = 32, 8
     api_id = suite.api_id
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n_items = items_per_core * cores
     sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
     pk = c_port.sk_to_pk(sk)
