@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=8, help="device-resident batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed sign/verify/proof_gen/BN254 figures")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     args = ap.parse_args()
 
     import torch
@@ -110,10 +114,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.all_ranks_on_device is not None:
+            local_rank = args.all_ranks_on_device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
 
     import parity_cases as pc
     from bbs_sign_amd import Engine  # noqa: F401  (fails loudly if the HIP library is missing)
@@ -155,8 +165,28 @@ def main():
     # one batch at a time (latency form), outside the timed region
     single_ms, single_stage = job.run_timed(3, per_stage=True)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([passed], dtype=torch.int64, device="cuda")
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the other three operations of the path and the second curve, one batch at a time (BASELINE configs[1..3])
+        def rate(j, reps=3):
+            j.run(); j.wait()
+            ms, _ = j.run_timed(reps, per_stage=False)
+            return n / (ms / reps * 1e-3)
+        extras = {"unit": "items/s, one 4096-item batch at a time",
+                  "bls12_381": {"sign": rate(eng.core_sign_upload(msgs)), "verify": rate(eng.core_verify_upload(sigs, msgs)),
+                                "proof_gen": rate(eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds))}}
+        _, eb, _, _, mb, db, rb = pc.bench_workload("bn254", n, L, R, None, 8, device=local_rank)
+        sb, st = eb.core_sign_batch(mb)
+        assert (st == 1).all()
+        pb, st = eb.core_proof_gen_batch(sb, mb, db, rb)
+        assert (st == 1).all()
+        jb = eb.core_proof_verify_upload(pb, [m[:R] for m in mb], db)
+        extras["bn254"] = {"sign": rate(eb.core_sign_upload(mb)), "verify": rate(eb.core_verify_upload(sb, mb)),
+                           "proof_gen": rate(eb.core_proof_gen_upload(sb, mb, db, rb)), "proof_verify": rate(jb)}
+        assert (jb.status() == 1).all()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([passed], dtype=torch.int64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)       # the only exchange: one pass-count per rank
@@ -200,6 +230,8 @@ def main():
             "single_batch": {"ms": single_ms / 3, "proof_verify_per_s": n / (single_ms / 3 * 1e-3),
                              "stage_ms": {k: v / 3 for k, v in single_stage.items()}},
         }
+        if extras is not None:
+            out["other_ops"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
