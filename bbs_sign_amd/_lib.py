@@ -61,6 +61,12 @@ SIGNATURES = {
     "bbs_create_generators": (ci, [ci, sz, c_u8p, sz, c_u8p]),
     "bbs_hash_to_g1": (ci, [ci, c_u8p, sz, c_u8p, sz, c_u8p]),
     "bbs_key_gen": (ci, [ci, c_u8p, sz, c_u8p, sz, c_u8p, sz, c_u8p]),
+    "bbs_signature_to_octets": (ci, [ci, c_u8p, c_u8p]),
+    "bbs_signature_from_octets": (ci, [ci, c_u8p, c_u8p]),
+    "bbs_proof_to_octets": (ci, [ci, c_u8p, c_u8p, sz, c_u8p]),
+    "bbs_proof_from_octets": (ci, [ci, c_u8p, sz, c_u8p, c_u8p, sz, ctypes.POINTER(sz)]),
+    "bbs_public_key_to_octets": (ci, [ci, c_u8p, ci, c_u8p]),
+    "bbs_public_key_from_octets": (ci, [ci, c_u8p, c_u8p, ctypes.POINTER(ci)]),
 }
 
 _cache = {}

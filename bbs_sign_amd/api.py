@@ -163,3 +163,102 @@ def proof_verify(pk: PublicKey, proof: Proof, header: bytes, ph: bytes, disclose
     L = len(proof.commitments) + len(disclosed_indexes)
     eng = _engine(pk.curve, L, pk=pk.pk, device=pk.device, lib_path=pk.lib_path)
     return eng.core_proof_verify(proof, header, ph, msg_to_scalars(eng, pk.curve, disclosed_messages), disclosed_indexes)
+
+
+# ---------------------------------------------------------------------------------- wire codec
+def _curve_id(curve: str) -> int:
+    return 0 if curve == "bls12_381" else 1
+
+
+def _codec_check(rc: int, where: str):
+    if rc == 0:
+        return
+    if rc in (-40, -41, -42):
+        raise BbsError(rc)
+    raise BbsRuntimeError(rc, where)
+
+
+def _g1_rec(fpb, p) -> bytes:
+    return bytes(2 * fpb) if p is None else int(p[0]).to_bytes(fpb, "little") + int(p[1]).to_bytes(fpb, "little")
+
+
+def _g1_unrec(fpb, b):
+    x, y = int.from_bytes(b[:fpb], "little"), int.from_bytes(b[fpb:2 * fpb], "little")
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def signature_to_octets(curve: str, sig: Signature, lib_path: Optional[str] = None) -> bytes:
+    """signature = compress(A) || I2OSP(e, 32)  (the byte string of src/tests/test_vector.rs:188-191)."""
+    lib = _lib.load_library(lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(curve)))
+    rec = _bytes_arr(_g1_rec(fpb, sig.a) + int(sig.e).to_bytes(32, "little"))
+    out = np.zeros(fpb + 32, dtype=np.uint8)
+    _codec_check(lib.bbs_signature_to_octets(_curve_id(curve), _u8(rec), _u8(out)), "bbs_signature_to_octets")
+    return out.tobytes()
+
+
+def octets_to_signature(curve: str, octets: bytes, lib_path: Optional[str] = None) -> Signature:
+    lib = _lib.load_library(lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(curve)))
+    if len(octets) != fpb + 32:
+        raise BbsError(-42)
+    rec = np.zeros(2 * fpb + 32, dtype=np.uint8)
+    _codec_check(lib.bbs_signature_from_octets(_curve_id(curve), _u8(_bytes_arr(octets)), _u8(rec)), "bbs_signature_from_octets")
+    b = rec.tobytes()
+    return Signature(_g1_unrec(fpb, b), int.from_bytes(b[2 * fpb:], "little"))
+
+
+def proof_to_octets(curve: str, proof: Proof, lib_path: Optional[str] = None) -> bytes:
+    lib = _lib.load_library(lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(curve)))
+    pf = _bytes_arr(_g1_rec(fpb, proof.a_bar) + _g1_rec(fpb, proof.b_bar) + _g1_rec(fpb, proof.d)
+                    + b"".join(int(x).to_bytes(32, "little") for x in (proof.e_cap, proof.r1_cap, proof.r3_cap, proof.challenge)))
+    cm = _bytes_arr(b"".join(int(x).to_bytes(32, "little") for x in proof.commitments))
+    out = np.zeros(3 * fpb + 32 * (4 + len(proof.commitments)), dtype=np.uint8)
+    _codec_check(lib.bbs_proof_to_octets(_curve_id(curve), _u8(pf), _u8(cm), len(proof.commitments), _u8(out)), "bbs_proof_to_octets")
+    return out.tobytes()
+
+
+def octets_to_proof(curve: str, octets: bytes, lib_path: Optional[str] = None) -> Proof:
+    lib = _lib.load_library(lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(curve)))
+    cap = max(len(octets) // 32, 1)
+    pf = np.zeros(6 * fpb + 128, dtype=np.uint8)
+    cm = np.zeros(cap * 32, dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    _codec_check(lib.bbs_proof_from_octets(_curve_id(curve), _u8(_bytes_arr(octets)), len(octets), _u8(pf), _u8(cm), cap,
+                                           ctypes.byref(n)), "bbs_proof_from_octets")
+    b, c = pf.tobytes(), cm.tobytes()
+    pts = [_g1_unrec(fpb, b[k * 2 * fpb:(k + 1) * 2 * fpb]) for k in range(3)]
+    sc = [int.from_bytes(b[6 * fpb + 32 * k:6 * fpb + 32 * (k + 1)], "little") for k in range(4)]
+    return Proof(pts[0], pts[1], pts[2], sc[0], sc[1], sc[2],
+                 [int.from_bytes(c[32 * k:32 * k + 32], "little") for k in range(n.value)], sc[3])
+
+
+def public_key_to_octets(pk: PublicKey) -> bytes:
+    lib = _lib.load_library(pk.lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(pk.curve)))
+    out = np.zeros(2 * fpb, dtype=np.uint8)
+    if pk.pk is None:
+        rec, inf = _bytes_arr(bytes(4 * fpb)), 1
+    else:
+        (x0, x1), (y0, y1) = pk.pk
+        rec, inf = _bytes_arr(b"".join(int(v).to_bytes(fpb, "little") for v in (x0, x1, y0, y1))), 0
+    _codec_check(lib.bbs_public_key_to_octets(_curve_id(pk.curve), _u8(rec), inf, _u8(out)), "bbs_public_key_to_octets")
+    return out.tobytes()
+
+
+def octets_to_public_key(curve: str, octets: bytes, lib_path: Optional[str] = None, device: int = 0) -> PublicKey:
+    lib = _lib.load_library(lib_path)
+    fpb = int(lib.bbs_fp_bytes(_curve_id(curve)))
+    if len(octets) != 2 * fpb:
+        raise BbsError(-42)
+    rec = np.zeros(4 * fpb, dtype=np.uint8)
+    inf = ctypes.c_int(0)
+    _codec_check(lib.bbs_public_key_from_octets(_curve_id(curve), _u8(_bytes_arr(octets)), _u8(rec), ctypes.byref(inf)),
+                 "bbs_public_key_from_octets")
+    if inf.value:
+        return PublicKey(curve, None, lib_path, device)
+    b = rec.tobytes()
+    f = [int.from_bytes(b[i * fpb:(i + 1) * fpb], "little") for i in range(4)]
+    return PublicKey(curve, ((f[0], f[1]), (f[2], f[3])), lib_path, device)

@@ -1,6 +1,7 @@
 // C ABI entry points (include/bbs_sign_amd.h) dispatching on the curve.
 #include "ops_decl.hpp"
 #include "host_h2c.hpp"
+#include "host_codec.hpp"
 
 // =============================================================================================
 // C ABI
@@ -308,6 +309,123 @@ int bbs_key_gen(int curve, const uint8_t* key_material, size_t km_len, const uin
     if (!any) return BBS_ST_INVALID_SECRET_KEY;
     for (int i = 0; i < 8; i++) put_le32(sk32_out + 4 * i, w[i]);
     return BBS_OK;
+}
+
+// ---- wire codec (host) ---------------------------------------------------------------------------
+}  // extern "C"
+template <class C>
+static int sig_to_octets(const uint8_t* rec, uint8_t* out) {
+    constexpr int NB = 4 * C::FpP::NC;
+    G1Aff<C> a;
+    if (!codec::g1_record_to_aff<C>(rec, a)) return BBS_ST_NONCANONICAL;
+    g1_compress_host<C>(a, out);
+    codec::scalar_le_to_be(rec + 2 * NB, out + NB);
+    return BBS_OK;
+}
+template <class C>
+static int sig_from_octets(const uint8_t* oct, uint8_t* rec) {
+    constexpr int NB = 4 * C::FpP::NC;
+    G1Aff<C> a;
+    bool inf;
+    const int rc = codec::g1_decompress<C>(oct, a, inf);
+    if (rc == -1) return BBS_ST_NONCANONICAL;
+    if (rc) return BBS_ST_NOT_ON_CURVE;
+    if (inf) return BBS_ST_INVALID_ENCODING;                       // octets_to_signature: A must not be the identity
+    if (!codec::scalar_be_to_le<C>(oct + NB, rec + 2 * NB)) return BBS_ST_NONCANONICAL;
+    bool zero = true;
+    for (int i = 0; i < 32; i++) zero &= rec[2 * NB + i] == 0;
+    if (zero) return BBS_ST_INVALID_ENCODING;                      // e = 0 is rejected
+    codec::g1_aff_to_record<C>(a, rec);
+    return BBS_OK;
+}
+template <class C>
+static int proof_to_octets(const uint8_t* pf, const uint8_t* cm, size_t n_cm, uint8_t* out) {
+    constexpr int NB = 4 * C::FpP::NC;
+    for (int p = 0; p < 3; p++) {
+        G1Aff<C> a;
+        if (!codec::g1_record_to_aff<C>(pf + (size_t)p * 2 * NB, a)) return BBS_ST_NONCANONICAL;
+        g1_compress_host<C>(a, out + (size_t)p * NB);
+    }
+    uint8_t* o = out + 3 * NB;
+    for (int k = 0; k < 3; k++) codec::scalar_le_to_be(pf + 6 * NB + 32 * k, o + 32 * k);          // e^, r1^, r3^
+    for (size_t k = 0; k < n_cm; k++) codec::scalar_le_to_be(cm + 32 * k, o + 96 + 32 * k);       // m^_j
+    codec::scalar_le_to_be(pf + 6 * NB + 96, o + 96 + 32 * n_cm);                                  // challenge
+    return BBS_OK;
+}
+template <class C>
+static int proof_from_octets(const uint8_t* oct, size_t len, uint8_t* pf, uint8_t* cm, size_t cm_cap, size_t* n_cm) {
+    constexpr int NB = 4 * C::FpP::NC;
+    const size_t fixed = 3 * NB + 4 * 32;
+    if (len < fixed || (len - fixed) % 32) return BBS_ST_INVALID_ENCODING;
+    const size_t u = (len - fixed) / 32;
+    if (u > cm_cap) return BBS_E_ARG;
+    for (int p = 0; p < 3; p++) {
+        G1Aff<C> a;
+        bool inf;
+        const int rc = codec::g1_decompress<C>(oct + (size_t)p * NB, a, inf);
+        if (rc == -1) return BBS_ST_NONCANONICAL;
+        if (rc) return BBS_ST_NOT_ON_CURVE;
+        if (inf) return BBS_ST_INVALID_ENCODING;                   // octets_to_proof rejects identity points
+        codec::g1_aff_to_record<C>(a, pf + (size_t)p * 2 * NB);
+    }
+    const uint8_t* o = oct + 3 * NB;
+    for (int k = 0; k < 3; k++) if (!codec::scalar_be_to_le<C>(o + 32 * k, pf + 6 * NB + 32 * k)) return BBS_ST_NONCANONICAL;
+    for (size_t k = 0; k < u; k++) if (!codec::scalar_be_to_le<C>(o + 96 + 32 * k, cm + 32 * k)) return BBS_ST_NONCANONICAL;
+    if (!codec::scalar_be_to_le<C>(o + 96 + 32 * u, pf + 6 * NB + 96)) return BBS_ST_NONCANONICAL;
+    if (n_cm) *n_cm = u;
+    return BBS_OK;
+}
+template <class C>
+static int pk_from_octets(const uint8_t* oct, uint8_t* rec, int* is_identity) {
+    using P = typename C::FpP;
+    constexpr int NB = 4 * P::NC;
+    G2Aff<C> q;
+    const int rc = codec::g2_decompress<C>(oct, q);
+    if (rc == -1) return BBS_ST_NONCANONICAL;
+    if (rc) return BBS_ST_NOT_ON_CURVE;
+    if (is_identity) *is_identity = q.inf ? 1 : 0;
+    if (q.inf) { std::memset(rec, 0, 4 * NB); return BBS_OK; }
+    fe_to_le_bytes<P>(q.x.c0, rec); fe_to_le_bytes<P>(q.x.c1, rec + NB);
+    fe_to_le_bytes<P>(q.y.c0, rec + 2 * NB); fe_to_le_bytes<P>(q.y.c1, rec + 3 * NB);
+    return BBS_OK;
+}
+template <class C>
+static int pk_to_octets(const uint8_t* rec, int is_identity, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr int NB = 4 * P::NC;
+    G2Aff<C> q{};
+    q.inf = is_identity != 0;
+    if (!q.inf && (!fe_from_le_bytes<P>(rec, q.x.c0) || !fe_from_le_bytes<P>(rec + NB, q.x.c1) ||
+                   !fe_from_le_bytes<P>(rec + 2 * NB, q.y.c0) || !fe_from_le_bytes<P>(rec + 3 * NB, q.y.c1))) return BBS_ST_NONCANONICAL;
+    g2_compress<C>(q, out);
+    return BBS_OK;
+}
+extern "C" {
+#define CURVE_OK(c) ((c) == BBS_CURVE_BLS12_381 || (c) == BBS_CURVE_BN254)
+int bbs_signature_to_octets(int curve, const uint8_t* sig_record, uint8_t* out) {
+    if (!CURVE_OK(curve) || !sig_record || !out) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? sig_to_octets<BlsCurve>(sig_record, out) : sig_to_octets<BnCurve>(sig_record, out);
+}
+int bbs_signature_from_octets(int curve, const uint8_t* octets, uint8_t* sig_record_out) {
+    if (!CURVE_OK(curve) || !octets || !sig_record_out) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? sig_from_octets<BlsCurve>(octets, sig_record_out) : sig_from_octets<BnCurve>(octets, sig_record_out);
+}
+int bbs_proof_to_octets(int curve, const uint8_t* pf, const uint8_t* cm, size_t n_cm, uint8_t* out) {
+    if (!CURVE_OK(curve) || !pf || !out || (n_cm && !cm)) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? proof_to_octets<BlsCurve>(pf, cm, n_cm, out) : proof_to_octets<BnCurve>(pf, cm, n_cm, out);
+}
+int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t* pf_out, uint8_t* cm_out, size_t cm_cap, size_t* n_cm_out) {
+    if (!CURVE_OK(curve) || !octets || !pf_out || (cm_cap && !cm_out)) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? proof_from_octets<BlsCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out)
+                                        : proof_from_octets<BnCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out);
+}
+int bbs_public_key_to_octets(int curve, const uint8_t* pk_affine, int is_identity, uint8_t* out) {
+    if (!CURVE_OK(curve) || !out || (!is_identity && !pk_affine)) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? pk_to_octets<BlsCurve>(pk_affine, is_identity, out) : pk_to_octets<BnCurve>(pk_affine, is_identity, out);
+}
+int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_affine_out, int* is_identity_out) {
+    if (!CURVE_OK(curve) || !octets || !pk_affine_out) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? pk_from_octets<BlsCurve>(octets, pk_affine_out, is_identity_out) : pk_from_octets<BnCurve>(octets, pk_affine_out, is_identity_out);
 }
 
 int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single, uint8_t* out_dist) {

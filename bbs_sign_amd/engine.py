@@ -39,6 +39,7 @@ STATUS_NAMES = {
     -23: "Panic(dst size is invalid)",
     -40: "NonCanonical",
     -41: "NotOnCurve",
+    -42: "InvalidEncoding",
 }
 ERRORS = {-100: "BBS_E_ARG", -101: "BBS_E_HIP", -102: "BBS_E_STATE", -103: "BBS_E_PUBLIC_KEY",
           -104: "BBS_E_NO_DEVICE", -105: "BBS_E_NOMEM"}

@@ -56,7 +56,8 @@ extern "C" {
 #define BBS_ST_PANIC_DST_TOO_LONG (-23)       /* src/utils/utilities_helper.rs:46-52 */
 /* inputs arkworks' types cannot represent */
 #define BBS_ST_NONCANONICAL (-40)             /* scalar >= r or coordinate >= p */
-#define BBS_ST_NOT_ON_CURVE (-41)
+#define BBS_ST_NOT_ON_CURVE (-41)            /* also: not in the prime-order subgroup (codec) */
+#define BBS_ST_INVALID_ENCODING (-42)        /* octet string of the wrong shape / forbidden identity or zero */
 
 /* batch-level errors */
 #define BBS_OK 0
@@ -213,6 +214,24 @@ int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t*
 /* SecretKey::key_gen (src/key_gen.rs:46-81): returns 0 or the KeyGenError code. */
 int bbs_key_gen(int curve, const uint8_t* key_material, size_t key_material_len, const uint8_t* key_info,
                 size_t key_info_len, const uint8_t* key_dst, size_t key_dst_len, uint8_t* sk32_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Wire codec (host side).  Octet strings as in the reference's vectors (src/tests/test_vector.rs:
+ * 163-260): signature = compress(A) || e, proof = compress(Abar) || compress(Bbar) || compress(D) ||
+ * e^ || r1^ || r3^ || m^_1 .. m^_U || c, public key = compress(pk); scalars 32 B big-endian.
+ * `*_from_octets` validate: canonical encodings, on curve, prime-order subgroup, and reject an
+ * identity point / zero e where the BBS draft does.  Return 0 or a BBS_ST_* code.
+ * (The reference derives ark-serialize's CanonicalSerialize/Deserialize for these types --
+ * src/sign.rs:18, src/proof_gen.rs:29, src/key_gen.rs:12 -- without ever exercising them.)
+ * ------------------------------------------------------------------------------------------ */
+int bbs_signature_to_octets(int curve, const uint8_t* sig_record, uint8_t* out /* fp_bytes + 32 */);
+int bbs_signature_from_octets(int curve, const uint8_t* octets, uint8_t* sig_record_out);
+int bbs_proof_to_octets(int curve, const uint8_t* proof_fixed, const uint8_t* commitments, size_t n_commitments,
+                        uint8_t* out /* 3 * fp_bytes + 32 * (4 + n_commitments) */);
+int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t* proof_fixed_out,
+                          uint8_t* commitments_out, size_t commitments_cap, size_t* n_commitments_out);
+int bbs_public_key_to_octets(int curve, const uint8_t* pk_affine, int is_identity, uint8_t* out /* 2 * fp_bytes */);
+int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_affine_out, int* is_identity_out);
 
 /* GPU self-test: one Fp12 operation (12 Fp values a, b, canonical LE, tower order) computed by the
  * one-lane code and by the six-lane wavefront-cooperative code; the caller compares the outputs.

@@ -1,0 +1,85 @@
+"""Wire codec (host side of the product library: no GPU needed): the octet strings of the reference's
+vectors (src/tests/test_vector.rs:139-260) decode to the oracle's structures and re-encode to the same
+bytes; malformed encodings are rejected."""
+import os
+import sys
+
+import pytest
+
+from bbs_sign_amd import BbsError, api
+from oracle import bbs
+from oracle.bbs import BLS_SUITE as S, BN_SUITE
+from oracle.curves import BLS12_381 as C, BN254
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIG_HEX = "84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f27164657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0"
+PROOF_HEX = "94916292a7a6bade28456c601d3af33fcf39278d6594b467e128a3f83686a104ef2b2fcf72df0215eeaf69262ffe8194a19fab31a82ddbe06908985abc4c9825788b8a1610942d12b7f5debbea8985296361206dbace7af0cc834c80f33e0aadaeea5597befbb651827b5eed5a66f1a959bb46cfd5ca1a817a14475960f69b32c54db7587b5ee3ab665fbd37b506830a49f21d592f5e634f47cee05a025a2f8f94e73a6c15f02301d1178a92873b6e8634bafe4983c3e15a663d64080678dbf29417519b78af042be2b3e1c4d08b8d520ffab008cbaaca5671a15b22c239b38e940cfeaa5e72104576a9ec4a6fad78c532381aeaa6fb56409cef56ee5c140d455feeb04426193c57086c9b6d397d9418"
+PK_HEX = "a820f230f6ae38503b86c70dc50b61c58a77e45c39ab25c0652bbaa8fa136f2851bd4781c9dcde39fc9d1d52c9e60268061e7d7632171d91aa8d460acee0e96f1e7c4cfb12d3ff9ab5d5dc91c277db75c845d649ef3c4f63aebc364cd55ded0c"
+
+
+@pytest.fixture(scope="session")
+def lib():
+    sys.path.insert(0, ROOT)
+    from bbs_sign_amd import build as b
+    return b.build(twin=False, verbose=False)
+
+
+def test_vectors_round_trip(lib):
+    sig = api.octets_to_signature("bls12_381", bytes.fromhex(SIG_HEX), lib)
+    assert bbs.g1_compress(C, sig.a).hex() + bbs.scalar_be(C, sig.e).hex() == SIG_HEX
+    assert C.g1_is_on_curve(sig.a)
+    assert api.signature_to_octets("bls12_381", sig, lib).hex() == SIG_HEX
+    proof = api.octets_to_proof("bls12_381", bytes.fromhex(PROOF_HEX), lib)
+    assert proof.commitments == [] and C.g1_is_on_curve(proof.a_bar) and C.g1_is_on_curve(proof.d)
+    assert api.proof_to_octets("bls12_381", proof, lib).hex() == PROOF_HEX
+    pk = api.octets_to_public_key("bls12_381", bytes.fromhex(PK_HEX), lib)
+    assert bbs.g2_compress(C, pk.pk).hex() == PK_HEX
+    assert api.public_key_to_octets(pk).hex() == PK_HEX
+
+
+def test_proof_with_commitments_and_bn254(lib):
+    import random
+    rng = random.Random(3)
+    for suite, name in ((S, "bls12_381"), (BN_SUITE, "bn254")):
+        c = suite.curve
+        pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in range(3)]
+        sc = [rng.randrange(c.r) for _ in range(4)]
+        cms = [rng.randrange(c.r) for _ in range(5)]
+        p = api.Proof(pts[0], pts[1], pts[2], sc[0], sc[1], sc[2], cms, sc[3])
+        oct_ = api.proof_to_octets(name, p, lib)
+        want = b"".join(bbs.g1_compress(c, q) for q in pts) + b"".join(bbs.scalar_be(c, x) for x in sc[:3] + cms + sc[3:])
+        assert oct_ == want
+        back = api.octets_to_proof(name, oct_, lib)
+        assert (back.a_bar, back.b_bar, back.d, back.e_cap, back.r1_cap, back.r3_cap, back.commitments, back.challenge) == \
+               (p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, p.commitments, p.challenge)
+        pk = suite.curve.g2_mul(c.g2, rng.randrange(1, c.r))
+        o = api.public_key_to_octets(api.PublicKey(name, pk, lib))
+        assert o == bbs.g2_compress(c, pk)
+        assert api.octets_to_public_key(name, o, lib).pk == pk
+
+
+def test_malformed_octets_are_rejected(lib):
+    good = bytearray.fromhex(SIG_HEX)
+    cases = []
+    b = bytearray(good); b[0] &= 0x7F; cases.append(bytes(b))                       # compression flag cleared
+    b = bytearray(good); b[0] ^= 0x20; b[47] ^= 1; cases.append(bytes(b))          # x changed: (almost surely) not on the curve / subgroup
+    cases.append(bytes([0xC0]) + bytes(47) + bytes(good[48:]))                      # A = identity
+    cases.append(bytes(good[:48]) + bytes(32))                                      # e = 0
+    cases.append(bytes(good[:48]) + C.r.to_bytes(32, "big"))                        # e = r: not canonical
+    cases.append(bytes([0x9F]) + bytes([0xFF] * 47) + bytes(good[48:]))             # x >= p
+    for o in cases:
+        with pytest.raises(BbsError):
+            api.octets_to_signature("bls12_381", o, lib)
+    with pytest.raises(BbsError):
+        api.octets_to_proof("bls12_381", bytes.fromhex(PROOF_HEX)[:-1], lib)
+    # a point on the curve but outside the prime-order subgroup is rejected
+    x = 1
+    while True:
+        y2 = (x ** 3 + 4) % C.p
+        y = pow(y2, (C.p + 1) // 4, C.p)
+        if y * y % C.p == y2 and C.g1_mul((x, y), C.r) is not None:
+            break
+        x += 1
+    o = bytes(bbs.g1_compress(C, (x, y))) + bytes(good[48:])
+    with pytest.raises(BbsError):
+        api.octets_to_signature("bls12_381", o, lib)
