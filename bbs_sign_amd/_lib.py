@@ -27,6 +27,7 @@ SIGNATURES = {
     "bbs_ctx_create": (ci, [ci, ci, ctypes.POINTER(vp)]),
     "bbs_ctx_destroy": (None, [vp]),
     "bbs_ctx_set_window_bits": (ci, [vp, ci]),
+    "bbs_ctx_set_batch_verification": (ci, [vp, ci, c_u8p]),
     "bbs_ctx_set_generators": (ci, [vp, c_u8p, sz, c_u8p, sz]),
     "bbs_ctx_set_public_key": (ci, [vp, c_u8p, ci]),
     "bbs_ctx_set_secret_key": (ci, [vp, c_u8p]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "bbs_jobs_run_timed": (ci, [ctypes.POINTER(vp), ci, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
     "bbs_hash_to_scalar_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, sz, c_u8p]),
     "bbs_g1_msm_batch": (ci, [vp, sz, c_u8p, sz, c_u8p, c_u8p, sz, c_u8p, c_i8p]),
+    "bbs_g1_msm_pippenger": (ci, [vp, sz, c_u8p, c_u8p, c_u8p, ctypes.POINTER(ci), c_i8p]),
     "bbs_pairing_product2_is_one_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
     "bbs_selftest_f12": (ci, [vp, ci, c_u8p, c_u8p, c_u8p, c_u8p]),
     "bbs_create_generators": (ci, [ci, sz, c_u8p, sz, c_u8p]),

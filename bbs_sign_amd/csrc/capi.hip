@@ -3,6 +3,12 @@
 #include "host_h2c.hpp"
 #include "host_codec.hpp"
 
+// Many independent batches are kept in flight, one HIP stream pair each.  The HIP runtime maps the streams of a
+// process onto 4 hardware queues unless told otherwise, and a long narrow kernel then blocks the streams sharing
+// its queue (measured on MI355X: 645k -> 780k proof_verify/s with 16 queues).  Takes effect only if this library
+// is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
+__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -47,6 +53,10 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
     if (!ctx || bits < 4 || bits > 16) return BBS_E_ARG;
     if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->win_bits = bits; else AS_BN(ctx)->win_bits = bits;
     return BBS_OK;
+}
+int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, AS_BLS(ctx)->set_batch_verification(enabled, seed32), AS_BN(ctx)->set_batch_verification(enabled, seed32));
 }
 int bbs_ctx_set_generators(bbs_ctx* ctx, const uint8_t* g, size_t count, const uint8_t* api_id, size_t api_id_len) {
     if (!ctx) return BBS_E_ARG;
@@ -261,6 +271,11 @@ int bbs_hash_to_scalar_batch(bbs_ctx* ctx, size_t n, const uint8_t* msgs, const 
 int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t* vp, const uint8_t* vs, size_t nv, uint8_t* out, int8_t* status) {
     if (!ctx) return BBS_E_ARG;
     return DISPATCH(ctx, msm_batch<BlsCurve>(AS_BLS(ctx), n, fs, nf, vp, vs, nv, out, status), msm_batch<BnCurve>(AS_BN(ctx), n, fs, nf, vp, vs, nv, out, status));
+}
+
+int bbs_g1_msm_pippenger(bbs_ctx* ctx, size_t n, const uint8_t* pts, const uint8_t* scal, uint8_t* out, int* out_inf, int8_t* status) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, msm_pippenger<BlsCurve>(AS_BLS(ctx), n, pts, scal, out, out_inf, status), msm_pippenger<BnCurve>(AS_BN(ctx), n, pts, scal, out, out_inf, status));
 }
 
 // ---- host-side setup helpers (once per ciphersuite / key; no GPU involved) ---------------------

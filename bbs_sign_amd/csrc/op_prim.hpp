@@ -105,6 +105,53 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     }
     return BBS_OK;
 }
+// S = sum_i k_i * P_i over n per-item points by the bucket method (pippenger.hpp); items whose encoding is not
+// canonical (-40) or whose point is not on the curve (-41) are reported in status and contribute nothing
+template <class C>
+int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal, uint8_t* out, int* out_inf, int8_t* status) {
+    constexpr int N = C::FpP::N;
+    constexpr int NC = C::FpP::NC;
+    constexpr int FPB = 4 * NC;
+    constexpr int NW = 32;
+    using R = typename C::FrP;
+    if (!out || !out_inf || !status || (n && (!pts || !scal))) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    Soa P, S;
+    P.init(2 * NC, std::max<size_t>(n, 1)); S.init(8, std::max<size_t>(n, 1));
+    std::vector<int8_t> st0(std::max<size_t>(n, 1), 1);
+    for (size_t i = 0; i < n; i++) {
+        bool ok = pack_g1<C>(P, 0, i, pts + i * 2 * FPB);
+        ok &= pack_fe<R>(S, 0, i, scal + i * 32);
+        if (!ok) st0[i] = BBS_ST_NONCANONICAL;
+    }
+    const size_t n_pad = (n + 3) & ~(size_t)3, T = (size_t)NW * PIP_NB;
+    DevBuf dP, dS, dSt, dPm, dDig, dList, dB, dSeg, dW, dOut;
+    if (dP.alloc(P.bytes()) || dS.alloc(S.bytes()) || dSt.alloc(n + 4) || dPm.alloc((size_t)2 * N * n * 4 + 4) ||
+        dDig.alloc((size_t)NW * n_pad + 4) || dList.alloc((size_t)NW * n * 4 + 4) || dB.alloc((size_t)3 * N * T * 4) ||
+        dSeg.alloc((size_t)3 * N * NW * (PIP_NB / PIP_SEG) * 4) || dW.alloc((size_t)3 * N * NW * 4) || dOut.alloc((size_t)2 * N * 4))
+        return BBS_E_NOMEM;
+    if (rt::h2d(dP.p, P.v.data(), P.bytes(), ctx->stream) || rt::h2d(dS.p, S.v.data(), S.bytes(), ctx->stream) ||
+        rt::h2d(dSt.p, st0.data(), n, ctx->stream) || rt::dmemset(dDig.p, 0, (size_t)NW * n_pad, ctx->stream)) return BBS_E_HIP;
+    PipPrep<C> prep{dP.as<uint32_t>(), dPm.as<uint32_t>(), dSt.as<int8_t>(), n};
+    PipDigitArgs da{n, n_pad, dS.as<uint32_t>(), dSt.as<int8_t>(), dDig.as<uint8_t>()};
+    PipArgs<C> a{};
+    a.n = n; a.n_pad = n_pad; a.M = 1; a.NW = NW; a.pts0 = dPm.as<uint32_t>(); a.pts1 = a.pts0; a.dig = dDig.as<uint8_t>();
+    a.list = dList.as<uint32_t>(); a.buckets = dB.as<uint32_t>(); a.segs = dSeg.as<uint32_t>(); a.wins = dW.as<uint32_t>();
+    a.out = dOut.as<uint32_t>();
+    if (rt::launch<PipPrep<C>>(ctx->stream, prep, n) || rt::launch<PipDigits>(ctx->stream, da, n) ||
+        rt::launch<PipBuckets<C>>(ctx->stream, a, T) || rt::launch<PipSegments<C>>(ctx->stream, a, (size_t)NW * (PIP_NB / PIP_SEG)) ||
+        rt::launch<PipWindows<C>>(ctx->stream, a, (size_t)NW) || rt::launch<PipFinal<C>>(ctx->stream, a, 1) || rt::sync(ctx->stream))
+        return BBS_E_HIP;
+    std::vector<uint32_t> w((size_t)2 * N);
+    if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
+    G1Aff<C> r;
+    for (int j = 0; j < N; j++) { r.x.v[j] = w[j]; r.y.v[j] = w[N + j]; }
+    *out_inf = g1a_is_inf<C>(r) ? 1 : 0;
+    if (*out_inf) std::memset(out, 0, 2 * FPB);
+    else { fe_to_le_bytes<typename C::FpP>(r.x, out); fe_to_le_bytes<typename C::FpP>(r.y, out + FPB); }
+    return BBS_OK;
+}
+
 template <class C>
 int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
     constexpr int N = C::FpP::N;

@@ -20,7 +20,7 @@
 
 #include "../../include/bbs_sign_amd.h"
 #include "host_g2.hpp"
-#include "stages.hpp"
+#include "pippenger.hpp"
 
 using namespace bbs;
 
@@ -218,6 +218,35 @@ struct Ctx : bbs_ctx {
     CtxConsts<C> hc{};               // host mirror
     DevBuf d_consts, d_tables, d_winbase, d_bases;
     bool consts_dirty = true;
+    // batch verification (pippenger.hpp): off by default = every item gets its own pairing product
+    bool batch_verify = false;
+    uint32_t rlc_seed[8] = {0};
+    uint64_t rlc_counter = 0;
+
+    // secret seed of the next batch: SHA-256(context seed || counter)
+    void next_rlc_seed(uint32_t* out8) {
+        Sha256 s;
+        sha256_init(s);
+        for (int k = 0; k < 8; k++) sha256_word(s, rlc_seed[k]);
+        sha256_u64be(s, rlc_counter++);
+        sha256_final(s, out8);
+    }
+    int set_batch_verification(int enabled, const uint8_t* seed32) {
+        if (enabled) {
+            uint8_t buf[32];
+            if (seed32) std::memcpy(buf, seed32, 32);
+            else {
+                FILE* f = std::fopen("/dev/urandom", "rb");
+                const size_t got = f ? std::fread(buf, 1, 32, f) : 0;
+                if (f) std::fclose(f);
+                if (got != 32) return BBS_E_STATE;
+            }
+            for (int k = 0; k < 8; k++) rlc_seed[k] = le32(buf + 4 * k);
+            rlc_counter = 0;
+        }
+        batch_verify = enabled != 0;
+        return BBS_OK;
+    }
 
     int init(int dev) {
         device = dev;

@@ -5,3 +5,4 @@ template int h2s_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const u
 template int msm_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
 template int pairing_batch<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const uint8_t*, int8_t*);
 template int selftest_f12<BlsCurve>(Ctx<BlsCurve>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+template int msm_pippenger<BlsCurve>(Ctx<BlsCurve>*, size_t, const uint8_t*, const uint8_t*, uint8_t*, int*, int8_t*);

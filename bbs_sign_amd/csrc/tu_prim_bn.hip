@@ -5,3 +5,4 @@ template int h2s_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uin
 template int msm_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, int8_t*);
 template int pairing_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, int8_t*);
 template int selftest_f12<BnCurve>(Ctx<BnCurve>*, int, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+template int msm_pippenger<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, uint8_t*, int*, int8_t*);

@@ -190,6 +190,15 @@ class Engine:
         buf = _bytes_arr(self._fr(sk))
         self._chk(self.lib.bbs_ctx_set_secret_key(self.h, _u8(buf)), "bbs_ctx_set_secret_key")
 
+    def set_batch_verification(self, enabled: bool, seed: Optional[bytes] = None):
+        """Opt-in random-linear-combination batch verification for core_proof_verify (include/bbs_sign_amd.h);
+        seed=None draws the secret seed from the operating system."""
+        if seed is not None and len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        buf = _bytes_arr(seed) if seed is not None else None
+        self._chk(self.lib.bbs_ctx_set_batch_verification(self.h, 1 if enabled else 0, _u8(buf) if buf is not None else None),
+                  "bbs_ctx_set_batch_verification")
+
     def public_key(self):
         """sk_to_pk (src/key_gen.rs:83-90) of the secret key set on this context."""
         out = np.zeros(4 * self.fpb, dtype=np.uint8)
@@ -392,6 +401,18 @@ class Engine:
                                             st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_batch")
         b = out.tobytes()
         return [self._g1_dec(b[i * 2 * self.fpb:(i + 1) * 2 * self.fpb]) if st[i] == 1 else None for i in range(n)], st[:n]
+
+    def g1_msm_pippenger(self, points, scalars):
+        """sum_i scalars[i] * points[i] by the device's bucket method; returns (affine point or None, status)."""
+        n = len(points)
+        pb = _bytes_arr(b"".join(self._g1(p) for p in points))
+        sb = _bytes_arr(b"".join(self._fr(s) for s in scalars))
+        out = np.zeros(2 * self.fpb, dtype=np.uint8)
+        inf = ctypes.c_int(0)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_g1_msm_pippenger(self.h, n, _u8(pb), _u8(sb), _u8(out), ctypes.byref(inf),
+                                                st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_pippenger")
+        return (None if inf.value else self._g1_dec(out.tobytes())), st[:n]
 
     def pairing_product2_is_one_batch(self, pa, pb) -> np.ndarray:
         n = len(pa)

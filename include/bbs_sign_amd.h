@@ -88,6 +88,15 @@ void bbs_ctx_destroy(bbs_ctx* ctx);
  * bbs_ctx_set_generators.  Table bytes = (count+1) * ceil(256/w) * (2^w - 1) * 2 * fp_bytes. */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
+/* Batch verification for core_proof_verify (off by default).  When enabled, the n two-pairing products of a
+ * batch (src/proof_verify.rs:112-115) are replaced by ONE product over random linear combinations
+ * sum rho_i * Abar_i, sum rho_i * Bbar_i (128-bit rho_i derived from a secret seed; bucket-method
+ * multi-scalar multiplication on the device) taken over the items that passed every earlier check; only if
+ * that combined check fails are the items checked one by one.  The booleans equal the reference's except with
+ * probability 2^-128 per batch.  seed32 = NULL draws the seed from the operating system; a caller-supplied
+ * seed must be secret and fresh.  Takes effect for jobs uploaded afterwards. */
+int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32);
+
 /* generators = [Q1, H_1 .. H_L] (count = L+1 affine G1 points) and the api_id they belong to:
  * the `generators: &[E::G1]` and `api_id: &[u8]` arguments of every reference core_* function
  * (src/sign.rs:63-69, src/verify.rs:53-60, src/proof_gen.rs:116-125, src/proof_verify.rs:64-73). */
@@ -196,6 +205,12 @@ int bbs_hash_to_scalar_batch(bbs_ctx* ctx, size_t n, const uint8_t* msgs, const 
 int bbs_g1_msm_batch(bbs_ctx* ctx, size_t n, const uint8_t* fixed_scalars, size_t n_fixed,
                      const uint8_t* var_points, const uint8_t* var_scalars, size_t n_var,
                      uint8_t* out_affine, int8_t* status);
+/* out = sum_i scalars[i] * points[i]: one large variable-base multi-scalar multiplication over n per-item
+ * affine points by the bucket (Pippenger) method (the arkworks `VariableBaseMSM` shape; the reference itself
+ * only ever sums <= 38 terms per item, src/proof_verify.rs:163-182).  status[i] = 1, or -40 / -41 for an item
+ * that is not canonical / not on the curve (it then contributes nothing). */
+int bbs_g1_msm_pippenger(bbs_ctx* ctx, size_t n, const uint8_t* points_affine, const uint8_t* scalars,
+                         uint8_t* out_affine, int* out_is_identity, int8_t* status);
 /* status[i] = ( e(Pa[i], pk) * e(Pb[i], BP2) == 1 ) */
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_affine,
                                       const uint8_t* pb_affine, int8_t* status);

@@ -357,6 +357,103 @@ def check_primitives(curve, lib_path=None):
 
 
 # ------------------------------------------------------------------------------------------------
+def check_pippenger(curve, lib_path=None, n=40):
+    """One large variable-base sum by the device's bucket method against the oracle's plain sum, with the
+    cases that stress bucket accumulation: equal points in one bucket (doubling), P and -P in one bucket
+    (cancellation), identity points, scalars 0 / 1 / r-1, an off-curve point and a non-canonical scalar."""
+    rng = random.Random(21)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    eng = make_engine(curve, gens_for(suite, 2), b"x", lib_path)
+    pts = [c.g1_mul(c.g1, rng.randrange(1, 1 << 40)) for _ in range(n)]
+    sc = [rng.randrange(c.r) for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, c.r - 1
+    pts[3] = None
+    pts[5] = pts[4]; sc[5] = sc[4]                       # same point, same digits: doubling inside every bucket
+    pts[7] = c.g1_neg(pts[6]); sc[7] = sc[6]             # cancels inside every bucket
+    sc[8] = sc[9] = 0x0101010101010101010101010101010101010101010101010101010101010101 % c.r
+    got, st = eng.g1_msm_pippenger(pts, sc)
+    assert list(st) == [1] * n
+    want = None
+    for p_, k in zip(pts, sc):
+        want = c.g1_add(want, c.g1_mul(p_, k))
+    assert got == want, curve
+    # everything cancels -> identity; empty input -> identity
+    got, st = eng.g1_msm_pippenger([pts[6], pts[7]], [5, 5])
+    assert got is None and list(st) == [1, 1]
+    got, st = eng.g1_msm_pippenger([], [])
+    assert got is None
+    # flagged items contribute nothing
+    bad_pt = (pts[10][0], (pts[10][1] + 1) % c.p)
+    got, st = eng.g1_msm_pippenger([pts[10], bad_pt, pts[11], pts[12]], [3, 4, c.r, 7])
+    assert list(st) == [1, -41, -40, 1]
+    assert got == c.g1_add(c.g1_mul(pts[10], 3), c.g1_mul(pts[12], 7))
+    eng.close()
+
+
+def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
+    """Opt-in batch verification (one combined pairing check, per-item fallback) returns the same statuses as the
+    default per-item mode and the oracle: all-valid batch; items that fail before the pairing (they are left out of
+    the combination); a self-consistent proof of a forged signature (challenge matches, pairing fails: forces the
+    fallback); host-validation errors."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    exact = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    batch = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    batch.set_batch_verification(True, bytes(rng.randrange(256) for _ in range(32)))
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 3, 40]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = exact.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    proofs, st = exact.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    # 1. all valid
+    assert list(batch.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
+    # 2. failures before the pairing only: the combined check passes for the rest
+    bad = [to_engine_proof(p_) for p_ in proofs]
+    bad[1].e_cap = (bad[1].e_cap + 1) % c.r
+    bad[4].challenge = (bad[4].challenge + 1) % c.r
+    idx2 = [list(d) for d in disclosed]
+    idx2[6] = idx2[6] + [L]                                         # InvalidDisclosedIndex on the host
+    dm2 = [list(d) for d in dm]
+    dm2[6] = dm2[6] + [1]
+    want = list(exact.core_proof_verify_batch(bad, dm2, idx2, headers, phs))
+    assert want == [1, 0, 1, 1, 0, 1, -1, 1, 1][:n], want
+    assert list(batch.core_proof_verify_batch(bad, dm2, idx2, headers, phs)) == want
+    # 3. a proof generated from a forged signature: challenge matches, pairing product is not 1 -> fallback
+    forged = [Signature(s.a, s.e) for s in sigs]
+    forged[2] = Signature(c.g1_add(sigs[2].a, c.g1), sigs[2].e)
+    forged[7] = Signature(c.g1_mul(sigs[7].a, 2), sigs[7].e)
+    fp, st = exact.core_proof_gen_batch(forged, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    fp[3].a_bar = None                                               # identity Abar (bbs_over_bls_tests.rs:119-133)
+    want = list(exact.core_proof_verify_batch(fp, dm, disclosed, headers, phs))
+    assert want == [1, 1, 0, 0, 1, 1, 1, 0, 1][:n], want
+    assert list(batch.core_proof_verify_batch(fp, dm, disclosed, headers, phs)) == want
+    op = bbs.Proof(fp[2].a_bar, fp[2].b_bar, fp[2].d, fp[2].e_cap, fp[2].r1_cap, fp[2].r3_cap, fp[2].commitments, fp[2].challenge)
+    assert bbs.core_proof_verify(suite, pk, op, gens, headers[2], phs[2], dm[2], disclosed[2], api_id) is False
+    # 4. a resident job can be run again and a context can go back to the per-item mode
+    job = batch.core_proof_verify_upload(fp, dm, disclosed, headers, phs)
+    for _ in range(2):
+        job.run()
+        assert list(job.status()) == want
+    job.free()
+    batch.set_batch_verification(False)
+    assert list(batch.core_proof_verify_batch(fp, dm, disclosed, headers, phs)) == want
+    exact.close()
+    batch.close()
+
+
+# ------------------------------------------------------------------------------------------------
 def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0, device=0):
     """SURVEY 8d synthetic workload: one issuer key (IKM [1u8;32]), item b has L 32-byte messages
     derived from (b, j), empty header / ph, disclosed 0..R, proof_gen scalars from the seeded
@@ -396,6 +493,20 @@ def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2):
         proofs[i].commitments[0] = (proofs[i].commitments[0] + 1) % c.r
     st = eng.core_proof_verify_batch(proofs, dm, disclosed)
     assert [int(x) for x in st] == [0 if i % 16 == 0 else 1 for i in range(n)]
+    # the same two batches in batch-verification mode, then with one pairing-only failure (forged signature,
+    # self-consistent proof) that forces the per-item fallback over the whole batch
+    eng.set_batch_verification(True)
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+    assert [int(x) for x in st] == [0 if i % 16 == 0 else 1 for i in range(n)]
+    k = n // 2 + 1
+    fp, st = eng.core_proof_gen_batch([Signature(c.g1_add(sigs[k].a, c.g1), sigs[k].e)], [msgs[k]], [disclosed[k]], [rnds[k]])
+    assert st[0] == 1
+    good_k = proofs[k]
+    proofs[k] = fp[0]
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+    assert [int(x) for x in st] == [0 if (i % 16 == 0 or i == k) else 1 for i in range(n)]
+    proofs[k] = good_k
+    eng.set_batch_verification(False)
     for i in ([1, n - 1][:spot]):
         want_sig = bbs.core_sign(suite, sk, gens, b"", msgs[i], suite.api_id)
         assert (sigs[i].a, sigs[i].e) == (want_sig.a, want_sig.e)

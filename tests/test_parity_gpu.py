@@ -34,6 +34,16 @@ def test_primitives(curve):
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_pippenger(curve):
+    pc.check_pippenger(curve, None, n=200)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_batch_verification(curve):
+    pc.check_batch_verification(curve, None)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_full_batch_4096(curve):
     pc.check_big_batch(curve, None, n=4096, L=32, R=8)
 

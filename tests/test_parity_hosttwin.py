@@ -41,3 +41,13 @@ def test_error_semantics(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_primitives(twin, curve):
     pc.check_primitives(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_pippenger(twin, curve):
+    pc.check_pippenger(curve, twin, n=24)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_batch_verification(twin, curve):
+    pc.check_batch_verification(curve, twin)
