@@ -7,7 +7,7 @@
 // process onto 4 hardware queues unless told otherwise, and a long narrow kernel then blocks the streams sharing
 // its queue (measured on MI355X: 645k -> 780k proof_verify/s with 16 queues).  Takes effect only if this library
 // is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
-__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 // =============================================================================================
 // C ABI

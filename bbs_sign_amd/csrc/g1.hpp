@@ -150,12 +150,13 @@ BBS_HD uint32_t limb_bit(const uint32_t* s, int i) {
     return (s[i >> 5] >> (i & 31)) & 1u;
 }
 
+// Generic path (any on-curve P, small-order points included):
 // k * P for an affine P and a canonical 256-bit scalar: MSB-first double-and-add over the
 // non-adjacent form of k (digits in {-1,0,1}: digit_{i-1} = bit_i(3k) - bit_i(k)), mixed additions
 // of +-P.  ~256 doublings + ~85 additions; the group element equals ark-ec's
 // `Projective::mul_bigint` result (plain double-and-add in the reference).
 template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_naf(const G1Aff<C>& p, const uint32_t* k) {
     uint32_t h[9];
     uint64_t c = 0;
 #pragma unroll
@@ -179,6 +180,211 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
         }
     }
     return r;
+}
+
+// ---- regular fixed-window scalar multiplication ------------------------------------------------
+// On a GPU the 64 lanes of a wavefront run one instruction stream: with a sparse recoding (NAF) some lane needs
+// the addition at almost every bit, so the wavefront pays ~256 doublings + ~256 additions per multiplication.
+// Here every lane adds at the same 64 steps: k (made odd) is written with 64 ODD digits d_i in {+-1, .., +-15}
+// (u = (k >> 1) | 2^255, d_i = 2 * nibble_i(u) - 15), the table {1,3,..,15} P is built with 1 doubling + 7 mixed
+// additions and brought to ONE common Z, i.e. to affine points of the isomorphic curve y^2 = x^3 + b Z^6 on
+// which the whole loop then runs with mixed additions (the a = 0 formulas do not involve b); the result's Z is
+// multiplied by the common Z at the end.  ~252 doublings + 64 mixed additions + ~125 multiplications of set-up.
+// An even k is handled as (k + 1) P - P.  The group element is the one ark-ec's double-and-add produces.
+// Inputs for which the table would hit an exceptional case (identity, points of order < 16: on-curve points
+// outside the prime-order subgroup) take the generic path.
+
+// mixed addition that also returns Z3 / Z1 (= 2 H); false in an exceptional case
+template <class C>
+BBS_HD bool g1j_add_aff_zr(const G1Jac<C>& p, const G1Aff<C>& q, G1Jac<C>& r, Fp<C>& zr) {
+    Fp<C> Z1Z1 = G1SQR<FP>(p.z);
+    Fp<C> U2 = G1MUL<FP>(q.x, Z1Z1);
+    Fp<C> S2 = G1MUL<FP>(G1MUL<FP>(q.y, p.z), Z1Z1);
+    Fp<C> H = fe_sub<FP>(U2, p.x);
+    if (fe_is_zero<FP>(H)) return false;
+    Fp<C> rr = fe_lin<FP, 2, -2>(S2, p.y);
+    Fp<C> HH = G1SQR<FP>(H);
+    Fp<C> I = fe_scale<FP, 4>(HH);
+    Fp<C> J = G1MUL<FP>(H, I);
+    Fp<C> V = G1MUL<FP>(p.x, I);
+    r.x = fe_lin<FP, 1, -1, -2>(G1SQR<FP>(rr), J, V);
+    Fp<C> m = G1MUL<FP>(rr, fe_sub<FP>(V, r.x));
+    r.y = fe_lin<FP, 1, -2>(m, G1MUL<FP>(p.y, J));
+    r.z = fe_lin<FP, 1, -1, -1>(G1SQR<FP>(fe_add_nr<FP>(p.z, H)), Z1Z1, HH);
+    zr = fe_dbl<FP>(H);
+    return true;
+}
+
+constexpr int G1_TAB = 8;          // odd multiples 1, 3, .., 15
+
+// where a table lives: in the lane's private memory (one multiplication: 896 B of scratch for BLS12-381) or in
+// a caller-provided HBM buffer laid out [entry][word][item] (the three tables of a joint multiplication would be
+// 2.7 KB of scratch per lane; scratch is reserved per hardware queue for every wave slot of the chip, and 16
+// queues x 5.4 KB x 64 lanes x 8192 slots did not fit -- HSA_STATUS_ERROR_OUT_OF_RESOURCES)
+template <class C>
+struct TabPriv {
+    G1Aff<C> t[G1_TAB];
+    BBS_HD G1Aff<C> ld(uint32_t e) const { return t[e]; }
+    BBS_HD void st(uint32_t e, const G1Aff<C>& p) { t[e] = p; }
+};
+template <class C>
+struct TabHbm {
+    uint32_t* base;          // word w of entry e at base[(e * 2N + w) * stride]
+    size_t stride;
+    BBS_HD G1Aff<C> ld(uint32_t e) const {
+        constexpr int N = C::FpP::N;
+        G1Aff<C> p;
+        const uint32_t* b = base + (size_t)e * 2 * N * stride;
+#pragma unroll
+        for (int w = 0; w < N; w++) { p.x.v[w] = b[(size_t)w * stride]; p.y.v[w] = b[(size_t)(N + w) * stride]; }
+        return p;
+    }
+    BBS_HD void st(uint32_t e, const G1Aff<C>& p) {
+        constexpr int N = C::FpP::N;
+        uint32_t* b = base + (size_t)e * 2 * N * stride;
+#pragma unroll
+        for (int w = 0; w < N; w++) { b[(size_t)w * stride] = p.x.v[w]; b[(size_t)(N + w) * stride] = p.y.v[w]; }
+    }
+};
+
+// table of the odd multiples of P as affine points of the curve isomorphic by `zc` (point (x', y') there is the
+// Jacobian point (x', y', zc) here); false if P is the identity or an exceptional case occurred.
+// (Inlined into its caller: as a separate function writing the caller's private table through pointers it
+// faulted on MI355X with a memory aperture violation -- tools/repro_mul.py -- while the inlined form is clean.)
+template <class C, class T>
+BBS_HD bool g1_odd_table(const G1Aff<C>& p, T& tab, Fp<C>& zc) {
+    if (g1a_is_inf<C>(p)) return false;
+    const G1Jac<C> d = g1j_dbl<C>(G1Jac<C>{p.x, p.y, fe_one<FP>()});          // Z = 2 y != 0 (no 2-torsion)
+    const Fp<C> zd2 = fe_sqr<FP>(d.z), zd3 = fe_mul<FP>(zd2, d.z);
+    const G1Aff<C> dd = {d.x, d.y};                                            // 2P, affine on the curve scaled by d.z
+    G1Jac<C> cur = {fe_mul<FP>(p.x, zd2), fe_mul<FP>(p.y, zd3), fe_one<FP>()}; // P on that curve
+    Fp<C> zr[G1_TAB];
+    tab.st(0, G1Aff<C>{cur.x, cur.y});
+#pragma unroll 1
+    for (int j = 1; j < G1_TAB; j++) {
+        G1Jac<C> nxt;
+        if (!g1j_add_aff_zr<C>(cur, dd, nxt, zr[j])) return false;
+        cur = nxt;
+        tab.st(j, G1Aff<C>{cur.x, cur.y});                                     // (2j+1) P with Z_j; rescaled below
+    }
+    Fp<C> sc = zr[G1_TAB - 1];                                                 // Z_7 / Z_j
+#pragma unroll 1
+    for (int j = G1_TAB - 2; j >= 0; j--) {
+        const Fp<C> s2 = fe_sqr<FP>(sc);
+        const G1Aff<C> e = tab.ld(j);
+        tab.st(j, G1Aff<C>{fe_mul<FP>(e.x, s2), fe_mul<FP>(fe_mul<FP>(e.y, s2), sc)});
+        if (j) sc = fe_mul<FP>(sc, zr[j]);
+    }
+    zc = fe_mul<FP>(cur.z, d.z);
+    return true;
+}
+
+// u = ((k | 1) >> 1) | 2^255 : nibble i of u gives the odd digit d_i = 2 U - 15
+BBS_HD void g1_recode(const uint32_t* k, uint32_t* u) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) u[i] = (k[i] >> 1) | (k[i + 1] << 31);
+    u[7] = (k[7] >> 1) | 0x80000000u;
+}
+template <class C, class T>
+BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U) {
+    const bool neg = U < 8;
+    G1Aff<C> q = tab.ld(neg ? 7u - U : U - 8u);
+    q.y = fe_select<FP>(neg, fe_neg<FP>(q.y), q.y);
+    return q;
+}
+
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
+#ifdef BBS_G1_MUL_NAF
+    return g1_mul_aff_naf<C>(p, k);
+#endif
+    TabPriv<C> tab;
+    Fp<C> zc;
+    if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
+    uint32_t u[8];
+    g1_recode(k, u);
+    const bool even = (k[0] & 1u) == 0;
+    G1Jac<C> r = g1j_from_aff<C>(g1_tab_digit<C>(tab, u[7] >> 28));
+#pragma unroll 1
+    for (int i = 62; i >= -1; i--) {
+        G1Aff<C> q;
+        if (i >= 0) {
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+            q = g1_tab_digit<C>(tab, (u[i >> 3] >> (4 * (i & 7))) & 15u);
+        } else {
+            q = even ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();       // (k + 1) P - P
+        }
+        r = g1j_add_aff<C>(r, q);
+    }
+    r.z = fe_mul<FP>(r.z, zc);
+    return r;
+}
+
+// k0 P0 + k1 P1 + k2 P2 on ONE shared doubling chain (Straus): the three tables are brought to one common curve
+// (scale of table j times the other two tables' scales), ~252 doublings + 3 * 64 mixed additions.
+// The tables live in the caller's HBM buffer `tabs` (3 * G1_TAB * 2N words, stride apart).
+// Returns false (out untouched) when a table hit an exceptional case: the caller then sums three separate
+// multiplications (done there, not here, so that the rare path does not deepen this function's stack).
+template <class C>
+BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
+                                       const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, G1Jac<C>& out) {
+#ifdef BBS_G1_MUL_NAF
+    return false;
+#endif
+    constexpr int N = C::FpP::N;
+    Fp<C> zc[3];
+    const G1Aff<C>* ps[3] = {&p0, &p1, &p2};
+    bool ok = true;
+#pragma unroll 1
+    for (int j = 0; j < 3; j++) {
+        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        ok = ok && g1_odd_table<C>(*ps[j], tab, zc[j]);
+    }
+    if (!ok) return false;
+    // point (x, y) of table j is Jacobian (x, y, zc_j) = (x t^2, y t^3, zc_0 zc_1 zc_2) with t = product of the other two
+    const Fp<C> z01 = fe_mul<FP>(zc[0], zc[1]);
+    const Fp<C> t[3] = {fe_mul<FP>(zc[1], zc[2]), fe_mul<FP>(zc[0], zc[2]), z01};
+    const Fp<C> zall = fe_mul<FP>(z01, zc[2]);
+#pragma unroll 1
+    for (int j = 0; j < 3; j++) {
+        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        const Fp<C> t2 = fe_sqr<FP>(t[j]), t3 = fe_mul<FP>(t2, t[j]);
+#pragma unroll 1
+        for (int e = 0; e < G1_TAB; e++) {
+            const G1Aff<C> q = tab.ld(e);
+            tab.st(e, G1Aff<C>{fe_mul<FP>(q.x, t2), fe_mul<FP>(q.y, t3)});
+        }
+    }
+    uint32_t u[3][8];
+    g1_recode(k0, u[0]); g1_recode(k1, u[1]); g1_recode(k2, u[2]);
+    const bool even[3] = {(k0[0] & 1u) == 0, (k1[0] & 1u) == 0, (k2[0] & 1u) == 0};
+    G1Jac<C> r = g1j_inf<C>();
+#pragma unroll 1
+    for (int i = 63; i >= -1; i--) {
+        if (i >= 0 && i < 63) {
+#pragma unroll 1
+            for (int s = 0; s < 4; s++) r = g1j_dbl<C>(r);
+        }
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {
+            const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+            G1Aff<C> q;
+            if (i >= 0) q = g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
+            else q = even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+            r = g1j_add_aff<C>(r, q);
+        }
+    }
+    r.z = fe_mul<FP>(r.z, zall);
+    out = r;
+    return true;
+}
+template <class C>
+BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
+                             const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride) {
+    G1Jac<C> r;
+    if (g1_mul3_aff_fast<C>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
+    return g1j_add<C>(g1j_add<C>(g1_mul_aff<C>(p0, k0), g1_mul_aff<C>(p1, k1)), g1_mul_aff<C>(p2, k2));
 }
 
 #undef FP

@@ -228,7 +228,7 @@ __host__ __device__ inline void g1j_to_aff2(const G1Jac<C>& a, const G1Jac<C>& b
 // =============================================================================================
 // proof_verify
 // =============================================================================================
-constexpr int PV_NVAR = 4;                    // c*Bbar, e^*Abar, r1^*D, r3^*D
+constexpr int PV_NVAR = 2;                    // (c*Bbar + e^*Abar + r1^*D) jointly, r3^*D
 constexpr int PV_NPARTS = PV_NVAR + NFIX;
 
 template <class C>
@@ -252,6 +252,7 @@ struct PvArgs {
     uint32_t* partials;       // [PV_NPARTS][3N][n] Jacobian
     uint32_t* aff;            // [5][2N][n] Montgomery affine: a_bar, b_bar, d, T1, T2
     uint32_t* fmiller;        // [2][12N][n]
+    uint32_t* vtab;           // [3][G1_TAB][2N][n] window tables of the joint multiplication (g1.hpp)
 };
 
 // stage 1 (lane per item): domain, fixed-base scalars
@@ -289,18 +290,27 @@ struct PvMsmPart {
         const size_t i = t - (size_t)part * n;
         if (a.status[i] < 0) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
-        if (part < PV_NVAR) {
-            // part: 0 c*Bbar | 1 e^*Abar | 2 r1^*D | 3 r3^*D
-            const int pt = (part == 0) ? 1 : (part == 1) ? 0 : 2;
-            const int scw = (part == 0) ? 3 : (part == 1) ? 0 : (part == 2) ? 1 : 2;
-            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * C::FpP::NC * n, n, i);
-            if (part < 3) {
-                if (!g1a_on_curve<C>(p)) { a.status[i] = -41; return; }
-                g1a_store_mont<C>(a.aff + (size_t)pt * 2 * N * n, n, i, p);
-            }
+        if (part == 0) {
+            // T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain
+            constexpr int NC = C::FpP::NC;
+            G1Aff<C> pa = g1a_load_canon_to_mont<C>(a.pts, n, i);
+            G1Aff<C> pb = g1a_load_canon_to_mont<C>(a.pts + (size_t)2 * NC * n, n, i);
+            G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * NC * n, n, i);
+            if (!g1a_on_curve<C>(pa) || !g1a_on_curve<C>(pb) || !g1a_on_curve<C>(pd)) { a.status[i] = -41; return; }
+            g1a_store_mont<C>(a.aff, n, i, pa);
+            g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, pb);
+            g1a_store_mont<C>(a.aff + (size_t)4 * N * n, n, i, pd);
+            uint32_t kc[8], ke[8], k1[8];
+            soa_ld<8>(a.sc + (size_t)3 * 8 * n, n, i, kc);
+            soa_ld<8>(a.sc, n, i, ke);
+            soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
+            g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n));
+        } else if (part == 1) {
+            // r3^*D, the variable-base term of T2 (proof_verify.rs:175-182)
+            G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * C::FpP::NC * n, n, i);
             uint32_t k[8];
-            soa_ld<8>(a.sc + (size_t)scw * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+            soa_ld<8>(a.sc + (size_t)2 * 8 * n, n, i, k);
+            g1j_store<C>(out, n, i, g1_mul_aff<C>(pd, k));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - PV_NVAR));
         }
@@ -315,8 +325,8 @@ struct PvChallenge {
         const size_t n = a.n;
         if (a.status[i] < 0) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
-        G1Jac<C> t1 = g1j_add<C>(g1j_add<C>(part(0), part(1)), part(2));
-        G1Jac<C> t2 = part(3);
+        G1Jac<C> t1 = part(0);
+        G1Jac<C> t2 = part(1);
         for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(PV_NVAR + f));
         G1Aff<C> T1, T2;
         g1j_to_aff2<C>(t1, t2, T1, T2);

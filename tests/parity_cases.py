@@ -232,9 +232,11 @@ def check_random_batch(curve, lib_path=None, n=6, L=5, seed=1):
             p.commitments[-1] = (p.commitments[-1] + 5) % c.r; expect[i] = 0
         elif k == 4:
             p.d = c.g1_add(p.d, c.g1); expect[i] = 0
+        elif k == 5 and curve == "bls12_381":
+            p.d = (0, 2); expect[i] = 0                                    # on the curve, order 3: generic multiplication path
     st = eng.core_proof_verify_batch(bad, dm, disclosed, headers, phs)
     assert list(st) == expect, (curve, list(st), expect)
-    for i in range(min(n, 2)):
+    for i in sorted(set(range(min(n, 2))) | ({5} if n > 5 else set())):
         op = bbs.Proof(bad[i].a_bar, bad[i].b_bar, bad[i].d, bad[i].e_cap, bad[i].r1_cap, bad[i].r3_cap,
                        bad[i].commitments, bad[i].challenge)
         assert bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], disclosed[i], api_id) == bool(expect[i])
@@ -346,6 +348,28 @@ def check_primitives(curve, lib_path=None):
         for k in range(2):
             want = c.g1_add(want, c.g1_mul(vpts[i][k], vsc[i][k]))
         assert out[i] == want, (curve, i)
+    if curve == "bls12_381":
+        # on-curve points OUTSIDE the prime-order subgroup, small orders included: the windowed scalar multiplication
+        # must give the plain group-law result (its table set-up falls back to the generic path for orders < 16)
+        h = 0x396c8c005555e1568c00aaab0000aaab
+        x = 5
+        while True:
+            y2 = (x ** 3 + 4) % c.p
+            y = pow(y2, (c.p + 1) // 4, c.p)
+            if y * y % c.p == y2 and c.g1_mul((x, y), c.r) is not None:
+                break
+            x += 1
+        Q = (x, y)
+        odd = [(0, 2), c.g1_mul(Q, c.r * (h // 11)), c.g1_mul(Q, c.r * (h // 33)), c.g1_mul(Q, c.r * (h // (3 * 11 * 11))), Q,
+               c.g1_mul(Q, c.r)]
+        assert c.g1_mul(odd[0], 3) is None and c.g1_mul(odd[1], 11) is None and c.g1_mul(odd[2], 33) is None
+        vp = [[pt, c.g1_mul(c.g1, 7)] for pt in odd]
+        vk = [[rng.randrange(c.r), rng.randrange(c.r)] for _ in odd]
+        vk[1][0] = 22; vk[2][0] = c.r - 1
+        out, st = eng.g1_msm_batch([[0] * (L + 2)] * len(odd), vp, vk)
+        assert list(st) == [1] * len(odd)
+        for i in range(len(odd)):
+            assert out[i] == c.g1_add(c.g1_mul(vp[i][0], vk[i][0]), c.g1_mul(vp[i][1], vk[i][1])), ("odd-order point", i)
     # pairing product e(Pa, pk) * e(Pb, BP2) == 1
     a = rng.randrange(1, c.r)
     Pa = [c.g1_mul(c.g1, a), c.g1_mul(c.g1, a), None, None, c.g1]
