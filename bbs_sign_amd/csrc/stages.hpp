@@ -34,6 +34,9 @@ constexpr int MAX_DST = 255;
 #ifndef BBS_PAIR_WAVES
 #define BBS_PAIR_WAVES 4
 #endif
+#ifndef BBS_MSM_WAVES
+#define BBS_MSM_WAVES 1          // multi-scalar-multiplication stages (2 and 3 measured: no gain, spills)
+#endif
 
 // ---- context constants resident in HBM ------------------------------------------------------
 struct HashCtx {
@@ -283,6 +286,7 @@ struct PvScalars {
 // stage 2 (lane per (part, item)): MSM parts
 template <class C>
 struct PvMsmPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const PvArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -570,6 +574,7 @@ struct VfScalars {
 
 template <class C>
 struct VfMsmPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const VfArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -663,6 +668,7 @@ struct SgScalars {
 
 template <class C>
 struct SgMsmPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const SgArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -770,6 +776,7 @@ struct PgScalars {
 // lane per (chunk, item): B = P1 + Q1*domain + sum H_j m_j
 template <class C>
 struct PgBPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -798,6 +805,7 @@ struct PgBCombine {
 
 template <class C>
 struct PgMsmPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -922,6 +930,7 @@ struct MsmArgs {
 
 template <class C>
 struct MsmPart {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const MsmArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
