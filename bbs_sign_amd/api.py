@@ -9,9 +9,8 @@ call -- create_generators (33 hash-to-curve operations at L = 32) and the api_id
 computed once per (ciphersuite, L) by the host side of the library (bbs_create_generators) and kept
 in an engine context; msg_to_scalars runs on the device (bbs_hash_to_scalar_batch).
 
-BLS12-381 only at this level: the BN254 hash-to-curve backend of the reference (crate
-bn254_hash2curve, SvdW) is not restated; BN254 is served at the core_* level (bbs_sign_amd.Engine)
-with caller-supplied generators, as the reference's own core tests do.
+Both ciphersuites of the reference (src/constants.rs): BLS12-381 (simplified SWU hash-to-curve) and BN254
+(Shallue-van de Woestijne, restated from RFC 9380 and pinned by the reference's P1 constant).
 """
 from __future__ import annotations
 
@@ -50,8 +49,6 @@ def create_generators(curve: str, count: int, lib_path: Optional[str] = None) ->
         aid = _bytes_arr(api_id(curve))
         out = np.zeros(max(count, 1) * 2 * fpb, dtype=np.uint8)
         rc = lib.bbs_create_generators(0 if curve == "bls12_381" else 1, count, _u8(aid), len(api_id(curve)), _u8(out))
-        if rc == -106:
-            raise NotImplementedError("create_generators for %s (SvdW hash-to-curve is not restated)" % curve)
         if rc:
             raise BbsRuntimeError(rc, "bbs_create_generators")
         b = out.tobytes()
@@ -137,6 +134,21 @@ class SecretKey:
         """SecretKey::sign (src/sign.rs:32-60)."""
         eng = _engine(self.curve, len(messages), sk=self.sk, device=self.device, lib_path=self.lib_path)
         return eng.core_sign(header, msg_to_scalars(eng, self.curve, messages))
+
+
+def hash_to_g1(curve: str, msg: bytes, dst: bytes, lib_path: Optional[str] = None):
+    """The suite's hash-to-G1 (src/utils/interface_utilities.rs:24-44), host side of the library."""
+    lib = _lib.load_library(lib_path)
+    cid = 0 if curve == "bls12_381" else 1
+    fpb = int(lib.bbs_fp_bytes(cid))
+    out = np.zeros(2 * fpb, dtype=np.uint8)
+    m, d = _bytes_arr(msg), _bytes_arr(dst)
+    rc = lib.bbs_hash_to_g1(cid, _u8(m), len(msg), _u8(d), len(dst), _u8(out))
+    if rc:
+        raise BbsRuntimeError(rc, "bbs_hash_to_g1")
+    b = out.tobytes()
+    x, y = int.from_bytes(b[:fpb], "little"), int.from_bytes(b[fpb:], "little")
+    return None if x == 0 and y == 0 else (x, y)
 
 
 def calculate_random_scalars(curve: str, count: int) -> List[int]:

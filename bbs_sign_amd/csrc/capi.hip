@@ -16,6 +16,30 @@ __attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_M
 #define AS_BLS(ctx) static_cast<Ctx<BlsCurve>*>(ctx)
 #define AS_BN(ctx) static_cast<Ctx<BnCurve>*>(ctx)
 
+// ---- host-side helpers shared by both curves --------------------------------------------------
+template <class C>
+static int create_generators_out(size_t count, const uint8_t* api_id, size_t api_id_len, uint8_t* out_affine) {
+    constexpr size_t FPB = 4 * C::FpP::NC;
+    std::vector<G1Aff<C>> g;
+    if (create_generators_host<C>(count, api_id, api_id_len, g)) return BBS_ST_PANIC_DST_TOO_LONG;
+    for (size_t k = 0; k < count; k++) {
+        if (g1a_is_inf<C>(g[k])) { std::memset(out_affine + k * 2 * FPB, 0, 2 * FPB); continue; }
+        fe_to_le_bytes<typename C::FpP>(g[k].x, out_affine + k * 2 * FPB);
+        fe_to_le_bytes<typename C::FpP>(g[k].y, out_affine + k * 2 * FPB + FPB);
+    }
+    return BBS_OK;
+}
+template <class C>
+static int hash_to_g1_out(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out_affine) {
+    constexpr size_t FPB = 4 * C::FpP::NC;
+    bool ok = true;
+    G1Aff<C> p = H2cOf<C>::run(msg, msg_len, dst, dst_len, ok);
+    if (!ok) return BBS_ST_PANIC_DST_TOO_LONG;
+    if (g1a_is_inf<C>(p)) { std::memset(out_affine, 0, 2 * FPB); return BBS_OK; }
+    fe_to_le_bytes<typename C::FpP>(p.x, out_affine);
+    fe_to_le_bytes<typename C::FpP>(p.y, out_affine + FPB);
+    return BBS_OK;
+}
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -281,27 +305,16 @@ int bbs_g1_msm_pippenger(bbs_ctx* ctx, size_t n, const uint8_t* pts, const uint8
 // ---- host-side setup helpers (once per ciphersuite / key; no GPU involved) ---------------------
 int bbs_create_generators(int curve, size_t count, const uint8_t* api_id, size_t api_id_len, uint8_t* out_affine) {
     if ((api_id_len && !api_id) || (count && !out_affine)) return BBS_E_ARG;
-    if (curve != BBS_CURVE_BLS12_381) return BBS_E_UNSUPPORTED;      // BN254 SvdW (bn254_hash2curve) not restated
-    std::vector<G1Aff<BlsCurve>> g;
-    if (create_generators_bls(count, api_id, api_id_len, g)) return BBS_ST_PANIC_DST_TOO_LONG;
-    for (size_t k = 0; k < count; k++) {
-        if (g1a_is_inf<BlsCurve>(g[k])) { std::memset(out_affine + k * 96, 0, 96); continue; }
-        fe_to_le_bytes<BlsFpParams>(g[k].x, out_affine + k * 96);
-        fe_to_le_bytes<BlsFpParams>(g[k].y, out_affine + k * 96 + 48);
-    }
-    return BBS_OK;
+    if (curve == BBS_CURVE_BLS12_381) return create_generators_out<BlsCurve>(count, api_id, api_id_len, out_affine);
+    if (curve == BBS_CURVE_BN254) return create_generators_out<BnCurve>(count, api_id, api_id_len, out_affine);
+    return BBS_E_ARG;
 }
 
 int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out_affine) {
     if ((msg_len && !msg) || (dst_len && !dst) || !out_affine) return BBS_E_ARG;
-    if (curve != BBS_CURVE_BLS12_381) return BBS_E_UNSUPPORTED;
-    bool ok = true;
-    G1Aff<BlsCurve> p = h2c::hash_to_g1(msg, msg_len, dst, dst_len, ok);
-    if (!ok) return BBS_ST_PANIC_DST_TOO_LONG;
-    if (g1a_is_inf<BlsCurve>(p)) { std::memset(out_affine, 0, 96); return BBS_OK; }
-    fe_to_le_bytes<BlsFpParams>(p.x, out_affine);
-    fe_to_le_bytes<BlsFpParams>(p.y, out_affine + 48);
-    return BBS_OK;
+    if (curve == BBS_CURVE_BLS12_381) return hash_to_g1_out<BlsCurve>(msg, msg_len, dst, dst_len, out_affine);
+    if (curve == BBS_CURVE_BN254) return hash_to_g1_out<BnCurve>(msg, msg_len, dst, dst_len, out_affine);
+    return BBS_E_ARG;
 }
 
 // SecretKey::key_gen (src/key_gen.rs:46-81)

@@ -6,9 +6,11 @@
 // crate is not vendored; this is the RFC algorithm with the 11-isogeny evaluated by Velu's formula
 // (constants: tools/gen_params.py), pinned by the reference's generator vectors
 // (src/tests/test_vector.rs:66-68,123-136) in tests/test_public_api.py.
+// BN254 (interface_utilities.rs:24-28, crate bn254_hash2curve 0.1.2, not vendored): RFC 9380 hash_to_curve with
+// the Shallue-van de Woestijne map, Z = 1, L = 48, cofactor 1 -- pinned by the reference's one BN254 known answer,
+// P1 of src/constants.rs:39-51 (tests/test_oracle_kat.py, tests/test_public_api.py).
 // Per-call in the reference (sign.rs:49, verify.rs:35, proof_gen.rs:98, proof_verify.rs:40-43);
-// here the result is computed once and lives in a context.  BN254 (SvdW, crate bn254_hash2curve)
-// is not restated: BBS_E_UNSUPPORTED.
+// here the result is computed once and lives in a context.
 #pragma once
 #include <cstring>
 #include <vector>
@@ -169,8 +171,97 @@ inline G1Aff<C> hash_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* ds
 
 }  // namespace h2c
 
+namespace h2c_bn {
+
+using P = BnFpParams;
+using F = Fe<P>;
+using C = BnCurve;
+
+inline F fconst(const uint32_t* w) { F r; for (int i = 0; i < P::N; i++) r.v[i] = w[i]; return r; }
+
+inline F from_be_bytes_mod(const uint8_t* b, size_t len) {              // Horner over 16-byte chunks
+    uint32_t w[P::NC] = {0};
+    w[4] = 1;
+    const F two128 = fe_from_words<P>(w);
+    F acc = fe_zero<P>();
+    for (size_t off = 0; off < len; off += 16) {
+        uint32_t c[P::NC] = {0};
+        for (size_t k = 0; k < 16; k++) {
+            const size_t bitpos = 8 * (15 - k);
+            c[bitpos / 32] |= (uint32_t)b[off + k] << (bitpos % 32);
+        }
+        acc = fe_add<P>(fe_mul<P>(acc, two128), fe_from_words<P>(c));
+    }
+    return acc;
+}
+inline F pow_words(const F& a, const uint32_t* e, int nw) {
+    F r = fe_one<P>();
+    for (int i = nw - 1; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            r = fe_sqr<P>(r);
+            if ((e[i] >> b) & 1) r = fe_mul<P>(r, a);
+        }
+    return r;
+}
+inline bool sqrt_fp(const F& a, F& out) {                                // p = 3 mod 4
+    out = pow_words(a, BnSvdw::SQRT_EXP, 8);
+    return fe_eq<P>(fe_sqr<P>(out), a);
+}
+inline uint32_t sgn0(const F& a) {
+    uint32_t w[P::NC];
+    fe_to_words<P>(a, w);
+    return w[0] & 1u;
+}
+inline F g(const F& x) { return fe_add<P>(fe_mul<P>(fe_sqr<P>(x), x), curve_b<C>()); }
+
+// RFC 9380 6.6.1 (straight-line Shallue-van de Woestijne)
+inline G1Aff<C> map_to_curve_svdw(const F& u) {
+    const F Z = fconst(BnSvdw::Z_M), c1 = fconst(BnSvdw::C1_M), c2 = fconst(BnSvdw::C2_M), c3 = fconst(BnSvdw::C3_M),
+            c4 = fconst(BnSvdw::C4_M), one = fe_one<P>();
+    F tv1 = fe_mul<P>(fe_sqr<P>(u), c1);
+    const F tv2 = fe_add<P>(one, tv1);
+    tv1 = fe_sub<P>(one, tv1);
+    const F t12 = fe_mul<P>(tv1, tv2);
+    const F tv3 = fe_is_zero<P>(t12) ? fe_zero<P>() : fe_inv<P>(t12);    // inv0
+    const F tv4 = fe_mul<P>(fe_mul<P>(fe_mul<P>(u, tv1), tv3), c3);
+    const F x1 = fe_sub<P>(c2, tv4), x2 = fe_add<P>(c2, tv4);
+    F x3 = fe_mul<P>(fe_sqr<P>(tv2), tv3);
+    x3 = fe_add<P>(fe_mul<P>(fe_sqr<P>(x3), c4), Z);
+    F y, x = x1;
+    if (!sqrt_fp(g(x1), y)) {
+        x = x2;
+        if (!sqrt_fp(g(x2), y)) {
+            x = x3;
+            const bool ok = sqrt_fp(g(x3), y);
+            (void)ok;
+        }
+    }
+    if (sgn0(u) != sgn0(y)) y = fe_neg<P>(y);
+    return {x, y};
+}
+
+inline G1Aff<C> hash_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, bool& ok) {
+    std::vector<uint8_t> uni;
+    ok = expand_message_host(msg, msg_len, dst, dst_len, 96, uni);
+    if (!ok) return g1a_inf<C>();
+    const G1Aff<C> q0 = map_to_curve_svdw(from_be_bytes_mod(uni.data(), 48));
+    const G1Aff<C> q1 = map_to_curve_svdw(from_be_bytes_mod(uni.data() + 48, 48));
+    return g1j_to_aff<C>(g1j_add_aff<C>(g1j_from_aff<C>(q0), q1));       // cofactor 1
+}
+
+}  // namespace h2c_bn
+
+template <class C> struct H2cOf;
+template <> struct H2cOf<BlsCurve> {
+    static G1Aff<BlsCurve> run(const uint8_t* m, size_t ml, const uint8_t* d, size_t dl, bool& ok) { return h2c::hash_to_g1(m, ml, d, dl, ok); }
+};
+template <> struct H2cOf<BnCurve> {
+    static G1Aff<BnCurve> run(const uint8_t* m, size_t ml, const uint8_t* d, size_t dl, bool& ok) { return h2c_bn::hash_to_g1(m, ml, d, dl, ok); }
+};
+
 // create_generators (interface_utilities.rs:47-73).  0 ok, -1 dst too long (reference panics)
-inline int create_generators_bls(size_t count, const uint8_t* api_id, size_t api_id_len, std::vector<G1Aff<BlsCurve>>& out) {
+template <class C>
+inline int create_generators_host(size_t count, const uint8_t* api_id, size_t api_id_len, std::vector<G1Aff<C>>& out) {
     auto cat = [&](const char* suf) {
         std::vector<uint8_t> v(api_id, api_id + api_id_len);
         v.insert(v.end(), suf, suf + std::strlen(suf));
@@ -187,7 +278,7 @@ inline int create_generators_bls(size_t count, const uint8_t* api_id, size_t api
         for (int b = 7; b >= 0; b--) m.push_back((uint8_t)(idx >> (8 * b)));
         if (!expand_message_host(m.data(), m.size(), seed_dst.data(), seed_dst.size(), 48, v)) return -1;
         bool ok = true;
-        out.push_back(h2c::hash_to_g1(v.data(), v.size(), gen_dst.data(), gen_dst.size(), ok));
+        out.push_back(H2cOf<C>::run(v.data(), v.size(), gen_dst.data(), gen_dst.size(), ok));
         if (!ok) return -1;
     }
     return 0;

@@ -67,7 +67,7 @@ extern "C" {
 #define BBS_E_PUBLIC_KEY (-103)  /* public key not on the twist or not of order r */
 #define BBS_E_NO_DEVICE (-104)
 #define BBS_E_NOMEM (-105)
-#define BBS_E_UNSUPPORTED (-106) /* BN254 hash-to-curve (SvdW, crate bn254_hash2curve) is not restated */
+#define BBS_E_UNSUPPORTED (-106) /* reserved: operation not available for this curve */
 
 typedef struct bbs_ctx bbs_ctx;
 typedef struct bbs_job bbs_job;
@@ -218,8 +218,9 @@ int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_
 /* ------------------------------------------------------------------------------------------
  * Host-side setup helpers: once per ciphersuite / key, no GPU involved.
  * ------------------------------------------------------------------------------------------ */
-/* create_generators (src/utils/interface_utilities.rs:47-73) with the reference's BLS12-381
- * hash-to-curve backend (:30-44); out = count affine G1 points.  The reference recomputes this on
+/* create_generators (src/utils/interface_utilities.rs:47-73) with the curve's hash-to-curve backend
+ * (:24-44: BLS12-381 simplified SWU + 11-isogeny; BN254 Shallue-van de Woestijne, pinned by P1 of
+ * src/constants.rs:39-51); out = count affine G1 points.  The reference recomputes this on
  * every sign / verify / proof_gen / proof_verify call; callers cache it per (api_id, count). */
 int bbs_create_generators(int curve, size_t count, const uint8_t* api_id, size_t api_id_len,
                           uint8_t* out_affine);

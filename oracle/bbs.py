@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 from .curves import BLS12_381, BN254, Curve
-from .hashing import expand_message, from_okm, hash_to_g1_bls, hash_to_scalar, i2osp
+from .hashing import expand_message, from_okm, hash_to_g1_bls, hash_to_g1_bn, hash_to_scalar, i2osp
 
 
 class BbsError(Exception):
@@ -159,11 +159,8 @@ _GEN_CACHE = {}
 
 
 def create_generators(suite: Suite, count: int, api_id: bytes):
-    """src/utils/interface_utilities.rs:47-73.  BLS12-381 only (the BN254 SvdW map of
-    bn254_hash2curve 0.1.2 is outside this path; BN254 callers supply generators, as
-    src/tests/core_sign_tests.rs:51 does at the core_* level)."""
-    if suite.curve.name != "bls12_381":
-        raise NotImplementedError("BN254 hash-to-curve (SvdW) is not restated")
+    """src/utils/interface_utilities.rs:47-73 with the suite's hash-to-G1 (:24-44)."""
+    h2g = hash_to_g1_bls if suite.curve.name == "bls12_381" else hash_to_g1_bn
     key = (suite.curve.name, api_id)
     have = _GEN_CACHE.setdefault(key, {"v": None, "gens": []})
     seed_dst = api_id + b"SIG_GENERATOR_SEED_"
@@ -174,7 +171,7 @@ def create_generators(suite: Suite, count: int, api_id: bytes):
     while len(have["gens"]) < count:
         i = len(have["gens"])
         have["v"] = expand_message(have["v"] + i2osp(i + 1, 8), seed_dst, 48)
-        have["gens"].append(hash_to_g1_bls(have["v"], generator_dst))
+        have["gens"].append(h2g(have["v"], generator_dst))
     return list(have["gens"][:count])
 
 

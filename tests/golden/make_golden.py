@@ -82,6 +82,16 @@ def main():
             })
             print(name, "case", ci, "L", L, "ok", flush=True)
         doc["suites"][name] = entry
+    # BN254 create_generators (Shallue-van de Woestijne hash-to-G1, pinned by the reference's P1 constant):
+    # the first 11 generators of the ciphersuite, and P1 re-derived from its seed
+    bn = bbs.BN_SUITE
+    g = bbs.create_generators(bn, 11, bn.api_id)
+    v = expand_message(bn.api_id + b"BP_MESSAGE_GENERATOR_SEED", bn.api_id + b"SIG_GENERATOR_SEED_", 48)
+    v = expand_message(v + i2osp(1, 8), bn.api_id + b"SIG_GENERATOR_SEED_", 48)
+    from oracle.hashing import hash_to_g1_bn
+    assert hash_to_g1_bn(v, bn.api_id + b"SIG_GENERATOR_DST_") == bn.p1
+    doc["bn254_create_generators"] = {"api_id": bn.api_id.hex(), "generators": [pt(bn.curve, x) for x in g],
+                                      "p1": pt(bn.curve, bn.p1)}
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=0)
     print("wrote", OUT)

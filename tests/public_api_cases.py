@@ -30,6 +30,22 @@ def check_create_generators_kat(lib_path=None):      # test_vector.rs:123-136 (h
     for i, h in want.items():
         assert bbs.g1_compress(C, g[i]).hex() == h
     assert g == bbs.create_generators(S, 11, S.api_id)
+    # BN254: the reference's one known answer -- P1 (constants.rs:39-51) is the first generator under the seed
+    # "...BP_MESSAGE_GENERATOR_SEED" -- through the library's host code, and the generators against the oracle
+    from oracle.hashing import expand_message, i2osp
+    bn = bbs.BN_SUITE
+    v = expand_message(bn.api_id + b"BP_MESSAGE_GENERATOR_SEED", bn.api_id + b"SIG_GENERATOR_SEED_", 48)
+    v = expand_message(v + i2osp(1, 8), bn.api_id + b"SIG_GENERATOR_SEED_", 48)
+    assert api.hash_to_g1("bn254", v, bn.api_id + b"SIG_GENERATOR_DST_", lib_path) == bn.p1
+    assert api.create_generators("bn254", 6, lib_path) == bbs.create_generators(bn, 6, bn.api_id)
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bbs_golden.json")) as f:
+        gold = json.load(f)["bn254_create_generators"]
+    assert api.create_generators("bn254", 11, lib_path) == [(int(x, 16), int(y, 16)) for x, y in gold["generators"]]
+    msgs = [b"", b"a", bytes(range(200))]
+    for m in msgs:
+        assert api.hash_to_g1("bn254", m, b"QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_", lib_path) == \
+            __import__("oracle.hashing", fromlist=["x"]).hash_to_g1_bn(m, b"QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_")
 
 
 def check_key_gen_kat(lib_path=None):                 # test_vector.rs:139-160, key_gen.rs:127-216
@@ -71,9 +87,33 @@ CASES = [(0, [], b""), (0, [], b"abc"), (1, [0], b"abc"), (1, [], b"abc"), (10, 
          (10, [0, 4, 7, 9], b"def"), (5, [0, 4], b"defghjsdjdbcjbejd"), (5, [0, 1, 2, 3, 4], b"def")]
 
 
-def check_round_trips(lib_path=None, cases=CASES):    # bbs_over_bls_tests.rs:41-84
+def check_readme_example_bn254(lib_path=None):          # README.md:64-128, BASELINE.json configs[0]
+    """The reference's README flow on BN254: key_gen from IKM [5; 32], 4 messages, sign -> verify -> proof_gen ->
+    proof_verify, every output against the oracle's public interface."""
+    suite = bbs.BN_SUITE
+    msgs = [b"message1", b"message2", b"msg3", b"msg4"]
+    sk = api.SecretKey.key_gen("bn254", bytes([5] * 32), b"", b"BBS-SIG-KEYGEN-SALT-", lib_path)
+    assert sk.sk == bbs.key_gen(suite, bytes([5] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
+    pk = sk.sk_to_pk()
+    assert pk.pk == bbs.sk_to_pk(suite, sk.sk)
+    sig = sk.sign(msgs, b"")
+    want = bbs.sign(suite, sk.sk, msgs, b"")
+    assert (sig.a, sig.e) == (want.a, want.e)
+    assert pk.verify(sig, b"", msgs) is True
+    assert pk.verify(sig, b"", msgs[:3] + [b"msg5"]) is False
+    rnd = bbs.seeded_random_scalars(suite, b"readme", suite.api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + 2)
+    proof = api.proof_gen(pk, sig, b"", b"ph", msgs, [0, 2], rnd)
+    wantp = bbs.proof_gen(suite, pk.pk, want, b"", b"ph", msgs, [0, 2], rnd)
+    assert (proof.a_bar, proof.b_bar, proof.d, proof.e_cap, proof.r1_cap, proof.r3_cap, list(proof.commitments), proof.challenge) == \
+           (wantp.a_bar, wantp.b_bar, wantp.d, wantp.e_cap, wantp.r1_cap, wantp.r3_cap, list(wantp.commitments), wantp.challenge)
+    assert api.proof_verify(pk, proof, b"", b"ph", [msgs[0], msgs[2]], [0, 2]) is True
+    assert api.proof_verify(pk, proof, b"", b"ph", [msgs[0], msgs[1]], [0, 2]) is False
+    assert bbs.proof_verify(suite, pk.pk, wantp, b"", b"ph", [msgs[0], msgs[2]], [0, 2]) is True
+
+
+def check_round_trips(lib_path=None, cases=CASES, curve="bls12_381"):    # bbs_over_bls_tests.rs:41-84, bbs_over_bn tests
     rng = random.Random(9)
-    sk = api.SecretKey.key_gen("bls12_381", bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-", lib_path)
+    sk = api.SecretKey.key_gen(curve, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-", lib_path)
     pk = sk.sk_to_pk()
     for count, disclosed, header in cases:
         msgs = [bytes(rng.randrange(256) for _ in range(5)) for _ in range(count)]

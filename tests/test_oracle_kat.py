@@ -95,3 +95,17 @@ def test_sign_and_proof_vectors():  # test_vector.rs:163-192 and :199-260
     assert got == PROOF_HEX
     assert bbs.proof_verify(S, pk, proof, HEADER, PH, [M1], [0]) is True
     assert bbs.proof_verify(S, pk, proof, HEADER, PH + b"x", [M1], [0]) is False
+
+
+def test_bn254_p1_is_first_bp_generator():
+    """The reference's one BN254 known answer: P1 (constants.rs:39-51) is the first generator under the seed
+    '...BP_MESSAGE_GENERATOR_SEED' (test_vector.rs:21-25, constants.rs comment).  Pins the restated SvdW
+    hash-to-G1 (crate bn254_hash2curve 0.1.2 is not vendored)."""
+    from oracle.bbs import BN_SUITE
+    from oracle.hashing import expand_message, hash_to_g1_bn, i2osp
+    api = BN_SUITE.api_id
+    v = expand_message(api + b"BP_MESSAGE_GENERATOR_SEED", api + b"SIG_GENERATOR_SEED_", 48)
+    v = expand_message(v + i2osp(1, 8), api + b"SIG_GENERATOR_SEED_", 48)
+    assert hash_to_g1_bn(v, api + b"SIG_GENERATOR_DST_") == BN_SUITE.p1
+    gens = bbs.create_generators(BN_SUITE, 3, api)
+    assert all(BN_SUITE.curve.g1_is_on_curve(g) for g in gens) and len(set(gens)) == 3

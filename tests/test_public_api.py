@@ -42,3 +42,11 @@ def test_round_trips_twin(twin):
 
 def test_invalid_proofs_twin(twin):
     pa.check_invalid_proofs(twin)
+
+
+def test_readme_example_bn254_twin(twin):
+    pa.check_readme_example_bn254(twin)
+
+
+def test_round_trips_bn254_twin(twin):
+    pa.check_round_trips(twin, pa.CASES[:3], curve="bn254")

@@ -18,3 +18,8 @@ def test_round_trips():
 
 def test_invalid_proofs():
     pa.check_invalid_proofs(None)
+
+
+def test_bn254_public_interface():
+    pa.check_readme_example_bn254(None)
+    pa.check_round_trips(None, pa.CASES, curve="bn254")

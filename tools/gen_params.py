@@ -297,6 +297,33 @@ def sswu_struct(p, r, n):
     return s
 
 
+def svdw_struct(p, n):
+    """BN254 hash-to-curve constants: Shallue-van de Woestijne map (RFC 9380 6.6.1) with Z = 1 on y^2 = x^3 + 3."""
+    Z, A, B = 1, 0, 3
+    g = lambda x: (x * x * x + A * x + B) % p
+    gz = g(Z)
+    h = (3 * Z * Z + 4 * A) % p
+    assert gz != 0 and h != 0
+    t = (-h * pow(4 * gz, -1, p)) % p
+    assert t != 0 and pow(t, (p - 1) // 2, p) == 1                    # -(3Z^2+4A)/(4g(Z)) is a non-zero square
+    assert pow(gz, (p - 1) // 2, p) == 1 or pow(g((-Z * pow(2, -1, p)) % p), (p - 1) // 2, p) == 1
+    c1 = gz
+    c2 = (-Z * pow(2, -1, p)) % p
+    c3 = pow((-gz * h) % p, (p + 1) // 4, p)
+    assert c3 * c3 % p == (-gz * h) % p
+    if c3 & 1:
+        c3 = p - c3                                                    # sgn0(c3) = 0
+    c4 = (-4 * gz * pow(h, -1, p)) % p
+    R = 1 << (28 * n)
+    mm = lambda val: val * R % p
+    s = "// BN254 G1 hash-to-curve constants (Shallue-van de Woestijne, Z = 1; see tools/gen_params.py)\n"
+    s += "struct BnSvdw {\n"
+    s += arr28("Z_M", mm(Z), n) + arr28("C1_M", mm(c1), n) + arr28("C2_M", mm(c2), n) + arr28("C3_M", mm(c3), n) + arr28("C4_M", mm(c4), n)
+    s += arr("SQRT_EXP", (p + 1) // 4, 8)
+    s += "};\n\n"
+    return s
+
+
 def main():
     bls_p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
     bls_r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -327,6 +354,7 @@ def main():
     s += curve_struct("Bn", bn_p, bn_r, 10, 3, (9, 1), "D", (1, 2), bn_g2, bn_p1,
                       4965661367192848881, False, "")
     s += sswu_struct(bls_p, bls_r, 14)
+    s += svdw_struct(bn_p, 10)
     s += "}  // namespace bbs\n"
     with open(OUT, "w") as f:
         f.write(s)
