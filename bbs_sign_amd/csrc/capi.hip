@@ -40,6 +40,30 @@ static int hash_to_g1_out(const uint8_t* msg, size_t msg_len, const uint8_t* dst
     fe_to_le_bytes<typename C::FpP>(p.y, out_affine + FPB);
     return BBS_OK;
 }
+// host arithmetic self-test: sum_k w_k a_k b_k in Fp2 through the lazily reduced column accumulators (tower.hpp F2Acc)
+template <class C>
+static int selftest_f2dot(size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* w, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr size_t FPB = 4 * P::NC;
+    F2Acc<C> acc;
+    f2acc_zero<C>(acc);
+    int weight = 0;
+    for (size_t k = 0; k < n_terms; k++) {
+        Fp2<C> x, y;
+        if (!fe_from_le_bytes<P>(a + k * 2 * FPB, x.c0) || !fe_from_le_bytes<P>(a + k * 2 * FPB + FPB, x.c1) ||
+            !fe_from_le_bytes<P>(b + k * 2 * FPB, y.c0) || !fe_from_le_bytes<P>(b + k * 2 * FPB + FPB, y.c1)) return BBS_E_ARG;
+        weight += w[k] ? w[k] : 1;
+        if (w[k] > 2 || weight > 6) return BBS_E_ARG;
+        if (w[k] == 0) f2acc_mac_fp<C>(acc, x, y.c0);
+        else if (w[k] == 1) f2acc_mac<C, 1>(acc, x, y);
+        else f2acc_mac<C, 2>(acc, x, y);
+    }
+    const Fp2<C> r = f2acc_finish<C>(acc);
+    fe_to_le_bytes<P>(r.c0, out);
+    fe_to_le_bytes<P>(r.c1, out + FPB);
+    return BBS_OK;
+}
+
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -459,6 +483,13 @@ int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_aff
 int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single, uint8_t* out_dist) {
     if (!ctx || !a || !b || !out_single || !out_dist) return BBS_E_ARG;
     return DISPATCH(ctx, selftest_f12<BlsCurve>(AS_BLS(ctx), op, a, b, out_single, out_dist), selftest_f12<BnCurve>(AS_BN(ctx), op, a, b, out_single, out_dist));
+}
+
+int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights, uint8_t* out) {
+    if (!a || !b || !weights || !out) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return selftest_f2dot<BlsCurve>(n_terms, a, b, weights, out);
+    if (curve == BBS_CURVE_BN254) return selftest_f2dot<BnCurve>(n_terms, a, b, weights, out);
+    return BBS_E_ARG;
 }
 
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {

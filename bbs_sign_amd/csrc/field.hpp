@@ -525,6 +525,45 @@ BBS_HD void unpack32(const uint32_t* w, uint32_t* l28) {
     }
 }
 
+// ---- column accumulators: a SUM of limb products, reduced once --------------------------------
+// t[0 .. 2N-2] are 64-bit column sums (weight 2^(28 c)).  One Montgomery reduction serves a whole dot product
+// instead of one per product; the caller keeps the total weight of what it accumulates <= 6 (bounds asserted
+// numerically by tools/gen_params.py, constant WP2X).
+template <class P>
+BBS_HD void cols_zero(uint64_t* t) {
+#pragma unroll
+    for (int c = 0; c < 2 * P::N - 1; c++) t[c] = 0;
+}
+template <class P>
+BBS_HD void cols_mac(uint64_t* t, const uint32_t* a, const uint32_t* b) {     // a limbs < 2^30, b limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+#pragma unroll
+        for (int j = 0; j < P::N; j++) t[i + j] += (uint64_t)a[i] * b[j];
+    }
+}
+// t / R mod p, normal result (< 2p); t is consumed
+template <class P>
+BBS_HD void cols_reduce(uint32_t* r, uint64_t* t) {
+    constexpr int N = P::N;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        const uint32_t m = ((uint32_t)t[c] * P::INV) & MASK28;
+#pragma unroll
+        for (int j = 0; j < N; j++) t[c + j] += (uint64_t)m * P::MOD[j];
+        t[c + 1] += t[c] >> 28;
+    }
+    uint64_t carry = 0;
+#pragma unroll
+    for (int c = N; c < 2 * N - 1; c++) {
+        const uint64_t v = t[c] + carry;
+        r[c - N] = (uint32_t)v & MASK28;
+        carry = v >> 28;
+    }
+    r[N - 1] = (uint32_t)carry;
+    BBS_BOUND_ASSERT(carry <= P::MOD2[N - 1], "cols_reduce result < 2p");
+}
+
 }  // namespace r28
 
 // =============================================================================================

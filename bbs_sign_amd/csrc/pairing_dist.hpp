@@ -20,6 +20,22 @@
 #if defined(__HIP_DEVICE_COMPILE__) || !defined(BBS_HOST_TWIN)
 namespace bbs {
 
+// hot lane-sliced operations: separate functions by default; -DBBS_DIST_INLINE=1 inlines the Miller-loop pair
+// (square, line), =2 also the cyclotomic square (A/B knob)
+#ifndef BBS_DIST_INLINE
+#define BBS_DIST_INLINE 2
+#endif
+#if BBS_DIST_INLINE >= 1
+#define BBS_DIST_MILLER __device__ __forceinline__
+#else
+#define BBS_DIST_MILLER __device__ __attribute__((noinline))
+#endif
+#if BBS_DIST_INLINE >= 2
+#define BBS_DIST_CYCLO __device__ __forceinline__
+#else
+#define BBS_DIST_CYCLO __device__ __attribute__((noinline))
+#endif
+
 constexpr int GRP = 6;                 // lanes per item
 constexpr int GRP_PER_WAVE = 10;
 
@@ -48,6 +64,64 @@ __device__ __forceinline__ Fp2<C> f2_sel(bool c, const Fp2<C>& a, const Fp2<C>& 
 template <class C>
 __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int src) { return f2_shfl<C>(g, L.base + src); }
 
+#ifndef BBS_DIST_LAZY
+#define BBS_DIST_LAZY 1
+#endif
+#if BBS_DIST_LAZY
+// f * h: lane k computes its own output coefficient  c_k = sum_j g_j h_{(k-j) mod 6} xi^[j > k]  as ONE Fp2 dot
+// product (tower.hpp F2Acc): the six products are accumulated as unreduced column sums and reduced once --
+// 6 * 3 N^2 + 2 N^2 multiply-accumulates instead of 6 * 5 N^2.  Operands come in by ds_bpermute.
+template <class C>
+__device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
+    F2Acc<C> acc;
+    f2acc_zero<C>(acc);
+    const int k = L.m;
+#pragma unroll 1
+    for (int j = 0; j < GRP; j++) {
+        const Fp2<C> a = d_coef<C>(L, g, j);
+        int src = k - j;
+        if (src < 0) src += GRP;
+        Fp2<C> b = d_coef<C>(L, h, src);
+        b = f2_sel<C>(j > k, f2_mul_xi<C>(b), b);
+        f2acc_mac<C, 1>(acc, a, b);
+    }
+    return f2acc_finish<C>(acc);
+}
+
+// f^2: c_k = sum over unordered pairs {i, j}, i + j = k mod 6, of w g_i g_j xi^[i + j >= 6] (w = 1 for squares,
+// 2 otherwise): four slots per lane (odd lanes use three), total weight 6 -- 4 * 3 N^2 + 2 N^2.
+// slot s of lane k: i = SQ_I[k][s], j = SQ_J[k][s]; j = 7 marks the unused slot.
+template <class C>
+BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
+    // packed per lane: 4 slots x (i:3 bits, j:3 bits) -- (0,0)(3,3)(1,5)(2,4) | (0,1)(2,5)(3,4)- | (1,1)(0,2)(4,4)(3,5) |
+    //                  (0,3)(1,2)(4,5)- | (2,2)(0,4)(1,3)(5,5) | (0,5)(1,4)(2,3)-
+    constexpr uint32_t PK[6] = {
+        (0u | 0u << 3) | (3u | 3u << 3) << 6 | (1u | 5u << 3) << 12 | (2u | 4u << 3) << 18,
+        (0u | 1u << 3) | (2u | 5u << 3) << 6 | (3u | 4u << 3) << 12 | (7u | 7u << 3) << 18,
+        (1u | 1u << 3) | (0u | 2u << 3) << 6 | (4u | 4u << 3) << 12 | (3u | 5u << 3) << 18,
+        (0u | 3u << 3) | (1u | 2u << 3) << 6 | (4u | 5u << 3) << 12 | (7u | 7u << 3) << 18,
+        (2u | 2u << 3) | (0u | 4u << 3) << 6 | (1u | 3u << 3) << 12 | (5u | 5u << 3) << 18,
+        (0u | 5u << 3) | (1u | 4u << 3) << 6 | (2u | 3u << 3) << 12 | (7u | 7u << 3) << 18};
+    const int k = L.m;
+    uint32_t pk = PK[0];
+#pragma unroll
+    for (int q = 1; q < 6; q++) pk = (k == q) ? PK[q] : pk;
+    F2Acc<C> acc;
+    f2acc_zero<C>(acc);
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+        const uint32_t i = (pk >> (6 * s)) & 7u, j = (pk >> (6 * s + 3)) & 7u;
+        const bool used = i != 7u;
+        const uint32_t ii = used ? i : 0u, jj = used ? j : 0u;
+        Fp2<C> a = d_coef<C>(L, g, (int)ii);
+        Fp2<C> b = d_coef<C>(L, g, (int)jj);
+        a = f2_sel<C>(used, a, f2_zero<C>());
+        b = f2_sel<C>(ii + jj >= (uint32_t)GRP, f2_mul_xi<C>(b), b);
+        f2acc_mac_sh<C>(acc, a, b, (used && ii != jj) ? 1u : 0u);
+    }
+    return f2acc_finish<C>(acc);
+}
+#else
 // f * h.  Lane m multiplies g_m by every h_j; product j belongs to w^(m+j): it is rotated to lane
 // (m + j) mod 6 and, on the RECEIVING lane k, lands in the plain sum (k >= j) or in the sum that
 // still has to be multiplied by xi (k < j, i.e. m + j >= 6).  Both sums are accumulated lazily
@@ -94,7 +168,7 @@ __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& 
 // m0 + 3) per receiver and per d of the right parity -- with factor 2 for d > 0 and xi when the
 // exponent wraps.  Lazy accumulation and final reduction as in d_mul.
 template <class C>
-__device__ __attribute__((noinline)) Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
+BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
     using P = typename C::FpP;
     constexpr int N = P::N;
     uint32_t A0[N], A1[N], B0[N], B1[N];
@@ -144,14 +218,46 @@ __device__ __attribute__((noinline)) Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& 
     }
 }
 
+#endif
+
 template <class C>
 __device__ __forceinline__ Fp2<C> d_conj(const Lane6& L, const Fp2<C>& g) {   // w -> -w
     return f2_sel<C>((L.m & 1) != 0, f2_neg<C>(g), g);
 }
 
 // multiply by the line through the twist point evaluated at P (see pairing.hpp for the forms)
+#if BBS_DIST_LAZY
+// three sparse terms as ONE dot product: 3 + 3 + 2 N^2 multiply-accumulates + one reduction pair
 template <class C>
-__device__ __attribute__((noinline)) Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEntry<C>& le, const G1Aff<C>& P) {
+BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEntry<C>& le, const G1Aff<C>& P) {
+    const Fp2<C> lx = f2_mul_fp<C>(le.nl, P.x);
+    F2Acc<C> acc;
+    f2acc_zero<C>(acc);
+    const int k = L.m;
+    if constexpr (C::K::TWIST_M) {
+        // l = c + lx w^2 + yP w^3 :  c_k = g_k c + xi^[k<2] g_{k-2} lx + xi^[k<3] g_{k-3} yP
+        Fp2<C> a = d_coef<C>(L, g, k < 2 ? k + 4 : k - 2);
+        Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
+        a = f2_sel<C>(k < 2, f2_mul_xi<C>(a), a);
+        b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
+        f2acc_mac<C, 1>(acc, g, le.c);
+        f2acc_mac<C, 1>(acc, a, lx);
+        f2acc_mac_fp<C>(acc, b, P.y);
+    } else {
+        // l = yP + lx w + c w^3    :  c_k = g_k yP + xi^[k<1] g_{k-1} lx + xi^[k<3] g_{k-3} c
+        Fp2<C> a = d_coef<C>(L, g, k < 1 ? k + 5 : k - 1);
+        Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
+        a = f2_sel<C>(k < 1, f2_mul_xi<C>(a), a);
+        b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
+        f2acc_mac_fp<C>(acc, g, P.y);
+        f2acc_mac<C, 1>(acc, a, lx);
+        f2acc_mac<C, 1>(acc, b, le.c);
+    }
+    return f2acc_finish<C>(acc);
+}
+#else
+template <class C>
+BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEntry<C>& le, const G1Aff<C>& P) {
     using FPp = typename C::FpP;
     Fp2<C> lx = f2_mul_fp<C>(le.nl, P.x);
     int s1, s2;
@@ -179,13 +285,15 @@ __device__ __attribute__((noinline)) Fp2<C> d_mul_line(const Lane6& L, const Fp2
     return f2_add<C>(f2_add<C>(t0, t1), t2);
 }
 
+#endif
+
 // Granger-Scott squaring of a cyclotomic element: Fp4 pairs (g_m, g_{m+3}), m = 0,1,2
 //   X = (x0, x1):  X^2 = (x0^2 + xi x1^2, 2 x0 x1)
 //   g0' = 3 A2[0] - 2 g0   g3' = 3 A2[1] + 2 g3
 //   g1' = 3 xi C2[1] + 2 g1   g4' = 3 C2[0] - 2 g4
 //   g2' = 3 B2[0] - 2 g2   g5' = 3 B2[1] + 2 g5
 template <class C>
-__device__ __attribute__((noinline)) Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
+BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     const bool hi = L.m >= 3;
     const int partner = hi ? L.m - 3 : L.m + 3;
     Fp2<C> px = d_coef<C>(L, g, partner);

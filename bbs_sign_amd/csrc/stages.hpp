@@ -32,7 +32,7 @@ namespace bbs {
 constexpr int NFIX = 8;          // fixed-base chunks per MSM (one lane each)
 constexpr int MAX_DST = 255;
 #ifndef BBS_PAIR_WAVES
-#define BBS_PAIR_WAVES 4
+#define BBS_PAIR_WAVES 1
 #endif
 #ifndef BBS_MSM_WAVES
 #define BBS_MSM_WAVES 1          // multi-scalar-multiplication stages (2 and 3 measured: no gain, spills)
@@ -985,7 +985,7 @@ struct PairPrep {
 // =============================================================================================
 template <class C>
 struct PairDist {
-    static constexpr int WAVES_PER_EU = BBS_PAIR_WAVES;      // 128 VGPRs: four wavefronts per SIMD hide each other's waits
+    static constexpr int WAVES_PER_EU = BBS_PAIR_WAVES;      // 1: the whole register file for one wavefront (measured best)
     static __device__ void run(const PairArgs<C>& a, size_t t) {
         const int lane = (int)(t & 63);
         const int grp = lane / GRP;

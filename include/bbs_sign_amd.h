@@ -255,6 +255,11 @@ int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_aff
  * exponentiation, 10 cyclotomic square, 11 power by the curve parameter. */
 int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single,
                      uint8_t* out_dist);
+/* Host arithmetic self-test (no GPU): out = sum_k w_k * a_k * b_k in Fp2 computed by the lazily reduced column
+ * accumulators the pairing kernel uses (one Montgomery reduction pair per dot product).  a, b: n_terms records
+ * c0 || c1 (canonical LE); weights[k] = 1, 2, or 0 for "b_k is its c0 in Fp"; total weight <= 6. */
+int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
+                       uint8_t* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,56 @@
+"""Lazily reduced Fp2 dot products (tower.hpp F2Acc: the arithmetic core of the lane-sliced pairing kernel) on the
+host, against Python big integers: random and extreme operands, every weight pattern up to the design limit of 6,
+with the bound assertions of the host twin switched on (BBS_CHECK_BOUNDS)."""
+import ctypes
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.curves import BLS12_381, BN254
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def libs():
+    sys.path.insert(0, ROOT)
+    from bbs_sign_amd import _lib, build as b
+    return [_lib.load_library(b.build(twin=True, verbose=False)), _lib.load_library(b.build(twin=False, verbose=False))]
+
+
+def _u8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+@pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
+def test_f2dot(libs, cid, curve):
+    p = curve.p
+    fpb = curve.fp_bytes
+    rng = random.Random(77 + cid)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << (8 * fpb - 1)) % p]
+    patterns = [[1], [2], [0], [1] * 6, [2, 2, 2], [2, 2, 1, 1], [1, 1, 0], [2, 1, 1, 0, 1], [0] * 6, [2, 2, 0, 0]]
+    for lib in libs:
+        for pat in patterns:
+            for trial in range(6):
+                pick = (lambda: rng.choice(edge)) if trial < 2 else (lambda: rng.randrange(p))
+                a = [(pick(), pick()) for _ in pat]
+                b = [(pick(), pick()) for _ in pat]
+                if trial == 1:
+                    a = [(p - 1, p - 1)] * len(pat)
+                    b = [(p - 1, p - 1)] * len(pat)
+                re = im = 0
+                for (a0, a1), (b0, b1), w in zip(a, b, pat):
+                    if w == 0:
+                        re += a0 * b0; im += a1 * b0
+                    else:
+                        re += w * (a0 * b0 - a1 * b1); im += w * (a0 * b1 + a1 * b0)
+                ab = np.frombuffer(b"".join(x.to_bytes(fpb, "little") + y.to_bytes(fpb, "little") for x, y in a), dtype=np.uint8).copy()
+                bb = np.frombuffer(b"".join(x.to_bytes(fpb, "little") + y.to_bytes(fpb, "little") for x, y in b), dtype=np.uint8).copy()
+                wb = np.array(pat, dtype=np.uint8)
+                out = np.zeros(2 * fpb, dtype=np.uint8)
+                assert lib.bbs_selftest_f2dot(cid, len(pat), _u8(ab), _u8(bb), _u8(wb), _u8(out)) == 0
+                o = out.tobytes()
+                assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == (re % p, im % p), (cid, pat, trial)

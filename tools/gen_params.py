@@ -91,6 +91,29 @@ def field28_struct(name, mod, n, nc, bound_mult):
     assert adj is not None, name
     s += "    // K p^2 (K = %d) in lifted product columns, see r28::f2mul\n" % K
     s += "    static constexpr uint64_t WP2[%d] = {%s};\n" % (2 * n - 1, ", ".join("0x%016xull" % v for v in adj))
+    # the same for a SUM of products of total weight <= 6 accumulated column-wise BEFORE any reduction (r28::cols_*,
+    # tower.hpp F2Acc): column k lifted by >= 6 * maxcol[k] (a multiple of 2^28, borrowed from column k+1)
+    WSUM = 6
+    lift6 = [-(-(WSUM * maxcol[k] + (1 << 40)) // (1 << 28)) * (1 << 28) for k in range(ncol - 1)]     # margin covers the borrow
+    adj6 = None
+    for K6 in (32, 64, 128, 256, 512, 1024, 2048):
+        w = K6 * mod * mod
+        cols = [(w >> (28 * k)) & 0xFFFFFFF for k in range(ncol - 1)] + [w >> (28 * (ncol - 1))]
+        cand = [cols[k] + (lift6[k] if k < ncol - 1 else 0) - ((lift6[k - 1] >> 28) if k > 0 else 0) for k in range(ncol)]
+        assert sum(v << (28 * k) for k, v in enumerate(cand)) == w
+        # every column: lift covers the subtracted sum; t0 + lift + the reduction's additions stay below 2^64
+        ok = all(cand[k] >= WSUM * maxcol[k] and cand[k] + WSUM * maxcol[k] + n * (1 << 56) + (1 << 40) < (1 << 64) for k in range(ncol))
+        # the imaginary columns sum (a0 b1 + a1 b0) of total weight 6 fit 64 bits (the Karatsuba sum column may wrap
+        # modulo 2^64; the subtraction is done modulo 2^64 too, see tower.hpp f2acc_mac)
+        ok = ok and 2 * WSUM * n * ((1 << 28) - 1) ** 2 < (1 << 64)
+        # value bound: (6 (BOUND p)^2 + K p^2) / R + p < 2p
+        ok = ok and (WSUM * bound_mult * bound_mult + K6) * mod * mod < (mod << (28 * n))
+        if ok:
+            adj6 = cand
+            break
+    assert adj6 is not None, name
+    s += "    // K p^2 (K = %d) lifted for column sums of total weight <= 6, see r28::cols_* / F2Acc\n" % K6
+    s += "    static constexpr uint64_t WP2X[%d] = {%s};\n" % (2 * n - 1, ", ".join("0x%016xull" % v for v in adj6))
     # BOUND * p with 2^28 borrowed into every lower limb: a - b + SUBM is non-negative limb by limb
     mb = limbs28(bound_mult * mod, n)
     sub = [mb[0] + (1 << 28)] + [mb[i] + (1 << 28) - 1 for i in range(1, n - 1)] + [mb[n - 1] - 1]
