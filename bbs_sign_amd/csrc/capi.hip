@@ -64,6 +64,16 @@ static int selftest_f2dot(size_t n_terms, const uint8_t* a, const uint8_t* b, co
     return BBS_OK;
 }
 
+// host arithmetic self-test: x^-1 by the safegcd inversion and by the Fermat power (independent code paths)
+template <class P>
+static int selftest_inv(const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat) {
+    Fe<P> a;
+    if (!fe_from_le_bytes<P>(x, a)) return BBS_E_ARG;
+    fe_to_le_bytes<P>(fe_inv<P>(a), out_safegcd);
+    fe_to_le_bytes<P>(fe_inv_fermat<P>(a), out_fermat);
+    return BBS_OK;
+}
+
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -483,6 +493,13 @@ int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_aff
 int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out_single, uint8_t* out_dist) {
     if (!ctx || !a || !b || !out_single || !out_dist) return BBS_E_ARG;
     return DISPATCH(ctx, selftest_f12<BlsCurve>(AS_BLS(ctx), op, a, b, out_single, out_dist), selftest_f12<BnCurve>(AS_BN(ctx), op, a, b, out_single, out_dist));
+}
+
+int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat) {
+    if (!x || !out_safegcd || !out_fermat) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return scalar_field ? selftest_inv<BlsFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BlsFpParams>(x, out_safegcd, out_fermat);
+    if (curve == BBS_CURVE_BN254) return scalar_field ? selftest_inv<BnFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BnFpParams>(x, out_safegcd, out_fermat);
+    return BBS_E_ARG;
 }
 
 int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights, uint8_t* out) {

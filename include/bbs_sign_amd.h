@@ -258,6 +258,9 @@ int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, u
 /* Host arithmetic self-test (no GPU): out = sum_k w_k * a_k * b_k in Fp2 computed by the lazily reduced column
  * accumulators the pairing kernel uses (one Montgomery reduction pair per dot product).  a, b: n_terms records
  * c0 || c1 (canonical LE); weights[k] = 1, 2, or 0 for "b_k is its c0 in Fp"; total weight <= 6. */
+/* Host arithmetic self-test (no GPU): x^-1 in the base field (scalar_field = 0, fp_bytes LE) or the scalar field
+ * (1, 32 bytes LE) by the safegcd inversion the kernels use and by the Fermat power x^(p-2). */
+int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat);
 int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
                        uint8_t* out);
 

@@ -54,3 +54,25 @@ def test_f2dot(libs, cid, curve):
                 assert lib.bbs_selftest_f2dot(cid, len(pat), _u8(ab), _u8(bb), _u8(wb), _u8(out)) == 0
                 o = out.tobytes()
                 assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == (re % p, im % p), (cid, pat, trial)
+
+
+@pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
+def test_safegcd_inversion(libs, cid, curve):
+    """fe_inv (Bernstein-Yang divsteps) against Python's modular inverse and the library's own Fermat power, base
+    and scalar field, edge values (0 -> 0, 1, p-1, powers of two, all-ones patterns) and random values; the host
+    twin also asserts that g reached 0 within the fixed number of batches."""
+    rng = random.Random(5 + cid)
+    for sf, mod, nb in ((0, curve.p, curve.fp_bytes), (1, curve.r, 32)):
+        vals = [0, 1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, (1 << (mod.bit_length() - 1)),
+                (1 << (mod.bit_length() - 1)) - 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % mod,
+                (1 << 30) - 1, 1 << 30, (1 << 60) + 1]
+        vals += [1 << k for k in range(1, mod.bit_length() - 1, 37)]
+        vals += [rng.randrange(mod) for _ in range(300)]
+        for lib in libs:
+            for x in vals:
+                xb = np.frombuffer(x.to_bytes(nb, "little"), dtype=np.uint8).copy()
+                o1, o2 = np.zeros(nb, dtype=np.uint8), np.zeros(nb, dtype=np.uint8)
+                assert lib.bbs_selftest_inv(cid, sf, _u8(xb), _u8(o1), _u8(o2)) == 0
+                want = pow(x, -1, mod) if x else 0
+                assert int.from_bytes(o1.tobytes(), "little") == want, (cid, sf, hex(x))
+                assert int.from_bytes(o2.tobytes(), "little") == want

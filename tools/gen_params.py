@@ -134,6 +134,7 @@ def field28_struct(name, mod, n, nc, bound_mult):
     s += arr("MODC", mod, nc)                # canonical 32-bit limbs
     s += arr("HALF", (mod - 1) // 2, nc)
     s += arr("MOD_M2", mod - 2, nc)
+    s += modinv30_consts(mod)
     s += "};\n\n"
     return s
 
@@ -152,6 +153,22 @@ def f2_pow(a, e, p):
     return r
 
 
+
+def modinv30_consts(mod):
+    """Constants of the safegcd inversion (field.hpp modinv30): modulus in 30-bit limbs, its inverse mod 2^30, and
+    the number of 30-step batches >= the Bernstein-Yang bound floor((49 d + 80) / 17) for d-bit inputs."""
+    bits = mod.bit_length()
+    nl = (bits + 1 + 29) // 30
+    limbs30 = [(mod >> (30 * i)) & 0x3FFFFFFF for i in range(nl)]
+    minv = pow(mod, -1, 1 << 30)
+    batches = -(-((49 * bits + 80) // 17) // 30)
+    s = "    static constexpr int NL30 = %d;            // 30-bit limbs of the safegcd inversion\n" % nl
+    s += "    static constexpr int INV_BATCHES = %d;     // batches of 30 divsteps\n" % batches
+    s += "    static constexpr uint32_t MINV30 = 0x%08xu; // mod^-1 mod 2^30\n" % minv
+    s += "    static constexpr uint32_t MOD30[%d] = {%s};\n" % (nl, ", ".join("0x%08xu" % v for v in limbs30))
+    return s
+
+
 def field_struct(name, mod, n):
     R = 1 << (32 * n)
     inv = (-pow(mod, -1, 1 << 32)) % (1 << 32)
@@ -168,6 +185,7 @@ def field_struct(name, mod, n):
     s += arr("MODC", mod, n)
     s += arr("HALF", (mod - 1) // 2, n)    # (p-1)/2 : y > HALF <=> lexicographically largest
     s += arr("MOD_M2", mod - 2, n)         # exponent for Fermat inversion
+    s += modinv30_consts(mod)
     s += "};\n\n"
     return s
 
