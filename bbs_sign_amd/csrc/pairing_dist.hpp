@@ -6,12 +6,15 @@
 // six-lane group holds only g_m in Fp2 (24 VGPRs for BLS12-381); operands move between the lanes
 // of a group with ds_bpermute (__shfl).  Ten groups share one wavefront (lanes 60..63 idle).
 //
-//   mul        : lane m multiplies its g_m by every h_j (broadcast), the products are rotated to
-//                lane (m+j) mod 6 (times xi when m+j >= 6) and summed        6 Fp2 mul per lane
-//   line (M/D) : sparse, 3 non-zero coefficients                              3 Fp2-ish mul
-//   cyclotomic square (Granger-Scott over Fp4 pairs (m, m+3))                 2 Fp2 sqr
+// Lane k computes output coefficient k of every operation as ONE Fp2 dot product whose limb products are summed
+// in 64-bit columns and Montgomery-reduced once (tower.hpp F2Acc; N = limbs of Fp):
+//   mul        : c_k = sum_j g_j h_(k-j) xi^[j>k]                      6 * 3 N^2 + 2 N^2 multiply-accumulates
+//   square     : unordered pairs, four slots per lane                  4 * 3 N^2 + 2 N^2
+//   line (M/D) : sparse, 3 non-zero coefficients                       8 N^2 + 2 N^2 (+ 4 N^2 for nl * xP)
+//   cyclotomic square (Granger-Scott over Fp4 pairs (m, m+3))          four column products, 4 N^2 + 2 N^2
 //   conj, frob : lane-local
-//   inverse    : gathered on every lane (once per item)
+//   inverse    : gathered on every lane (once per item), one safegcd inversion in Fp
+// The kernel takes the whole register file (one wavefront per SIMD, Miller-loop operations inlined): DESIGN.md 5.
 //
 // Same group elements / booleans as pairing.hpp; selftest entry points compare the two on the GPU.
 #pragma once

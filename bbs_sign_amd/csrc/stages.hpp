@@ -7,11 +7,12 @@
 //
 // Work split (MI355X: 1024 SIMDs, a batch of 4096 items is only 64 wavefronts, so each item is
 // split over several lanes wherever the algebra allows):
-//   * a multi-scalar multiplication is cut into PARTS -- one variable-base scalar multiplication
-//     each, plus NFIX chunks of the fixed-base (windowed, precomputed-table) sum -- every part on
-//     its own lane (part-major thread index: a wavefront runs one kind of part);
-//   * the two Miller loops of a pairing product run on two lanes and are multiplied before the
-//     single shared final exponentiation.
+//   * a multi-scalar multiplication is cut into PARTS -- a variable-base scalar multiplication (or the
+//     joint multiplication of T1's three terms), plus NFIX chunks of the fixed-base (windowed,
+//     precomputed-table) sum -- every part on its own lane (part-major thread index: a wavefront runs
+//     one kind of part);
+//   * a pairing product is sliced over six lanes per item (pairing_dist.hpp, stage PairDist); the
+//     one-lane PairMiller / PairFinal stages below serve the CPU-side test build only.
 //
 // Algebraic restructurings (bit-identical group elements / booleans):
 //   proof_verify: T2 = Bv*c + D*r3^ + sum H_j m^_j  with  Bv = P1 + Q1*domain + sum H_i m_i
