@@ -70,6 +70,9 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 #ifndef BBS_DIST_LAZY
 #define BBS_DIST_LAZY 1
 #endif
+#ifndef BBS_DIST_UNROLL
+#define BBS_DIST_UNROLL 1        // iterations of the dot-product loops kept rolled (1) or unrolled (6 / 4): A/B knob
+#endif
 #if BBS_DIST_LAZY
 // f * h: lane k computes its own output coefficient  c_k = sum_j g_j h_{(k-j) mod 6} xi^[j > k]  as ONE Fp2 dot
 // product (tower.hpp F2Acc): the six products are accumulated as unreduced column sums and reduced once --
@@ -79,7 +82,7 @@ __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& 
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
     const int k = L.m;
-#pragma unroll 1
+#pragma unroll BBS_DIST_UNROLL
     for (int j = 0; j < GRP; j++) {
         const Fp2<C> a = d_coef<C>(L, g, j);
         int src = k - j;
@@ -111,7 +114,7 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
     for (int q = 1; q < 6; q++) pk = (k == q) ? PK[q] : pk;
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
-#pragma unroll 1
+#pragma unroll BBS_DIST_UNROLL
     for (int s = 0; s < 4; s++) {
         const uint32_t i = (pk >> (6 * s)) & 7u, j = (pk >> (6 * s + 3)) & 7u;
         const bool used = i != 7u;
