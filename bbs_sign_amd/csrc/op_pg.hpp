@@ -106,9 +106,9 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     int rc = BBS_OK;
     PgArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.sig_a = job->up(sa.v, rc); a.sig_e = job->up(se.v, rc); a.msgs = job->up(sm.v, rc);
-    a.dmask = job->up(dmask.v, rc); a.didx = job->up(didx_s.v, rc); a.rcount = job->up(rcount.v, rc);
-    a.rnd5 = job->up(rnd5.v, rc); a.mtilde = job->up(mt.v, rc);
+    a.sig_a = job->up(sa.soa(), rc); a.sig_e = job->up(se.soa(), rc); a.msgs = job->up(sm.soa(), rc);
+    a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
+    a.rnd5 = job->up(rnd5.soa(), rc); a.mtilde = job->up(mt.soa(), rc);
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
     a.ph_off = job->up(pp.off, rc); a.ph_len = job->up(pp.len, rc); a.ph_bytes = job->up(pp.bytes, rc);
     a.dom = job->template scratch<uint32_t>(8 * n, rc);

@@ -88,8 +88,8 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     DevBuf dF, dVP, dVS, dSt, dPart, dOut;
     if (dF.alloc(F.bytes()) || dVP.alloc(VP.bytes()) || dVS.alloc(VS.bytes()) || dSt.alloc(n + 4) ||
         dPart.alloc((nv + NFIX) * 3 * N * n * 4 + 4) || dOut.alloc((size_t)2 * NC * n * 4 + 4)) return BBS_E_NOMEM;
-    if (rt::h2d(dF.p, F.v.data(), F.bytes(), ctx->stream) || rt::h2d(dVP.p, VP.v.data(), VP.bytes(), ctx->stream) ||
-        rt::h2d(dVS.p, VS.v.data(), VS.bytes(), ctx->stream) || rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
+    if (rt::h2d(dF.p, F.soa().data(), F.bytes(), ctx->stream) || rt::h2d(dVP.p, VP.soa().data(), VP.bytes(), ctx->stream) ||
+        rt::h2d(dVS.p, VS.soa().data(), VS.bytes(), ctx->stream) || rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
     int rc = ctx->sync_consts();
     if (rc) return rc;
     MsmArgs<C> a;
@@ -130,7 +130,7 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
         dDig.alloc((size_t)NW * n_pad + 4) || dList.alloc((size_t)NW * n * 4 + 4) || dB.alloc((size_t)3 * N * T * 4) ||
         dSeg.alloc((size_t)3 * N * NW * (PIP_NB / PIP_SEG) * 4) || dW.alloc((size_t)3 * N * NW * 4) || dOut.alloc((size_t)2 * N * 4))
         return BBS_E_NOMEM;
-    if (rt::h2d(dP.p, P.v.data(), P.bytes(), ctx->stream) || rt::h2d(dS.p, S.v.data(), S.bytes(), ctx->stream) ||
+    if (rt::h2d(dP.p, P.soa().data(), P.bytes(), ctx->stream) || rt::h2d(dS.p, S.soa().data(), S.bytes(), ctx->stream) ||
         rt::h2d(dSt.p, st0.data(), n, ctx->stream) || rt::dmemset(dDig.p, 0, (size_t)NW * n_pad, ctx->stream)) return BBS_E_HIP;
     PipPrep<C> prep{dP.as<uint32_t>(), dPm.as<uint32_t>(), dSt.as<int8_t>(), n};
     PipDigitArgs da{n, n_pad, dS.as<uint32_t>(), dSt.as<int8_t>(), dDig.as<uint8_t>()};
@@ -170,7 +170,7 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     DevBuf dA, dB, dAm, dBm, dSt, dF;
     if (dA.alloc(A.bytes()) || dB.alloc(B.bytes()) || dAm.alloc((size_t)2 * N * n * 4 + 4) || dBm.alloc((size_t)2 * N * n * 4 + 4) || dSt.alloc(n + 4) ||
         dF.alloc((size_t)2 * 12 * N * n * 4 + 4)) return BBS_E_NOMEM;
-    if (rt::h2d(dA.p, A.v.data(), A.bytes(), ctx->stream) || rt::h2d(dB.p, B.v.data(), B.bytes(), ctx->stream) ||
+    if (rt::h2d(dA.p, A.soa().data(), A.bytes(), ctx->stream) || rt::h2d(dB.p, B.soa().data(), B.bytes(), ctx->stream) ||
         rt::h2d(dSt.p, st0.data(), n, ctx->stream)) return BBS_E_HIP;
     int rc = ctx->sync_consts();
     if (rc) return rc;

@@ -85,8 +85,8 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     int rc = BBS_OK;
     PvArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.pts = job->up(pts.v, rc); a.sc = job->up(sc.v, rc); a.slots = job->up(slots.v, rc);
-    a.dmask = job->up(dmask.v, rc); a.didx = job->up(didx_s.v, rc); a.rcount = job->up(rcount.v, rc);
+    a.pts = job->up(pts.soa(), rc); a.sc = job->up(sc.soa(), rc); a.slots = job->up(slots.soa(), rc);
+    a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
     a.ph_off = job->up(pp.off, rc); a.ph_len = job->up(pp.len, rc); a.ph_bytes = job->up(pp.bytes, rc);
     a.dom = job->template scratch<uint32_t>(8 * n, rc);

@@ -55,7 +55,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     SgArgs<C>& a = job->a;
     a.n = n; a.L = L; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     std::memcpy(a.sk, ctx->sk, sizeof(a.sk));
-    a.msgs = job->up(sm.v, rc);
+    a.msgs = job->up(sm.soa(), rc);
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)NFIX * 3 * N * n, rc);

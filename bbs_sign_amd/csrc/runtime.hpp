@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <type_traits>
@@ -35,7 +37,8 @@ inline int device_count() { return 1; }
 inline int stream_create(Stream*) { return 0; }
 inline void stream_destroy(Stream&) {}
 inline int dmalloc(void** p, size_t b) { *p = std::calloc(b ? b : 1, 1); return *p ? 0 : -1; }
-inline void dfree(void* p) { std::free(p); }
+inline void dfree(void* p, size_t, int) { std::free(p); }
+inline int current_device() { return 0; }
 inline int h2d(void* d, const void* h, size_t b, Stream&) { std::memcpy(d, h, b); return 0; }
 inline int d2h(void* h, const void* d, size_t b, Stream&) { std::memcpy(h, d, b); return 0; }
 inline int dmemset(void* d, int v, size_t b, Stream&) { std::memset(d, v, b); return 0; }
@@ -63,10 +66,47 @@ struct EventList {
 using Stream = hipStream_t;
 inline int set_device(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
 inline int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
-inline int stream_create(Stream* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; }
-inline void stream_destroy(Stream& s) { (void)hipStreamDestroy(s); }
-inline int dmalloc(void** p, size_t b) { return hipMalloc(p, b ? b : 4) == hipSuccess ? 0 : -1; }
-inline void dfree(void* p) { (void)hipFree(p); }
+inline int stream_create(Stream* s);      // pooled, defined below
+inline void stream_destroy(Stream& s);
+// Device buffers, streams and events are recycled per device: a one-shot batch call allocated ~20 buffers and two
+// streams and released them again, 6 ms of hipMalloc / hipFree / stream creation per 4096-proof call.  Buffers up
+// to 64 MiB go back to a free list by size class (powers of two below 1 MiB, multiples of 1 MiB above), at most
+// 2 GiB per device; larger ones (the window tables) are allocated and freed directly.
+struct Pools {
+    std::mutex mu;
+    std::map<int, std::multimap<size_t, void*>> bufs;
+    std::map<int, size_t> pooled_bytes;
+    std::map<int, std::vector<hipStream_t>> streams;
+    std::map<int, std::vector<hipEvent_t>> events;
+    static Pools& get() { static Pools* p = new Pools(); return *p; }      // lives as long as the process
+};
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+inline size_t size_class(size_t b) {
+    if (b < 256) return 256;
+    if (b <= (1u << 20)) { size_t c = 256; while (c < b) c <<= 1; return c; }
+    return (b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+}
+constexpr size_t POOL_MAX_BUF = (size_t)64 << 20, POOL_MAX_TOTAL = (size_t)2 << 30;
+inline int dmalloc(void** p, size_t b) {
+    const size_t cls = size_class(b);
+    if (cls <= POOL_MAX_BUF) {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& m = P.bufs[current_device()];
+        auto it = m.find(cls);
+        if (it != m.end()) { *p = it->second; m.erase(it); P.pooled_bytes[current_device()] -= cls; return 0; }
+    }
+    return hipMalloc(p, cls) == hipSuccess ? 0 : -1;
+}
+inline void dfree(void* p, size_t b, int dev) {        // dev = the device the buffer was allocated on
+    const size_t cls = size_class(b);
+    if (cls <= POOL_MAX_BUF) {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.pooled_bytes[dev] + cls <= POOL_MAX_TOTAL) { P.bufs[dev].emplace(cls, p); P.pooled_bytes[dev] += cls; return; }
+    }
+    (void)hipFree(p);
+}
 inline int h2d(void* d, const void* h, size_t b, Stream& s) {
     if (!b) return 0;
     if (hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
@@ -83,8 +123,36 @@ inline int d2d_async(void* d, const void* s_, size_t b, Stream& s) {
 }
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 using Event = hipEvent_t;
-inline int event_create(Event* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
-inline void event_destroy(Event& e) { (void)hipEventDestroy(e); }
+inline int stream_create(Stream* s) {
+    {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.streams[current_device()];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return 0; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1;
+}
+inline void stream_destroy(Stream& s) {                  // callers synchronise the stream first
+    Pools& P = Pools::get();
+    std::lock_guard<std::mutex> g(P.mu);
+    auto& v = P.streams[current_device()];
+    if (v.size() < 256) v.push_back(s); else (void)hipStreamDestroy(s);
+}
+inline int event_create(Event* e) {
+    {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.events[current_device()];
+        if (!v.empty()) { *e = v.back(); v.pop_back(); return 0; }
+    }
+    return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1;
+}
+inline void event_destroy(Event& e) {
+    Pools& P = Pools::get();
+    std::lock_guard<std::mutex> g(P.mu);
+    auto& v = P.events[current_device()];
+    if (v.size() < 512) v.push_back(e); else (void)hipEventDestroy(e);
+}
 inline int event_record(Event& e, Stream& s) { return hipEventRecord(e, s) == hipSuccess ? 0 : -1; }
 inline int stream_wait(Stream& s, Event& e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
 
@@ -123,12 +191,13 @@ struct EventList {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) rt::dfree(p); p = nullptr; bytes = 0; }
-    int alloc(size_t b) { release(); bytes = b; return rt::dmalloc(&p, b); }
+    void release() { if (p) rt::dfree(p, bytes, dev); p = nullptr; bytes = 0; }
+    int alloc(size_t b) { release(); bytes = b; dev = rt::current_device(); return rt::dmalloc(&p, b); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -142,13 +211,32 @@ inline void put_le32(uint8_t* b, uint32_t v) {
     b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); b[2] = (uint8_t)(v >> 16); b[3] = (uint8_t)(v >> 24);
 }
 
-// SoA array of `words` 32-bit words per item
+// SoA array of `words` 32-bit words per item.  Filled item by item into an item-major staging area (the writes of
+// one item are contiguous; writing word-major directly strides by n words and misses the cache on every store), then
+// transposed in 16-item tiles into the word-major layout the kernels read: soa().
 struct Soa {
-    std::vector<uint32_t> v;
+    std::vector<uint32_t> aos, v;
     size_t n = 0, words = 0;
-    void init(size_t words_, size_t n_) { words = words_; n = n_; v.assign(words_ * n_, 0u); }
-    uint32_t& at(size_t w, size_t i) { return v[w * n + i]; }
-    size_t bytes() const { return v.size() * 4; }
+    bool sealed = false;
+    void init(size_t words_, size_t n_) { words = words_; n = n_; aos.assign(words_ * n_, 0u); v.clear(); sealed = false; }
+    uint32_t& at(size_t w, size_t i) { return aos[i * words + w]; }
+    size_t bytes() const { return aos.size() * 4; }
+    const std::vector<uint32_t>& soa() {
+        if (!sealed) {
+            v.resize(aos.size());
+            constexpr size_t T = 16;
+            for (size_t i0 = 0; i0 < n; i0 += T) {
+                const size_t m = std::min(T, n - i0);
+                for (size_t w = 0; w < words; w++) {
+                    uint32_t* dst = v.data() + w * n + i0;
+                    const uint32_t* src = aos.data() + i0 * words + w;
+                    for (size_t k = 0; k < m; k++) dst[k] = src[k * words];
+                }
+            }
+            sealed = true;
+        }
+        return v;
+    }
 };
 
 // canonical scalar (32 B LE) into SoA words [w0, w0+8); returns false if >= r
@@ -263,7 +351,7 @@ struct Ctx : bbs_ctx {
         if (d_consts.alloc(sizeof(CtxConsts<C>))) return BBS_E_NOMEM;
         return BBS_OK;
     }
-    ~Ctx() override { rt::stream_destroy(stream); }
+    ~Ctx() override { (void)rt::set_device(device); (void)rt::sync(stream); rt::stream_destroy(stream); }
 
     int use() { return rt::set_device(device) ? BBS_E_HIP : BBS_OK; }
 
@@ -397,6 +485,7 @@ struct JobBase : bbs_job {
     bool main_ready = false, aux_ready = false;
     explicit JobBase(Ctx<C>* c) : ctx(c) { main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); }
     ~JobBase() override {
+        (void)ctx->use();            // streams and buffers go back to this device's pools
         if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
         if (main_ready) { rt::sync(main); rt::stream_destroy(main); }
     }
