@@ -575,4 +575,7 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8):
     assert all(r[1] for r in res), "proof_gen mismatch"
     assert all(r[2] for r in res), "proof_verify mismatch"
     assert [int(x) for x in st] == [0 if i % 7 == 0 else 1 for i in range(n)]
+    # the opt-in batch-verification mode returns the same booleans on the same (partly corrupted) batch
+    eng.set_batch_verification(True)
+    assert [int(x) for x in eng.core_proof_verify_batch(proofs, dm, disclosed)] == [int(x) for x in st]
     eng.close()

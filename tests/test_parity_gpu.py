@@ -49,4 +49,4 @@ def test_full_batch_4096(curve):
 
 
 def test_every_item_against_c_oracle():
-    pc.check_batch_vs_c_oracle(None, n=512)
+    pc.check_batch_vs_c_oracle(None, n=1024)
