@@ -10,10 +10,7 @@ struct PvJob : JobBase<C> {
     PvArgs<C> a{};
     PairArgs<C> pa{};
     PvFinishArgs fin{};
-    // batch verification only
-    PipArgs<C> pip{};
-    RlcArgs rlc{};
-    PairArgs<C> pa_sum{};
+    BvState<C> bv{};                  // batch verification only
 };
 
 template <class C>
@@ -106,60 +103,23 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
-    auto add_pairing = [j](PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist) {
-        (void)nm_miller; (void)nm_final; (void)nm_dist;
-#ifdef BBS_HOST_TWIN
-        j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
-        j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
-#else
-        j->stages.push_back({nm_dist, [j, pargs, aux]() { return rt::launch<PairDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
-#endif
-    };
     j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
     if (!ctx->batch_verify) {
         // every item its own pairing product, on the job's second stream concurrently with the MSM / challenge
         // stages: it needs only the proof's own points (canonical, converted in the kernel) and the
         // host-validated flag
-        add_pairing(&j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
+        add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
         // batch verification (pippenger.hpp): one combined pairing check over the items whose challenge matched;
         // if it fails, the per-item kernel decides (its lanes return at once when the combined check passed)
-        constexpr int NW = 16, M = 2;
-        const size_t n_pad = (n + 3) & ~(size_t)3;
-        PipArgs<C>& pp = job->pip;
-        RlcArgs& rl = job->rlc;
-        pp.n = n; pp.n_pad = n_pad; pp.M = M; pp.NW = NW;
-        pp.pts0 = a.aff; pp.pts1 = a.aff + (size_t)2 * N * n;                 // a_bar, b_bar (Montgomery, by PvMsmPart)
-        uint8_t* dig = job->template scratch<uint8_t>((size_t)NW * n_pad + 4, rc);
-        pp.dig = dig;
-        pp.list = job->template scratch<uint32_t>((size_t)M * NW * std::max<size_t>(n, 1), rc);
-        pp.buckets = job->template scratch<uint32_t>((size_t)3 * N * M * NW * PIP_NB, rc);
-        pp.segs = job->template scratch<uint32_t>((size_t)3 * N * M * NW * (PIP_NB / PIP_SEG), rc);
-        pp.wins = job->template scratch<uint32_t>((size_t)3 * N * M * NW, rc);
-        pp.out = job->template scratch<uint32_t>((size_t)M * 2 * N, rc);
-        int8_t* flags = job->up(std::vector<int8_t>{1, 0, 0, 0}, rc);          // [0] gate of the combined check, [1] its result
-        uint32_t* fm_sum = job->template scratch<uint32_t>((size_t)2 * 12 * N, rc);
-        if (rc) return rc;
-        if (rt::dmemset(dig, 0, (size_t)NW * n_pad, job->stream())) return BBS_E_HIP;
-        rl.n = n; rl.n_pad = n_pad; rl.status = a.status; rl.dig = dig; rl.batch_ok = flags + 1;
-        ctx->next_rlc_seed(rl.seed);
-        PairArgs<C>& ps = job->pa_sum;
-        ps.n = 1; ps.cc = a.cc; ps.pa = pp.out; ps.pb = pp.out + 2 * N; ps.negate_b = 1; ps.canonical = 0;
-        ps.gate_arr = flags; ps.gate = 1; ps.out = flags + 1; ps.fmiller = fm_sum;
         pa.gate_arr = a.status; pa.gate = 2;                                     // fallback: items still pending
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
-        j->stages.push_back({"rlc_scalars", [j]() { return rt::launch<RlcScalars>(j->stream(), j->rlc, j->n); }});
-        j->stages.push_back({"pip_buckets", [j]() { return rt::launch<PipBuckets<C>>(j->stream(), j->pip, (size_t)j->pip.M * j->pip.NW * PIP_NB); }});
-        j->stages.push_back({"pip_segments", [j]() { return rt::launch<PipSegments<C>>(j->stream(), j->pip, (size_t)j->pip.M * j->pip.NW * (PIP_NB / PIP_SEG)); }});
-        j->stages.push_back({"pip_windows", [j]() { return rt::launch<PipWindows<C>>(j->stream(), j->pip, (size_t)j->pip.M * j->pip.NW); }});
-        j->stages.push_back({"pip_final", [j]() { return rt::launch<PipFinal<C>>(j->stream(), j->pip, (size_t)j->pip.M); }});
-        add_pairing(&j->pa_sum, 0, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane");
-        j->stages.push_back({"rlc_apply", [j]() { return rt::launch<RlcApply>(j->stream(), j->rlc, j->n); }});
-        add_pairing(&j->pa, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");
+        // a_bar, b_bar in Montgomery form, stored by PvMsmPart
+        if ((rc = add_batch_verification<C>(j, &j->bv, ctx, n, a.cc, a.status, a.aff, a.aff + (size_t)2 * N * n, 1, &j->pa))) return rc;
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }});
     }
     *out = job.release();

@@ -9,6 +9,7 @@ struct VfJob : JobBase<C> {
     using JobBase<C>::JobBase;
     VfArgs<C> a{};
     PairArgs<C> pa{};
+    BvState<C> bv{};                  // batch verification only
 };
 
 template <class C>
@@ -59,12 +60,12 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->stream(), j->a, j->n * VF_NPARTS); }});
     j->stages.push_back({"vf_combine", [j]() { return rt::launch<VfCombine<C>>(j->stream(), j->a, j->n); }});
-#ifdef BBS_HOST_TWIN
-    j->stages.push_back({"pair_miller", [j]() { return rt::launch<PairMiller<C>>(j->stream(), j->pa, j->n * 2); }});
-    j->stages.push_back({"pair_final_exp", [j]() { return rt::launch<PairFinal<C>>(j->stream(), j->pa, j->n); }});
-#else
-    j->stages.push_back({"pairing_6lane", [j]() { return rt::launch<PairDist<C>>(j->stream(), j->pa, ((j->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }});
-#endif
+    if (!ctx->batch_verify) {
+        add_pairing_stages<C>(j, &j->pa, 0, "pair_miller", "pair_final_exp", "pairing_6lane");
+    } else {
+        // e(A, W) e(e A - B, BP2) == 1 for all pending items at once: A and e A - B are in a.aff (Montgomery)
+        if ((rc = add_batch_verification<C>(j, &j->bv, ctx, n, a.cc, a.status, a.aff, a.aff + (size_t)2 * N * n, 0, &j->pa))) return rc;
+    }
     *out = job.release();
     return BBS_OK;
 }

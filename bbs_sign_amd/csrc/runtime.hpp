@@ -538,3 +538,65 @@ struct JobBase : bbs_job {
     }
 };
 
+
+// =============================================================================================
+// batch verification plumbing shared by proof_verify and verify (pippenger.hpp)
+// =============================================================================================
+template <class C>
+struct BvState {
+    PipArgs<C> pip{};
+    RlcArgs rlc{};
+    PairArgs<C> pa_sum{};
+};
+
+// one pairing product check as stages on the job's main (aux = 0) or second stream
+template <class C, class J>
+void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist) {
+    (void)nm_miller; (void)nm_final; (void)nm_dist;
+#ifdef BBS_HOST_TWIN
+    j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
+    j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
+#else
+    j->stages.push_back({nm_dist, [j, pargs, aux]() { return rt::launch<PairDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
+#endif
+}
+
+// Stages of the combined check over the items whose status is 2: coefficients, bucket-method sums of the two point
+// sets (Montgomery affine, [2N][n] each), ONE pairing product e(sum pts0, pk) e(+-sum pts1, BP2), and -- only for
+// what is still pending afterwards -- the per-item kernel `fallback` (gate: status == 2).
+template <class C, class J>
+int add_batch_verification(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const CtxConsts<C>* cc, int8_t* status,
+                           const uint32_t* pts0, const uint32_t* pts1, int negate_b, PairArgs<C>* fallback) {
+    constexpr int N = C::FpP::N;
+    constexpr int NW = 16, M = 2;
+    const size_t n_pad = (n + 3) & ~(size_t)3;
+    int rc = BBS_OK;
+    PipArgs<C>& pp = bv->pip;
+    RlcArgs& rl = bv->rlc;
+    pp.n = n; pp.n_pad = n_pad; pp.M = M; pp.NW = NW; pp.pts0 = pts0; pp.pts1 = pts1;
+    uint8_t* dig = j->template scratch<uint8_t>((size_t)NW * n_pad + 4, rc);
+    pp.dig = dig;
+    pp.list = j->template scratch<uint32_t>((size_t)M * NW * std::max<size_t>(n, 1), rc);
+    pp.buckets = j->template scratch<uint32_t>((size_t)3 * N * M * NW * PIP_NB, rc);
+    pp.segs = j->template scratch<uint32_t>((size_t)3 * N * M * NW * (PIP_NB / PIP_SEG), rc);
+    pp.wins = j->template scratch<uint32_t>((size_t)3 * N * M * NW, rc);
+    pp.out = j->template scratch<uint32_t>((size_t)M * 2 * N, rc);
+    int8_t* flags = j->up(std::vector<int8_t>{1, 0, 0, 0}, rc);          // [0] gate of the combined check, [1] its result
+    uint32_t* fm_sum = j->template scratch<uint32_t>((size_t)2 * 12 * N, rc);
+    if (rc) return rc;
+    if (rt::dmemset(dig, 0, (size_t)NW * n_pad, j->stream())) return BBS_E_HIP;
+    rl.n = n; rl.n_pad = n_pad; rl.status = status; rl.dig = dig; rl.batch_ok = flags + 1;
+    ctx->next_rlc_seed(rl.seed);
+    PairArgs<C>& ps = bv->pa_sum;
+    ps.n = 1; ps.cc = cc; ps.pa = pp.out; ps.pb = pp.out + 2 * N; ps.negate_b = negate_b; ps.canonical = 0;
+    ps.gate_arr = flags; ps.gate = 1; ps.out = flags + 1; ps.fmiller = fm_sum;
+    j->stages.push_back({"rlc_scalars", [j, bv]() { return rt::launch<RlcScalars>(j->stream(), bv->rlc, j->n); }});
+    j->stages.push_back({"pip_buckets", [j, bv]() { return rt::launch<PipBuckets<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * PIP_NB); }});
+    j->stages.push_back({"pip_segments", [j, bv]() { return rt::launch<PipSegments<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * (PIP_NB / PIP_SEG)); }});
+    j->stages.push_back({"pip_windows", [j, bv]() { return rt::launch<PipWindows<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW); }});
+    j->stages.push_back({"pip_final", [j, bv]() { return rt::launch<PipFinal<C>>(j->stream(), bv->pip, (size_t)bv->pip.M); }});
+    add_pairing_stages<C>(j, &bv->pa_sum, 0, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane");
+    j->stages.push_back({"rlc_apply", [j, bv]() { return rt::launch<RlcApply>(j->stream(), bv->rlc, j->n); }});
+    add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");
+    return BBS_OK;
+}

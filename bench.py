@@ -220,6 +220,19 @@ def main():
             extras["bls12_381"]["proof_verify_batch_verification"]["batch_16384_per_s"] = 4 * n * 48 / (gms * 1e-3)
             for j in big:
                 j.free()
+            # core_verify in the same mode
+            eng.set_batch_verification(True)
+            vj = [eng.core_verify_upload(sigs, msgs) for _ in range(32)]
+            eng.set_batch_verification(False)
+            for j in vj:
+                j.run()
+            for j in vj:
+                j.wait()
+                assert (j.status() == 1).all()
+            vms, _ = Job.run_many_timed(vj, 96)
+            extras["bls12_381"]["verify_batch_verification"] = {"verify_per_s": n * 96 / (vms * 1e-3), "batches_in_flight": len(vj)}
+            for j in vj:
+                j.free()
         # host-inclusive form: bbs_core_proof_verify_batch on host buffers = validation + packing (C++),
         # H2D of the proofs, kernels, D2H of the statuses -- never the headline, which starts from HBM-resident batches
         import ctypes

@@ -88,9 +88,10 @@ void bbs_ctx_destroy(bbs_ctx* ctx);
  * bbs_ctx_set_generators.  Table bytes = (count+1) * ceil(256/w) * (2^w - 1) * 2 * fp_bytes. */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
-/* Batch verification for core_proof_verify (off by default).  When enabled, the n two-pairing products of a
- * batch (src/proof_verify.rs:112-115) are replaced by ONE product over random linear combinations
- * sum rho_i * Abar_i, sum rho_i * Bbar_i (128-bit rho_i derived from a secret seed; bucket-method
+/* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
+ * products of a batch (src/proof_verify.rs:112-115, src/verify.rs:88-92) are replaced by ONE product over random
+ * linear combinations of the items' G1 arguments (sum rho_i * Abar_i, sum rho_i * Bbar_i; for verify
+ * sum rho_i * A_i, sum rho_i * (e_i A_i - B_i); 128-bit rho_i derived from a secret seed; bucket-method
  * multi-scalar multiplication on the device) taken over the items that passed every earlier check; only if
  * that combined check fails are the items checked one by one.  The booleans equal the reference's except with
  * probability 2^-128 per batch.  seed32 = NULL draws the seed from the operating system; a caller-supplied

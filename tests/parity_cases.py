@@ -465,6 +465,19 @@ def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
     assert list(batch.core_proof_verify_batch(fp, dm, disclosed, headers, phs)) == want
     op = bbs.Proof(fp[2].a_bar, fp[2].b_bar, fp[2].d, fp[2].e_cap, fp[2].r1_cap, fp[2].r3_cap, fp[2].commitments, fp[2].challenge)
     assert bbs.core_proof_verify(suite, pk, op, gens, headers[2], phs[2], dm[2], disclosed[2], api_id) is False
+    # 3b. core_verify in the same mode: all valid, then forged A / identity A / wrong message / wrong header
+    assert list(batch.core_verify_batch(sigs, msgs, headers)) == [1] * n
+    vs = [Signature(s_.a, s_.e) for s_ in sigs]
+    vm = [list(m) for m in msgs]
+    vh = list(headers)
+    vs[0] = Signature(c.g1_add(sigs[0].a, c.g1), sigs[0].e)
+    vs[3] = Signature(None, sigs[3].e)
+    vm[5][0] = (vm[5][0] + 1) % c.r
+    vh[8] = vh[8] + b"x"
+    vs[6] = Signature(sigs[6].a, (sigs[6].e + 1) % c.r)
+    want_v = list(exact.core_verify_batch(vs, vm, vh))
+    assert want_v == [0, 1, 1, 0, 1, 0, 0, 1, 0][:n], want_v
+    assert list(batch.core_verify_batch(vs, vm, vh)) == want_v
     # 4. a resident job can be run again and a context can go back to the per-item mode
     job = batch.core_proof_verify_upload(fp, dm, disclosed, headers, phs)
     for _ in range(2):
