@@ -310,9 +310,11 @@ struct Ctx : bbs_ctx {
     bool batch_verify = false;
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
+    std::mutex mu;                   // uploads may come from several host threads: counter and constant sync
 
     // secret seed of the next batch: SHA-256(context seed || counter)
     void next_rlc_seed(uint32_t* out8) {
+        std::lock_guard<std::mutex> g(mu);
         Sha256 s;
         sha256_init(s);
         for (int k = 0; k < 8; k++) sha256_word(s, rlc_seed[k]);
@@ -381,6 +383,7 @@ struct Ctx : bbs_ctx {
     }
 
     int sync_consts() {
+        std::lock_guard<std::mutex> g(mu);
         if (!consts_dirty) return BBS_OK;
         hc.tables = d_tables.as<uint32_t>();
         if (rt::h2d(d_consts.p, &hc, sizeof(hc), stream)) return BBS_E_HIP;
