@@ -20,6 +20,11 @@
 //   PipSegments: lane per 16 buckets: running sums  sum_b (b - 16 s) B_b  and  sum_b B_b, then  + 16 s * (sum B_b).
 //   PipWindows : lane per window: adds its 16 segments and shifts by 2^(8 w).
 //   PipFinal   : lane per point set: adds the windows, one inversion, affine Montgomery out.
+// Batch verification does not need the one 128-bit combination: the 16 windows are 16 INDEPENDENT 8-bit
+// combinations (digit bytes of a hash are independent and uniform), each checked by its own pairing product; a bad
+// item survives one of them with probability <= 1/256 and all of them with 2^-128.  So PipWindowSums (no shifts)
+// writes 16 affine sums per point set and the 16 checks run side by side in two wavefronts of the pairing kernel --
+// no 120 doublings, no final addition chain.
 #pragma once
 #include "stages.hpp"
 
@@ -129,13 +134,28 @@ struct PipFinal {
     }
 };
 
+// batch verification: window sums without the 2^(8 w) shift, normalised: out[m] is an SoA array of NW affine points
+// ([2N][NW], Montgomery), i.e. NW "items" for the pairing stage
+template <class C>
+struct PipWindowSums {
+    static __host__ __device__ void run(const PipArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t TS = (size_t)a.M * a.NW * (PIP_NB / PIP_SEG);
+        const size_t m = t / (size_t)a.NW, w = t - m * (size_t)a.NW;
+        G1Jac<C> acc = g1j_inf<C>();
+        for (int s = 0; s < PIP_NB / PIP_SEG; s++) acc = g1j_add<C>(acc, g1j_load<C>(a.segs, TS, t * (PIP_NB / PIP_SEG) + s));
+        g1a_store_mont<C>(a.out + m * 2 * N * a.NW, (size_t)a.NW, w, g1j_to_aff<C>(acc));
+    }
+};
+
 // ---- batch verification glue ------------------------------------------------------------------
 struct RlcArgs {
     size_t n, n_pad;
     int8_t* status;           // 2 = challenge matched, pairing pending
     uint32_t seed[8];         // secret per-batch seed
     uint8_t* dig;             // [16][n_pad]
-    const int8_t* batch_ok;   // [1] result of the combined pairing check
+    const int8_t* batch_ok;   // [n_checks] results of the combined pairing checks
+    int n_checks;
 };
 
 // rho_i = first 128 bits of SHA-256(seed || I2OSP(i, 8)) for pending items, 0 otherwise
@@ -153,10 +173,13 @@ struct RlcScalars {
     }
 };
 
-// the combined check passed: every pending item's pairing product is 1
+// all combined checks passed: every pending item's pairing product is 1
 struct RlcApply {
     static __host__ __device__ void run(const RlcArgs& a, size_t i) {
-        if (a.batch_ok[0] == 1 && a.status[i] == 2) a.status[i] = 1;
+        if (a.status[i] != 2) return;
+        int ok = 1;
+        for (int k = 0; k < a.n_checks; k++) ok &= (a.batch_ok[k] == 1);
+        if (ok) a.status[i] = 1;
     }
 };
 

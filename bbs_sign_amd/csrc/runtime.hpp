@@ -565,8 +565,8 @@ void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller
 }
 
 // Stages of the combined check over the items whose status is 2: coefficients, bucket-method sums of the two point
-// sets (Montgomery affine, [2N][n] each), ONE pairing product e(sum pts0, pk) e(+-sum pts1, BP2), and -- only for
-// what is still pending afterwards -- the per-item kernel `fallback` (gate: status == 2).
+// sets (Montgomery affine, [2N][n] each) per 8-bit window, 16 pairing products e(sum_w pts0, pk) e(+-sum_w pts1, BP2)
+// side by side, and -- only for what is still pending afterwards -- the per-item kernel `fallback` (gate: status == 2).
 template <class C, class J>
 int add_batch_verification(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const CtxConsts<C>* cc, int8_t* status,
                            const uint32_t* pts0, const uint32_t* pts1, int negate_b, PairArgs<C>* fallback) {
@@ -583,21 +583,23 @@ int add_batch_verification(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const Ct
     pp.buckets = j->template scratch<uint32_t>((size_t)3 * N * M * NW * PIP_NB, rc);
     pp.segs = j->template scratch<uint32_t>((size_t)3 * N * M * NW * (PIP_NB / PIP_SEG), rc);
     pp.wins = j->template scratch<uint32_t>((size_t)3 * N * M * NW, rc);
-    pp.out = j->template scratch<uint32_t>((size_t)M * 2 * N, rc);
-    int8_t* flags = j->up(std::vector<int8_t>{1, 0, 0, 0}, rc);          // [0] gate of the combined check, [1] its result
-    uint32_t* fm_sum = j->template scratch<uint32_t>((size_t)2 * 12 * N, rc);
+    pp.out = j->template scratch<uint32_t>((size_t)M * 2 * N * NW, rc);          // [M][2N][NW]: NW affine sums per set
+    // [0 .. NW) gates of the NW combined checks (all 1), [NW .. 2 NW) their results
+    std::vector<int8_t> fl(2 * NW, 0);
+    for (int k = 0; k < NW; k++) fl[k] = 1;
+    int8_t* flags = j->up(fl, rc);
+    uint32_t* fm_sum = j->template scratch<uint32_t>((size_t)2 * 12 * N * NW, rc);
     if (rc) return rc;
     if (rt::dmemset(dig, 0, (size_t)NW * n_pad, j->stream())) return BBS_E_HIP;
-    rl.n = n; rl.n_pad = n_pad; rl.status = status; rl.dig = dig; rl.batch_ok = flags + 1;
+    rl.n = n; rl.n_pad = n_pad; rl.status = status; rl.dig = dig; rl.batch_ok = flags + NW; rl.n_checks = NW;
     ctx->next_rlc_seed(rl.seed);
     PairArgs<C>& ps = bv->pa_sum;
-    ps.n = 1; ps.cc = cc; ps.pa = pp.out; ps.pb = pp.out + 2 * N; ps.negate_b = negate_b; ps.canonical = 0;
-    ps.gate_arr = flags; ps.gate = 1; ps.out = flags + 1; ps.fmiller = fm_sum;
+    ps.n = NW; ps.cc = cc; ps.pa = pp.out; ps.pb = pp.out + (size_t)2 * N * NW; ps.negate_b = negate_b; ps.canonical = 0;
+    ps.gate_arr = flags; ps.gate = 1; ps.out = flags + NW; ps.fmiller = fm_sum;
     j->stages.push_back({"rlc_scalars", [j, bv]() { return rt::launch<RlcScalars>(j->stream(), bv->rlc, j->n); }});
     j->stages.push_back({"pip_buckets", [j, bv]() { return rt::launch<PipBuckets<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * PIP_NB); }});
     j->stages.push_back({"pip_segments", [j, bv]() { return rt::launch<PipSegments<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * (PIP_NB / PIP_SEG)); }});
-    j->stages.push_back({"pip_windows", [j, bv]() { return rt::launch<PipWindows<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW); }});
-    j->stages.push_back({"pip_final", [j, bv]() { return rt::launch<PipFinal<C>>(j->stream(), bv->pip, (size_t)bv->pip.M); }});
+    j->stages.push_back({"pip_window_sums", [j, bv]() { return rt::launch<PipWindowSums<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW); }});
     add_pairing_stages<C>(j, &bv->pa_sum, 0, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane");
     j->stages.push_back({"rlc_apply", [j, bv]() { return rt::launch<RlcApply>(j->stream(), bv->rlc, j->n); }});
     add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");

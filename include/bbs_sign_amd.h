@@ -89,13 +89,13 @@ void bbs_ctx_destroy(bbs_ctx* ctx);
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
 /* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
- * products of a batch (src/proof_verify.rs:112-115, src/verify.rs:88-92) are replaced by ONE product over random
+ * products of a batch (src/proof_verify.rs:112-115, src/verify.rs:88-92) are replaced by 16 products over random
  * linear combinations of the items' G1 arguments (sum rho_i * Abar_i, sum rho_i * Bbar_i; for verify
- * sum rho_i * A_i, sum rho_i * (e_i A_i - B_i); 128-bit rho_i derived from a secret seed; bucket-method
- * multi-scalar multiplication on the device) taken over the items that passed every earlier check; only if
- * that combined check fails are the items checked one by one.  The booleans equal the reference's except with
- * probability 2^-128 per batch.  seed32 = NULL draws the seed from the operating system; a caller-supplied
- * seed must be secret and fresh.  Takes effect for jobs uploaded afterwards. */
+ * sum rho_i * A_i, sum rho_i * (e_i A_i - B_i)) with 16 independent 8-bit coefficients rho_i per item derived
+ * from a secret seed (bucket-method multi-scalar multiplication on the device), taken over the items that passed
+ * every earlier check; only if one of those combined checks fails are the items checked one by one.  The booleans
+ * equal the reference's except with probability 2^-128 per batch.  seed32 = NULL draws the seed from the operating
+ * system; a caller-supplied seed must be secret and fresh.  Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32);
 
 /* generators = [Q1, H_1 .. H_L] (count = L+1 affine G1 points) and the api_id they belong to:
