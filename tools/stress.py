@@ -1,0 +1,18 @@
+"""Ad-hoc (GPU box): seeded random batches with ragged inputs and corruptions against the oracle, many seeds."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity_cases as pc
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+t0 = time.time()
+seed = 100
+done = 0
+while time.time() - t0 < budget:
+    for curve in ("bls12_381", "bn254"):
+        L = [0, 1, 2, 5, 7, 12][seed % 6]
+        pc.check_random_batch(curve, None, n=8 + seed % 9, L=L, seed=seed)
+        pc.check_batch_verification(curve, None, n=9, L=4 + seed % 3, seed=seed)
+        done += 1
+    seed += 1
+    print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
+print("stress ok:", done, "cases")
