@@ -283,8 +283,10 @@ def main():
         pb, st = eb.core_proof_gen_batch(sb, mb, db, rb)
         assert (st == 1).all()
         jb = eb.core_proof_verify_upload(pb, [m[:R] for m in mb], db)
+        dmb = [m[:R] for m in mb]
         extras["bn254"] = {"sign": rate(eb.core_sign_upload(mb)), "verify": rate(eb.core_verify_upload(sb, mb)),
-                           "proof_gen": rate(eb.core_proof_gen_upload(sb, mb, db, rb)), "proof_verify": rate(jb)}
+                           "proof_gen": rate(eb.core_proof_gen_upload(sb, mb, db, rb)), "proof_verify": rate(jb),
+                           "proof_verify_8_in_flight": rate8(lambda: eb.core_proof_verify_upload(pb, dmb, db))}
         assert (jb.status() == 1).all()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
