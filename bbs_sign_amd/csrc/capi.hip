@@ -74,6 +74,20 @@ static int selftest_inv(const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fer
     return BBS_OK;
 }
 
+// host arithmetic self-test: one half of an Fp4 square by the four-column form (tower.hpp fp4_sqr_part)
+template <class C>
+static int selftest_fp4sqr(int hi, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr size_t FPB = 4 * P::NC;
+    Fp2<C> A, B;
+    if (!fe_from_le_bytes<P>(a, A.c0) || !fe_from_le_bytes<P>(a + FPB, A.c1) || !fe_from_le_bytes<P>(b, B.c0) ||
+        !fe_from_le_bytes<P>(b + FPB, B.c1)) return BBS_E_ARG;
+    const Fp2<C> r = fp4_sqr_part<C>(hi != 0, A, B);
+    fe_to_le_bytes<P>(r.c0, out);
+    fe_to_le_bytes<P>(r.c1, out + FPB);
+    return BBS_OK;
+}
+
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -499,6 +513,13 @@ int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out
     if (!x || !out_safegcd || !out_fermat) return BBS_E_ARG;
     if (curve == BBS_CURVE_BLS12_381) return scalar_field ? selftest_inv<BlsFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BlsFpParams>(x, out_safegcd, out_fermat);
     if (curve == BBS_CURVE_BN254) return scalar_field ? selftest_inv<BnFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BnFpParams>(x, out_safegcd, out_fermat);
+    return BBS_E_ARG;
+}
+
+int bbs_selftest_fp4sqr(int curve, int hi, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (!a || !b || !out) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return selftest_fp4sqr<BlsCurve>(hi, a, b, out);
+    if (curve == BBS_CURVE_BN254) return selftest_fp4sqr<BnCurve>(hi, a, b, out);
     return BBS_E_ARG;
 }
 

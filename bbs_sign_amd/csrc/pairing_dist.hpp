@@ -303,52 +303,6 @@ BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEnt
 //   g0' = 3 A2[0] - 2 g0   g3' = 3 A2[1] + 2 g3
 //   g1' = 3 xi C2[1] + 2 g1   g4' = 3 C2[0] - 2 g4
 //   g2' = 3 B2[0] - 2 g2   g5' = 3 B2[1] + 2 g5
-#if BBS_DIST_LAZY
-// The Fp4 square of a pair as FOUR limb-column products and one reduction pair, the same instruction stream on
-// both lanes of the pair (operands selected per lane):
-//   low lane  (A = x0, B = x1):  x0^2 + xi x1^2 ;  high lane (A = x1, B = x0):  2 x0 x1
-//   slot      low lane                       high lane
-//   X1        (A0 + A1)(A0 - A1)             2 A0 B0
-//   X2        2 A0 A1                        2 A1 B1
-//   X3        (B0 + B1)(B0 - B1)             2 A0 B1
-//   X4        2 B0 B1                        2 A1 B0
-//   re = X1 + K p^2 + (low ? X3 - X4 : -X2) ;  im = X3 + X4 + (low ? X2 : 0)          (xi = 1 + u)
-// 4 N^2 + 2 N^2 multiply-accumulates instead of two fused Fp2 squares (8 N^2) plus their linear chains.
-template <class C>
-__device__ __forceinline__ Fp2<C> d_fp4_sqr_part(bool hi, const Fp2<C>& A, const Fp2<C>& B) {
-    using P = typename C::FpP;
-    constexpr int N = P::N;
-    static_assert(C::K::XI_C0 == 1, "xi = 1 + u");
-    const Fp<C> dA = fe_sub<P>(A.c0, A.c1), dB = fe_sub<P>(B.c0, B.c1);      // normal: keeps the columns small
-    uint32_t l1[N], r1[N], l2[N], r2[N], l3[N], r3[N], l4[N], r4[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const uint32_t a0 = A.c0.v[i], a1 = A.c1.v[i], b0 = B.c0.v[i], b1 = B.c1.v[i];
-        l1[i] = hi ? (a0 << 1) : (a0 + a1);  r1[i] = hi ? b0 : dA.v[i];
-        l2[i] = hi ? (a1 << 1) : (a0 << 1);  r2[i] = hi ? b1 : a1;
-        l3[i] = hi ? (a0 << 1) : (b0 + b1);  r3[i] = hi ? b1 : dB.v[i];
-        l4[i] = hi ? (a1 << 1) : (b0 << 1);  r4[i] = hi ? b0 : b1;
-    }
-    uint64_t x1[2 * N - 1], x2[2 * N - 1], x3[2 * N - 1], x4[2 * N - 1];
-    r28::cols_zero<P>(x1); r28::cols_zero<P>(x2); r28::cols_zero<P>(x3); r28::cols_zero<P>(x4);
-    r28::cols_mac<P>(x1, l1, r1);
-    r28::cols_mac<P>(x2, l2, r2);
-    r28::cols_mac<P>(x3, l3, r3);
-    r28::cols_mac<P>(x4, l4, r4);
-#pragma unroll
-    for (int c = 0; c < 2 * N - 1; c++) {
-        const uint64_t re = x1[c] + P::WP2X[c] + (hi ? (0 - x2[c]) : (x3[c] - x4[c]));
-        const uint64_t im = x3[c] + x4[c] + (hi ? 0 : x2[c]);
-        x1[c] = re;
-        x2[c] = im;
-    }
-    Fp2<C> r;
-    r28::cols_reduce<P>(r.c0.v, x1);
-    r28::cols_reduce<P>(r.c1.v, x2);
-    return r;
-}
-#endif
-
 template <class C>
 BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     const bool hi = L.m >= 3;
@@ -356,8 +310,8 @@ BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     Fp2<C> px = d_coef<C>(L, g, partner);
     Fp2<C> sq;                                              // lane m<3: X2[0] of pair m ; m>=3: X2[1] of pair m-3
 #if BBS_DIST_LAZY
-    if constexpr (C::K::XI_C0 == 1) {
-        sq = d_fp4_sqr_part<C>(hi, g, px);
+    if constexpr (C::K::XI_C0 == 1) {                       // BN254 (xi = 9 + u, 10 limbs): measured no faster, old form kept
+        sq = fp4_sqr_part<C>(hi, g, px);                    // tower.hpp: four column products, one reduction pair
     } else
 #endif
     {

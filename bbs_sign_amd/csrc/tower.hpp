@@ -146,6 +146,57 @@ BBS_HD Fp2<C> f2acc_finish(F2Acc<C>& acc) {
     return r;
 }
 
+// One half of an Fp4 square (Granger-Scott cyclotomic squaring; Fp4 = Fp2[s]/(s^2 - xi), xi = c + u) as FOUR
+// limb-column products and one reduction pair, the same instruction stream for both halves (operands selected by
+// `hi`; the two lanes of a pair in pairing_dist.hpp run it side by side):
+//   low  half (A = x0, B = x1):  x0^2 + xi x1^2 ;  high half (A = x1, B = x0):  2 x0 x1
+//   slot      low                            high
+//   X1        (A0 + A1)(A0 - A1)             2 A0 B0
+//   X2        2 A0 A1                        2 A1 B1
+//   X3        (B0 + B1)(B0 - B1)             2 A0 B1
+//   X4        2 B0 B1                        2 A1 B0
+//   re = X1 + K p^2 + (low ? c X3 - X4 : -X2) ;  im = X3 + (low ? c X4 + X2 : X4)
+// 4 N^2 + 2 N^2 multiply-accumulates instead of two fused Fp2 squares (8 N^2) plus their linear chains.
+// Column bounds: differences are taken reduced (normal limbs); for c = 9 (BN254) the sums as well, so that
+// c X3 and c X4 stay below 2^63.5 (N = 10).  Host-testable: bbs_selftest_fp4sqr.
+template <class C>
+BBS_HD Fp2<C> fp4_sqr_part(bool hi, const Fp2<C>& A, const Fp2<C>& B) {
+    using P = typename C::FpP;
+    constexpr int N = P::N;
+    constexpr uint32_t XC = C::K::XI_C0;
+    const Fp<C> dA = fe_sub<P>(A.c0, A.c1), dB = fe_sub<P>(B.c0, B.c1);
+    Fp<C> sA, sB;
+    if constexpr (XC == 1) { sA = fe_add_nr<P>(A.c0, A.c1); sB = fe_add_nr<P>(B.c0, B.c1); }
+    else { sA = fe_add<P>(A.c0, A.c1); sB = fe_add<P>(B.c0, B.c1); }
+    uint32_t l1[N], r1[N], l2[N], r2[N], l3[N], r3[N], l4[N], r4[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t a0 = A.c0.v[i], a1 = A.c1.v[i], b0 = B.c0.v[i], b1 = B.c1.v[i];
+        l1[i] = hi ? (a0 << 1) : sA.v[i];    r1[i] = hi ? b0 : dA.v[i];
+        l2[i] = hi ? (a1 << 1) : (a0 << 1);  r2[i] = hi ? b1 : a1;
+        l3[i] = hi ? (a0 << 1) : sB.v[i];    r3[i] = hi ? b1 : dB.v[i];
+        l4[i] = hi ? (a1 << 1) : (b0 << 1);  r4[i] = hi ? b0 : b1;
+    }
+    uint64_t x1[2 * N - 1], x2[2 * N - 1], x3[2 * N - 1], x4[2 * N - 1];
+    r28::cols_zero<P>(x1); r28::cols_zero<P>(x2); r28::cols_zero<P>(x3); r28::cols_zero<P>(x4);
+    r28::cols_mac<P>(x1, l1, r1);
+    r28::cols_mac<P>(x2, l2, r2);
+    r28::cols_mac<P>(x3, l3, r3);
+    r28::cols_mac<P>(x4, l4, r4);
+#pragma unroll
+    for (int c = 0; c < 2 * N - 1; c++) {
+        const uint64_t cx3 = XC * x3[c], cx4 = XC * x4[c];
+        const uint64_t re = x1[c] + P::WP2X[c] + (hi ? (0 - x2[c]) : (cx3 - x4[c]));
+        const uint64_t im = x3[c] + (hi ? x4[c] : (cx4 + x2[c]));
+        x1[c] = re;
+        x2[c] = im;
+    }
+    Fp2<C> r;
+    r28::cols_reduce<P>(r.c0.v, x1);
+    r28::cols_reduce<P>(r.c1.v, x2);
+    return r;
+}
+
 template <class C>
 BBS_HD Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
 #ifndef BBS_NO_FUSED_F2

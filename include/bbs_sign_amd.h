@@ -262,6 +262,9 @@ int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, u
 /* Host arithmetic self-test (no GPU): x^-1 in the base field (scalar_field = 0, fp_bytes LE) or the scalar field
  * (1, 32 bytes LE) by the safegcd inversion the kernels use and by the Fermat power x^(p-2). */
 int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat);
+/* Host arithmetic self-test (no GPU): one half of an Fp4 square as the pairing kernel computes it (four limb-column
+ * products, one reduction pair): hi = 0: a^2 + xi b^2, hi = 1: 2 a b, for a, b in Fp2 (c0 || c1, canonical LE). */
+int bbs_selftest_fp4sqr(int curve, int hi, const uint8_t* a, const uint8_t* b, uint8_t* out);
 int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
                        uint8_t* out);
 

@@ -76,3 +76,41 @@ def test_safegcd_inversion(libs, cid, curve):
                 want = pow(x, -1, mod) if x else 0
                 assert int.from_bytes(o1.tobytes(), "little") == want, (cid, sf, hex(x))
                 assert int.from_bytes(o2.tobytes(), "little") == want
+
+
+@pytest.mark.parametrize("cid,curve,xi0,nl", [(0, BLS12_381, 1, 14), (1, BN254, 9, 10)])
+def test_fp4_half_square(libs, cid, curve, xi0, nl):
+    """The four-column Fp4 half-square of the cyclotomic squaring (low half a^2 + xi b^2, high half 2 a b) against
+    big integers; operands chosen through their INTERNAL representation (x R^-1 is passed so that the Montgomery
+    form is x) to put all-ones limb patterns and the largest admissible values into the column sums."""
+    p = curve.p
+    fpb = curve.fp_bytes
+    R = 1 << (28 * nl)
+    Rinv = pow(R, -1, p)
+    rng = random.Random(31 + cid)
+    top = p.bit_length()
+    internal = [p - 1, (1 << (top - 1)) - 1, (1 << (top - 2)) - 1, 0, 1, int("0fffffff" * nl, 16) % p, (1 << (top - 1)) + 12345]
+    def f2mul(x, y):
+        return ((x[0] * y[0] - x[1] * y[1]) % p, (x[0] * y[1] + x[1] * y[0]) % p)
+    for lib in libs:
+        for trial in range(40):
+            if trial < 12:
+                vals = [rng.choice(internal) * Rinv % p for _ in range(4)]
+            else:
+                vals = [rng.randrange(p) for _ in range(4)]
+            a, b = (vals[0], vals[1]), (vals[2], vals[3])
+            for hi in (0, 1):
+                if hi:
+                    t = f2mul(a, b)
+                    want = (2 * t[0] % p, 2 * t[1] % p)
+                else:
+                    bb = f2mul(b, b)
+                    xb = ((xi0 * bb[0] - bb[1]) % p, (bb[0] + xi0 * bb[1]) % p)
+                    aa = f2mul(a, a)
+                    want = ((aa[0] + xb[0]) % p, (aa[1] + xb[1]) % p)
+                ab = np.frombuffer(a[0].to_bytes(fpb, "little") + a[1].to_bytes(fpb, "little"), dtype=np.uint8).copy()
+                bbuf = np.frombuffer(b[0].to_bytes(fpb, "little") + b[1].to_bytes(fpb, "little"), dtype=np.uint8).copy()
+                out = np.zeros(2 * fpb, dtype=np.uint8)
+                assert lib.bbs_selftest_fp4sqr(cid, hi, _u8(ab), _u8(bbuf), _u8(out)) == 0
+                o = out.tobytes()
+                assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == want, (cid, hi, trial)
