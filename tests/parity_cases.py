@@ -552,6 +552,33 @@ def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2):
     eng.close()
 
 
+def check_mixed_curves_in_flight(lib_path=None, n=1024, per_curve=3, rounds=4):
+    """BASELINE config 5 on one device: BN254 and BLS12-381 proof_verify batches resident and in flight together
+    (every job on its own streams, two contexts), every 16th item corrupted: the statuses of every job are exact."""
+    from bbs_sign_amd import Job
+    jobs = []
+    for curve in ("bls12_381", "bn254"):
+        suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, 32, 8, lib_path)
+        sigs, st = eng.core_sign_batch(msgs)
+        assert (st == 1).all()
+        proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+        assert (st == 1).all()
+        for i in range(0, n, 16):
+            proofs[i].commitments[0] = (proofs[i].commitments[0] + 1) % suite.curve.r
+        dm = [m[:8] for m in msgs]
+        jobs.append([eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(per_curve)])
+    order = [j for pair in zip(*jobs) for j in pair]
+    for _ in range(rounds):
+        for j in order:
+            j.run()
+    for j in order:
+        j.wait()
+    want = [0 if i % 16 == 0 else 1 for i in range(n)]
+    for j in order:
+        assert [int(x) for x in j.status()] == want
+        j.free()
+
+
 def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8):
     """EVERY item of a BASELINE-shaped batch against the plain-C oracle (oracle/c), bit for bit:
     signatures, proofs and proof_verify booleans incl. corrupted items."""

@@ -50,3 +50,7 @@ def test_full_batch_4096(curve):
 
 def test_every_item_against_c_oracle():
     pc.check_batch_vs_c_oracle(None, n=1024)
+
+
+def test_mixed_curves_in_flight():
+    pc.check_mixed_curves_in_flight(None)
