@@ -122,7 +122,7 @@ int bbs_ctx_create(int curve, int device_id, bbs_ctx** out) {
 void bbs_ctx_destroy(bbs_ctx* ctx) { delete ctx; }
 
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
-    if (!ctx || bits < 4 || bits > 16) return BBS_E_ARG;
+    if (!ctx || bits < 4 || bits > 22) return BBS_E_ARG;
     if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->win_bits = bits; else AS_BN(ctx)->win_bits = bits;
     return BBS_OK;
 }

@@ -84,7 +84,7 @@ int bbs_device_count(void);
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);
 void bbs_ctx_destroy(bbs_ctx* ctx);
 
-/* window width (bits) of the fixed-base tables, 4..16; takes effect at the next
+/* window width (bits) of the fixed-base tables, 4..22; takes effect at the next
  * bbs_ctx_set_generators.  Table bytes = (count+1) * ceil(256/w) * (2^w - 1) * 2 * fp_bytes. */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
