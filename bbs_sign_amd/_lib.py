@@ -65,6 +65,7 @@ SIGNATURES = {
     "bbs_selftest_f2dot": (ci, [ci, sz, c_u8p, c_u8p, c_u8p, c_u8p]),
     "bbs_create_generators": (ci, [ci, sz, c_u8p, sz, c_u8p]),
     "bbs_hash_to_g1": (ci, [ci, c_u8p, sz, c_u8p, sz, c_u8p]),
+    "bbs_scalar_from_okm": (ci, [ci, c_u8p, c_u8p]),
     "bbs_key_gen": (ci, [ci, c_u8p, sz, c_u8p, sz, c_u8p, sz, c_u8p]),
     "bbs_signature_to_octets": (ci, [ci, c_u8p, c_u8p]),
     "bbs_signature_from_octets": (ci, [ci, c_u8p, c_u8p]),

@@ -88,6 +88,15 @@ static int selftest_fp4sqr(int hi, const uint8_t* a, const uint8_t* b, uint8_t* 
     return BBS_OK;
 }
 
+// FromOkm (src/utils/utilities_helper.rs:15-40): 48 big-endian bytes -> scalar mod r, canonical LE out
+template <class C>
+static void scalar_from_okm(const uint8_t* okm48, uint8_t* out32) {
+    uint32_t be[12];
+    for (int k = 0; k < 12; k++) be[k] = ((uint32_t)okm48[4 * k] << 24) | ((uint32_t)okm48[4 * k + 1] << 16) | ((uint32_t)okm48[4 * k + 2] << 8) | okm48[4 * k + 3];
+    const Fr<C> r = fe_to_canonical<typename C::FrP>(fr_from_okm<C>(be));
+    for (int k = 0; k < 8; k++) put_le32(out32 + 4 * k, r.v[k]);
+}
+
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -363,6 +372,14 @@ int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t*
     if (curve == BBS_CURVE_BLS12_381) return hash_to_g1_out<BlsCurve>(msg, msg_len, dst, dst_len, out_affine);
     if (curve == BBS_CURVE_BN254) return hash_to_g1_out<BnCurve>(msg, msg_len, dst, dst_len, out_affine);
     return BBS_E_ARG;
+}
+
+int bbs_scalar_from_okm(int curve, const uint8_t* okm48, uint8_t* scalar_out) {
+    if (!okm48 || !scalar_out) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) scalar_from_okm<BlsCurve>(okm48, scalar_out);
+    else if (curve == BBS_CURVE_BN254) scalar_from_okm<BnCurve>(okm48, scalar_out);
+    else return BBS_E_ARG;
+    return BBS_OK;
 }
 
 // SecretKey::key_gen (src/key_gen.rs:46-81)

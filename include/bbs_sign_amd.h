@@ -228,6 +228,9 @@ int bbs_create_generators(int curve, size_t count, const uint8_t* api_id, size_t
 /* HashToG1::hash_to_g1 (interface_utilities.rs:17-44), BLS12-381. */
 int bbs_hash_to_g1(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len,
                    uint8_t* out_affine);
+/* FromOkm (src/utils/utilities_helper.rs:15-40): 48 big-endian bytes reduced mod r, 32 B LE out -- what
+ * calculate_random_scalars (src/utils/core_utilities.rs:70-81) applies to 48 random bytes. */
+int bbs_scalar_from_okm(int curve, const uint8_t* okm48, uint8_t* scalar_out);
 /* SecretKey::key_gen (src/key_gen.rs:46-81): returns 0 or the KeyGenError code. */
 int bbs_key_gen(int curve, const uint8_t* key_material, size_t key_material_len, const uint8_t* key_info,
                 size_t key_info_len, const uint8_t* key_dst, size_t key_dst_len, uint8_t* sk32_out);
