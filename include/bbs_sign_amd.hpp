@@ -232,4 +232,43 @@ inline Result<bool> proof_verify(const PublicKey& pk, const Proof& proof, const 
     return st >= 0 ? Result<bool>::ok(st == 1) : Result<bool>::err(st);
 }
 
+// proof_verify for n proofs of one issuer and one message count at once (what a verifier service calls: one engine
+// batch instead of n calls); element i of the result is what proof_verify(...) returns for proof i
+inline std::vector<Result<bool>> proof_verify_batch(const PublicKey& pk, const std::vector<Proof>& proofs,
+                                                    const std::vector<Bytes>& headers, const std::vector<Bytes>& phs,
+                                                    const std::vector<std::vector<Bytes>>& disclosed_msgs,
+                                                    const std::vector<std::vector<size_t>>& disclosed_indexes, size_t message_count) {
+    const Curve c = pk.curve;
+    const size_t n = proofs.size();
+    auto ctx = detail::context(c, message_count, false, pk.pk, pk.identity);
+    std::vector<Bytes> all_msgs;
+    for (const auto& item : disclosed_msgs) all_msgs.insert(all_msgs.end(), item.begin(), item.end());
+    const Bytes dm = detail::msg_to_scalars(ctx.get(), c, all_msgs);
+    Bytes fixed, cm, hb, pb;
+    std::vector<uint64_t> coff{0}, moff{0}, idx, ioff{0}, hoff{0}, poff{0};
+    for (size_t i = 0; i < n; i++) {
+        fixed.insert(fixed.end(), proofs[i].fixed.begin(), proofs[i].fixed.end());
+        cm.insert(cm.end(), proofs[i].commitments.begin(), proofs[i].commitments.end());
+        coff.push_back(cm.size() / 32);
+        moff.push_back(moff.back() + disclosed_msgs[i].size());
+        idx.insert(idx.end(), disclosed_indexes[i].begin(), disclosed_indexes[i].end());
+        ioff.push_back(idx.size());
+        hb.insert(hb.end(), headers[i].begin(), headers[i].end());
+        hoff.push_back(hb.size());
+        pb.insert(pb.end(), phs[i].begin(), phs[i].end());
+        poff.push_back(pb.size());
+    }
+    idx.push_back(0);
+    std::vector<int8_t> st(n ? n : 1, 0);
+    detail::check(bbs_core_proof_verify_batch(ctx.get(), n, detail::ptr(fixed), detail::ptr(cm), coff.data(), detail::ptr(dm), moff.data(),
+                                              idx.data(), ioff.data(), detail::ptr(hb), hoff.data(), detail::ptr(pb), poff.data(), st.data()),
+                  "bbs_core_proof_verify_batch");
+    std::vector<Result<bool>> out;
+    for (size_t i = 0; i < n; i++) {
+        detail::raise_if_not_variant(st[i]);
+        out.push_back(st[i] >= 0 ? Result<bool>::ok(st[i] == 1) : Result<bool>::err(st[i]));
+    }
+    return out;
+}
+
 }  // namespace bbs_plus

@@ -117,6 +117,12 @@ static void round_trips_and_invalid_proofs() {          // bbs_over_bls_tests.rs
     CHECK(!proof_verify(pk, zeros, {}, {}, dm, d).unwrap());
     // proof_gen errors (proof_gen.rs:135-143): disclosed index out of range, more indexes than messages
     CHECK(proof_gen(pk, sig, {}, {}, msgs, {0, 10}).is_err());
+    // the same checks through one engine batch: valid, forged a_bar, Err (index out of range), wrong message
+    std::vector<Proof> ps = {proof, forged, proof, proof};
+    std::vector<std::vector<Bytes>> dms = {dm, dm, dm, {msgs[0], msgs[2], msgs[5]}};
+    std::vector<std::vector<size_t>> ds = {d, d, {0, 1, 10}, d};
+    auto rs = proof_verify_batch(pk, ps, std::vector<Bytes>(4), std::vector<Bytes>(4), dms, ds, 10);
+    CHECK(rs.size() == 4 && rs[0].unwrap() && !rs[1].unwrap() && rs[2].is_err() && !rs[3].unwrap());
 }
 
 int main() {
