@@ -312,6 +312,30 @@ def check_error_semantics(curve, lib_path=None):
     eng2.close()
 
 
+def check_empty_batches(curve, lib_path=None):
+    """n = 0 through every batched entry point (the reference's functions are per item; an empty batch is the
+    degenerate case of the batch boundary), in the per-item and the batch-verification mode."""
+    suite = bbs.SUITES[curve]
+    eng = make_engine(curve, gens_for(suite, 4), suite.api_id, lib_path, sk=12345)
+    for mode in (False, True):
+        eng.set_batch_verification(mode)
+        sigs, st = eng.core_sign_batch([])
+        assert sigs == [] and len(st) == 0
+        assert len(eng.core_verify_batch([], [])) == 0
+        proofs, st = eng.core_proof_gen_batch([], [], [], [])
+        assert proofs == [] and len(st) == 0
+        assert len(eng.core_proof_verify_batch([], [], [])) == 0
+        job = eng.core_proof_verify_upload([], [], [])
+        job.run(); job.wait()
+        assert len(job.status()) == 0
+        job.free()
+    assert eng.hash_to_scalar_batch([], b"dst") == []
+    out, st = eng.g1_msm_batch([], [], [])
+    assert out == [] and len(st) == 0
+    assert len(eng.pairing_product2_is_one_batch([], [])) == 0
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------
 def check_primitives(curve, lib_path=None):
     rng = random.Random(11)

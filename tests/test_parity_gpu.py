@@ -54,3 +54,8 @@ def test_every_item_against_c_oracle():
 
 def test_mixed_curves_in_flight():
     pc.check_mixed_curves_in_flight(None)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_empty_batches(curve):
+    pc.check_empty_batches(curve, None)

@@ -51,3 +51,8 @@ def test_pippenger(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_batch_verification(twin, curve):
     pc.check_batch_verification(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_empty_batches(twin, curve):
+    pc.check_empty_batches(curve, twin)
