@@ -101,8 +101,8 @@ def cpu_baseline(items_per_core=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--inflight", type=int, default=8, help="device-resident batches in flight per GPU")
