@@ -62,7 +62,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(items_per_core=24):
+def cpu_baseline(items_per_core=48):
     """The oracle's plain-C restatement (oracle/c/bbs_oracle.c: reference operation order, per-call
     domain, 38 independent double-and-add scalar multiplications, two full pairings) timed on the host
     cores on a bounded sample of the same workload (items 0.. of the bench batch)."""
