@@ -34,6 +34,7 @@ def build(twin=False, force=False, jobs=None, verbose=True):
         return out
     objdir = os.path.join(HERE, "build", "twin" if twin else "gfx950")
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     tus = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     if twin:
         flags = ["-O2", "--offload-host-only", "-x", "hip", "-DBBS_HOST_TWIN", "-DBBS_CHECK_BOUNDS", "-fPIC"]
