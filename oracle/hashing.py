@@ -279,7 +279,9 @@ def hash_to_g1_bls(msg: bytes, dst: bytes, scale_index=None):
 # straight-line version) with Z = 1 on y^2 = x^3 + 3 and cofactor 1.  PINNED by the reference's one BN254
 # known answer: P1 of constants.rs:39-51 is, per test_vector.rs:21-25, the first generator under the seed
 # "...BP_MESSAGE_GENERATOR_SEED" -- reproduced exactly (tests/test_oracle_kat.py).  That vector does not exercise
-# the sign of the constant c3 (both candidate x are never squares at once in it); the RFC's sgn0(c3) = 0 is used.
+# the sign of the constant c3 (both candidate x are never squares at once in it); the RFC's sgn0(c3) = 0 is used,
+# which gives c3 = 8815841940592487685674414971303048083897117035520822607866, the constant of gnark-crypto's BN254
+# hash-to-curve (c2 and c4 coincide with it as well).
 from .curves import BN254  # noqa: E402
 
 _BN_P = BN254.p
