@@ -329,6 +329,11 @@ def main():
                            "valu_wave_insts_per_step": valu_total,
                            "source": "SQ_INSTS_VALU of pairing_6lane + pv_msm_parts + pv_challenge (profiles/r01_h_pmc.csv); peak = 1024 "
                                      "SIMDs x 2.4 GHz / 4 cycles per wave-instruction"},
+            # per kernel: launch duration (HIP events, this run), VALU wave-instructions and HBM bytes per launch (PMC)
+            "kernels": [{"kernel": k, "ms_per_launch": stage_ms[k] / args.steps,
+                         "valu_wave_insts": PMC[k]["valu_insts"] * (n / 4096.0),
+                         "hbm_bytes": (PMC[k]["fetch_bytes"] + PMC[k]["write_bytes"]) * (n / 4096.0)}
+                        for k in PMC if k in stage_ms],
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "gpu_ms_per_step_events": total_ms / args.steps,
             "batches_in_flight": len(jobs),
