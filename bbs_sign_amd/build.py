@@ -40,6 +40,8 @@ def build(twin=False, force=False, jobs=None, verbose=True):
         flags = ["-O2", "--offload-host-only", "-x", "hip", "-DBBS_HOST_TWIN", "-DBBS_CHECK_BOUNDS", "-fPIC"]
     else:
         flags = ["-O3", "--offload-arch=gfx950", "-fPIC"]
+    # only the C ABI of include/bbs_sign_amd.h is exported (capi.hip raises the visibility of its extern "C" blocks)
+    flags += ["-fvisibility=hidden", "-fvisibility-inlines-hidden"]
     jobs = jobs or min(8, os.cpu_count() or 1)
 
     def one(tu):

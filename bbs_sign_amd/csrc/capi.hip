@@ -97,6 +97,7 @@ static void scalar_from_okm(const uint8_t* okm48, uint8_t* out32) {
     for (int k = 0; k < 8; k++) put_le32(out32 + 4 * k, r.v[k]);
 }
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 size_t bbs_fp_bytes(int curve) { return curve == BBS_CURVE_BLS12_381 ? 48 : 32; }
@@ -406,6 +407,7 @@ int bbs_key_gen(int curve, const uint8_t* key_material, size_t km_len, const uin
 
 // ---- wire codec (host) ---------------------------------------------------------------------------
 }  // extern "C"
+#pragma GCC visibility pop
 template <class C>
 static int sig_to_octets(const uint8_t* rec, uint8_t* out) {
     constexpr int NB = 4 * C::FpP::NC;
@@ -493,6 +495,7 @@ static int pk_to_octets(const uint8_t* rec, int is_identity, uint8_t* out) {
     g2_compress<C>(q, out);
     return BBS_OK;
 }
+#pragma GCC visibility push(default)
 extern "C" {
 #define CURVE_OK(c) ((c) == BBS_CURVE_BLS12_381 || (c) == BBS_CURVE_BN254)
 int bbs_signature_to_octets(int curve, const uint8_t* sig_record, uint8_t* out) {
@@ -553,3 +556,4 @@ int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa,
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

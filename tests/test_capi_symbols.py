@@ -37,3 +37,17 @@ def test_missing_library_raises():
     from bbs_sign_amd import _lib
     with pytest.raises(_lib.LibraryMissing):
         _lib.load_library("/nonexistent/libbbs_sign_amd.so")
+
+
+def test_only_the_c_abi_is_exported():
+    """Everything the library exports is either a function of the header or a kernel launch stub (which the HIP
+    runtime needs by name): the C++ internals (templates of runtime.hpp, op_*.hpp) stay hidden."""
+    import subprocess
+    from bbs_sign_amd import _lib, build
+    path = build.build(twin=False, verbose=False)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    api = [n for n in names if n.startswith("bbs_")]
+    assert set(api) == set(_lib.SIGNATURES), set(api) ^ set(_lib.SIGNATURES)
+    other = [n for n in names if not n.startswith("bbs_") and "k_stage" not in n]
+    assert not other, other[:10]
