@@ -353,7 +353,11 @@ struct Ctx : bbs_ctx {
         if (d_consts.alloc(sizeof(CtxConsts<C>))) return BBS_E_NOMEM;
         return BBS_OK;
     }
-    ~Ctx() override { (void)rt::set_device(device); (void)rt::sync(stream); rt::stream_destroy(stream); }
+    ~Ctx() override {
+        (void)rt::set_device(device); (void)rt::sync(stream); rt::stream_destroy(stream);
+        volatile uint32_t* s = sk;                       // do not leave the secret key in freed host memory
+        for (int k = 0; k < 8; k++) s[k] = 0;
+    }
 
     int use() { return rt::set_device(device) ? BBS_E_HIP : BBS_OK; }
 
