@@ -515,6 +515,12 @@ int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t*
     return curve == BBS_CURVE_BLS12_381 ? proof_from_octets<BlsCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out)
                                         : proof_from_octets<BnCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out);
 }
+int bbs_proofs_from_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* octets, const uint64_t* oct_off, uint8_t* pf_out, uint8_t* cm_out,
+                                 uint64_t* cm_off_out, int8_t* status) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, proofs_from_octets_batch<BlsCurve>(AS_BLS(ctx), n, octets, oct_off, pf_out, cm_out, cm_off_out, status),
+                    proofs_from_octets_batch<BnCurve>(AS_BN(ctx), n, octets, oct_off, pf_out, cm_out, cm_off_out, status));
+}
 int bbs_public_key_to_octets(int curve, const uint8_t* pk_affine, int is_identity, uint8_t* out) {
     if (!CURVE_OK(curve) || !out || (!is_identity && !pk_affine)) return BBS_E_ARG;
     return curve == BBS_CURVE_BLS12_381 ? pk_to_octets<BlsCurve>(pk_affine, is_identity, out) : pk_to_octets<BnCurve>(pk_affine, is_identity, out);

@@ -152,6 +152,69 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
     return BBS_OK;
 }
 
+// n proofs as octet strings -> the records of bbs_core_proof_verify_*: lengths and scalars on the host, the 3 n
+// compressed points on the device (codec_dev.hpp).  status[i] = 1 or the code bbs_proof_from_octets gives for item i
+// (same order of checks).  commit_off_out: n + 1 entries; commitments_out holds sum_i U_i scalars.
+template <class C>
+int proofs_from_octets_batch(Ctx<C>* ctx, size_t n, const uint8_t* oct, const uint64_t* off, uint8_t* pf_out, uint8_t* cm_out,
+                             uint64_t* cm_off_out, int8_t* status) {
+    constexpr int NC = C::FpP::NC;
+    constexpr size_t NB = 4 * NC;
+    using R = typename C::FrP;
+    if (!status || !cm_off_out || (n && (!oct || !off || !pf_out))) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    const size_t fixed = 3 * NB + 4 * 32, rec = 6 * NB + 128;
+    std::vector<uint8_t> cpts(std::max<size_t>(3 * n, 1) * NB, 0);
+    cm_off_out[0] = 0;
+    auto be_to_le = [](const uint8_t* be, uint8_t* le) {
+        uint32_t w[8];
+        for (int i = 0; i < 32; i++) le[i] = be[31 - i];
+        for (int i = 0; i < 8; i++) w[i] = le32(le + 4 * i);
+        return limbs_lt_mod<R>(w);
+    };
+    for (size_t i = 0; i < n; i++) {
+        const size_t len = (size_t)(off[i + 1] - off[i]);
+        const uint8_t* o = oct + off[i];
+        status[i] = 1;
+        cm_off_out[i + 1] = cm_off_out[i];
+        std::memset(pf_out + i * rec, 0, rec);
+        if (off[i + 1] < off[i] || len < fixed || (len - fixed) % 32) { status[i] = BBS_ST_INVALID_ENCODING; continue; }
+        const size_t u = (len - fixed) / 32;
+        for (int p = 0; p < 3; p++) std::memcpy(cpts.data() + (i * 3 + p) * NB, o + (size_t)p * NB, NB);
+        // scalars (their verdict is applied after the points', as in bbs_proof_from_octets)
+        const uint8_t* s = o + 3 * NB;
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok &= be_to_le(s + 32 * k, pf_out + i * rec + 6 * NB + 32 * k);
+        if (cm_out) for (size_t k = 0; k < u; k++) ok &= be_to_le(s + 96 + 32 * k, cm_out + (cm_off_out[i] + k) * 32);
+        ok &= be_to_le(s + 96 + 32 * u, pf_out + i * rec + 6 * NB + 96);
+        cm_off_out[i + 1] = cm_off_out[i] + u;
+        if (!ok) status[i] = BBS_ST_NONCANONICAL;       // provisional: a point failure reported first
+    }
+    const size_t np = 3 * n;
+    DevBuf dIn, dOut, dCode;
+    if (dIn.alloc(cpts.size()) || dOut.alloc((size_t)2 * NC * std::max<size_t>(np, 1) * 4) || dCode.alloc(np + 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dIn.p, cpts.data(), cpts.size(), ctx->stream)) return BBS_E_HIP;
+    G1DecodeArgs<C> a{np, dIn.as<uint8_t>(), dOut.as<uint32_t>(), dCode.as<int8_t>()};
+    if (rt::launch<G1Decode<C>>(ctx->stream, a, np) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> w((size_t)2 * NC * std::max<size_t>(np, 1));
+    std::vector<int8_t> code(np + 4);
+    if (np && (rt::d2h(w.data(), dOut.p, (size_t)2 * NC * np * 4, ctx->stream) || rt::d2h(code.data(), dCode.p, np, ctx->stream))) return BBS_E_HIP;
+    for (size_t i = 0; i < n; i++) {
+        if (status[i] == BBS_ST_INVALID_ENCODING) continue;
+        int8_t verdict = status[i];
+        for (int p = 2; p >= 0; p--) {                   // the first failing point (lowest p) decides
+            const int8_t c = code[i * 3 + p];
+            if (c == 1) verdict = BBS_ST_INVALID_ENCODING;              // identity points are rejected
+            else if (c < 0) verdict = c;
+        }
+        status[i] = verdict;
+        if (verdict == 1)
+            for (int p = 0; p < 3; p++) unpack_words_le(w, np, 0, i * 3 + p, 2 * NC, pf_out + i * rec + (size_t)p * 2 * NB);
+        else std::memset(pf_out + i * rec, 0, rec);
+    }
+    return BBS_OK;
+}
+
 template <class C>
 int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {
     constexpr int N = C::FpP::N;

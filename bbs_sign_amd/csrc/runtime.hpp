@@ -22,7 +22,7 @@
 
 #include "../../include/bbs_sign_amd.h"
 #include "host_g2.hpp"
-#include "pippenger.hpp"
+#include "codec_dev.hpp"
 
 using namespace bbs;
 

@@ -414,6 +414,22 @@ class Engine:
                                                 st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_pippenger")
         return (None if inf.value else self._g1_dec(out.tobytes())), st[:n]
 
+    def proofs_from_octets_batch(self, octets: Sequence[bytes]):
+        """bbs_proofs_from_octets_batch: n proof octet strings -> (list of Proof or None, int8 statuses); the point
+        decompression and subgroup checks run on the device."""
+        n = len(octets)
+        flat, off = _ragged_bytes(octets)
+        rec = 6 * self.fpb + 128
+        pf = np.zeros(max(n, 1) * rec, dtype=np.uint8)
+        cap = max(sum(len(o) for o in octets) // 32, 1)
+        cm = np.zeros(cap * 32, dtype=np.uint8)
+        cmo = np.zeros(n + 1, dtype=np.uint64)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_proofs_from_octets_batch(self.h, n, _u8(flat), _u64(off), _u8(pf), _u8(cm), _u64(cmo),
+                                                        st.ctypes.data_as(_lib.c_i8p)), "bbs_proofs_from_octets_batch")
+        proofs = self._dec_proofs(pf, cm, cmo, st, n)
+        return proofs, st[:n]
+
     def pairing_product2_is_one_batch(self, pa, pb) -> np.ndarray:
         n = len(pa)
         a = _bytes_arr(b"".join(self._g1(p) for p in pa))

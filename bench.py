@@ -277,6 +277,26 @@ def main():
             "one_call_ms": one_ms, "one_call_per_s": n / (one_ms * 1e-3), "threads": nthreads, "threaded_per_s": piped,
             "note": "one-shot bbs_core_proof_verify_batch from host buffers (1.36 KB/proof over PCIe + host-side validation "
                     "and SoA packing on one core per call); sequential calls, then 8 host threads each issuing calls"}
+        # ingest: n proofs as octet strings -> records (3 n point decompressions + subgroup checks on the device)
+        from bbs_sign_amd import api as _api
+        octs = [_api.proof_to_octets("bls12_381", p_) for p_ in proofs[:n]]
+        eng.proofs_from_octets_batch(octs[:64])
+        flat_o, off_o = (__import__("bbs_sign_amd.engine", fromlist=["x"])._ragged_bytes(octs))
+        rec_o = 6 * eng.fpb + 128
+        pf_o = np.zeros(n * rec_o, dtype=np.uint8); cm_o = np.zeros(n * 32 * 32, dtype=np.uint8)
+        cmo_o = np.zeros(n + 1, dtype=np.uint64); st_o = np.zeros(n, dtype=np.int8)
+        def decode_call():
+            rc = eng.lib.bbs_proofs_from_octets_batch(eng.h, n, flat_o.ctypes.data_as(_l.c_u8p), off_o.ctypes.data_as(_l.c_u64p),
+                                                      pf_o.ctypes.data_as(_l.c_u8p), cm_o.ctypes.data_as(_l.c_u8p),
+                                                      cmo_o.ctypes.data_as(_l.c_u64p), st_o.ctypes.data_as(_l.c_i8p))
+            assert rc == 0 and (st_o == 1).all()
+        decode_call()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            decode_call()
+        extras["bls12_381"]["proofs_from_octets"] = {"proofs_per_s": 4 * n / (time.perf_counter() - t1),
+            "note": "bbs_proofs_from_octets_batch: 1040-byte proof octets -> records, 3 x 4096 G1 decompressions and "
+                    "subgroup checks on the device, scalars on the host, one call at a time"}
         _, eb, _, _, mb, db, rb = pc.bench_workload("bn254", n, L, R, None, 8, device=local_rank)
         sb, st = eb.core_sign_batch(mb)
         assert (st == 1).all()

@@ -250,6 +250,13 @@ int bbs_proof_to_octets(int curve, const uint8_t* proof_fixed, const uint8_t* co
                         uint8_t* out /* 3 * fp_bytes + 32 * (4 + n_commitments) */);
 int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t* proof_fixed_out,
                           uint8_t* commitments_out, size_t commitments_cap, size_t* n_commitments_out);
+/* bbs_proof_from_octets for n proofs at once: octets ragged (oct_off: n + 1 byte offsets); the 3 n points are
+ * decompressed and checked (on curve, prime-order subgroup) on the device, scalars on the host.  status[i] = 1 or the
+ * code bbs_proof_from_octets returns for item i; proofs_fixed_out: n records (zeros where status != 1);
+ * commitments_out / commit_off_out (n + 1 entries): the commitments of every well-formed item, packed. */
+int bbs_proofs_from_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* octets, const uint64_t* oct_off,
+                                 uint8_t* proofs_fixed_out, uint8_t* commitments_out, uint64_t* commit_off_out,
+                                 int8_t* status);
 int bbs_public_key_to_octets(int curve, const uint8_t* pk_affine, int is_identity, uint8_t* out /* 2 * fp_bytes */);
 int bbs_public_key_from_octets(int curve, const uint8_t* octets, uint8_t* pk_affine_out, int* is_identity_out);
 

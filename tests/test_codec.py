@@ -83,3 +83,98 @@ def test_malformed_octets_are_rejected(lib):
     o = bytes(bbs.g1_compress(C, (x, y))) + bytes(good[48:])
     with pytest.raises(BbsError):
         api.octets_to_signature("bls12_381", o, lib)
+
+
+# ---- batch decode (points decompressed and checked on the device) ------------------------------------------------
+def _proof_octets(suite, pts, sc, cms):
+    c = suite.curve
+    return b"".join(bbs.g1_compress(c, q) for q in pts) + b"".join(bbs.scalar_be(c, x) for x in sc[:3] + cms + sc[3:])
+
+
+def check_batch_decode(lib_path, curve_name):
+    """bbs_proofs_from_octets_batch against bbs_proof_from_octets item by item: records, commitments and status codes,
+    on valid proofs and on every kind of malformed one (bad flag, x >= p, not on the curve, on the curve but outside
+    the prime-order subgroup incl. order 3, identity points, scalars >= r, bad lengths)."""
+    import random
+    from bbs_sign_amd import Engine
+    suite = bbs.SUITES[curve_name]
+    c = suite.curve
+    rng = random.Random(17)
+    fpb = c.fp_bytes
+    items = []
+    for k in range(10):
+        pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in range(3)]
+        sc = [rng.randrange(c.r) for _ in range(4)]
+        cms = [rng.randrange(c.r) for _ in range(k % 4)]
+        items.append(bytearray(_proof_octets(suite, pts, sc, cms)))
+    bad = []
+    b = bytearray(items[0]); b[fpb - 1 if curve_name == "bn254" else 0] ^= 0x20 if curve_name == "bls12_381" else 0x80; bad.append(b)  # other root: still valid
+    if curve_name == "bls12_381":
+        b = bytearray(items[1]); b[0] &= 0x7F; bad.append(b)                                   # not the compressed form
+        b = bytearray(items[2]); b[fpb:2 * fpb] = bytes([0x9F]) + bytes([0xFF] * (fpb - 1)); bad.append(b)   # x >= p
+        b = bytearray(items[3]); b[2 * fpb:3 * fpb] = bytes([0xC0]) + bytes(fpb - 1); bad.append(b)          # identity D
+        b = bytearray(items[3]); b[0:fpb] = bytes([0xE0]) + bytes(fpb - 1); bad.append(b)                    # identity with sign bit
+        b = bytearray(items[4]); b[0:fpb] = bbs.g1_compress(c, (0, 2)); bad.append(b)                         # order 3
+        x = 7
+        while True:
+            y2 = (x ** 3 + 4) % c.p
+            y = pow(y2, (c.p + 1) // 4, c.p)
+            if y * y % c.p == y2 and c.g1_mul((x, y), c.r) is not None:
+                break
+            x += 1
+        b = bytearray(items[5]); b[fpb:2 * fpb] = bbs.g1_compress(c, (x, y)); bad.append(b)                   # large order, not in G1
+    else:
+        b = bytearray(items[2]); b[fpb:2 * fpb] = bytes([0xFF] * (fpb - 1)) + bytes([0x3F]); bad.append(b)   # x >= p
+        b = bytearray(items[3]); b[2 * fpb:3 * fpb] = bytes(fpb - 1) + bytes([0x40]); bad.append(b)          # identity D
+    xx = 3
+    while pow((xx ** 3 + (4 if curve_name == "bls12_381" else 3)) % c.p, (c.p - 1) // 2, c.p) == 1:
+        xx += 1                                                                                 # x with no point on the curve
+    enc = bytearray(bbs.g1_compress(c, c.g1))
+    if curve_name == "bls12_381":
+        enc = bytearray((xx).to_bytes(fpb, "big")); enc[0] |= 0x80
+    else:
+        enc = bytearray((xx).to_bytes(fpb, "little"))
+    b = bytearray(items[6]); b[0:fpb] = enc; bad.append(b)                                                    # not on the curve
+    b = bytearray(items[7]); b[3 * fpb:3 * fpb + 32] = c.r.to_bytes(32, "big"); bad.append(b)                # e^ = r
+    b = bytearray(items[8]); b[-32:] = bytes([0xFF] * 32); bad.append(b)                                      # challenge >= r
+    bad.append(items[9][:-1]); bad.append(items[9][:3 * fpb + 100]); bad.append(bytearray())                  # bad lengths
+    allo = [bytes(x) for x in items + bad]
+    eng = Engine(curve_name, lib_path=lib_path, window_bits=4)
+    proofs, st = eng.proofs_from_octets_batch(allo)
+    n_ok = 0
+    for i, o in enumerate(allo):
+        try:
+            want = api.octets_to_proof(curve_name, o, lib_path)
+            code = 1
+        except BbsError as e:
+            want, code = None, e.status
+        assert int(st[i]) == code, (curve_name, i, int(st[i]), code)
+        if want is not None:
+            got = proofs[i]
+            assert (got.a_bar, got.b_bar, got.d, got.e_cap, got.r1_cap, got.r3_cap, got.commitments, got.challenge) == \
+                   (want.a_bar, want.b_bar, want.d, want.e_cap, want.r1_cap, want.r3_cap, want.commitments, want.challenge), i
+            n_ok += 1
+        else:
+            assert proofs[i] is None
+    assert n_ok >= 11
+    ps, st = eng.proofs_from_octets_batch([])
+    assert ps == [] and len(st) == 0
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def twin():
+    sys.path.insert(0, ROOT)
+    from bbs_sign_amd import build as b
+    return b.build(twin=True, verbose=False)
+
+
+@pytest.mark.parametrize("curve_name", ["bls12_381", "bn254"])
+def test_batch_decode_twin(twin, curve_name):
+    check_batch_decode(twin, curve_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bls12_381", "bn254"])
+def test_batch_decode_gpu(curve_name):
+    check_batch_decode(None, curve_name)

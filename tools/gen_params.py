@@ -202,6 +202,13 @@ def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_d
     s += "    static constexpr uint64_t X_ABS = 0x%016xull;\n" % xabs
     s += "    static constexpr uint32_t XI_C0 = %d;   // xi = XI_C0 + u\n" % xi[0]
     s += arr("B_M", m(b), n)
+    # cube root of unity beta with (beta x, y) = [-x^2] (x, y) on the prime-order subgroup (BLS12: the
+    # endomorphism subgroup test phi(P) == -[x^2] P; validated numerically against [r] P below); unused for cofactor 1
+    g_ = 2
+    while pow(g_, (p - 1) // 3, p) == 1:
+        g_ += 1
+    beta = pow(g_, (p - 1) // 3, p)
+    s += arr("BETA_M", m(beta), n)
     s += arr("B3_M", m(3 * b), n)
     s += arr("G1X_M", m(g1[0]), n) + arr("G1Y_M", m(g1[1]), n)
     s += arr("P1X_M", m(p1[0]), n) + arr("P1Y_M", m(p1[1]), n)
