@@ -97,6 +97,50 @@ static void scalar_from_okm(const uint8_t* okm48, uint8_t* out32) {
     for (int k = 0; k < 8; k++) put_le32(out32 + 4 * k, r.v[k]);
 }
 
+// compress a G1 record (x || y, canonical LE; zeros = identity) without any field arithmetic: the flag needs only
+// the comparison y > (p - 1) / 2 on the canonical words.  false: a coordinate is not canonical.
+template <class C>
+static bool g1_record_compress(const uint8_t* rec, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr int NC = P::NC, NB = 4 * NC;
+    uint32_t xw[NC], yw[NC], any = 0;
+    for (int k = 0; k < NC; k++) { xw[k] = le32(rec + 4 * k); yw[k] = le32(rec + NB + 4 * k); any |= xw[k] | yw[k]; }
+    if (!limbs_lt_mod<P>(xw) || !limbs_lt_mod<P>(yw)) return false;
+    if (C::ID == 0) {
+        if (!any) { std::memset(out, 0, NB); out[0] = 0xC0; return true; }
+        for (int i = 0; i < NB; i++) out[i] = rec[NB - 1 - i];
+        out[0] |= 0x80;
+        if (words_gt_half<P>(yw)) out[0] |= 0x20;
+    } else {
+        if (!any) { std::memset(out, 0, NB); out[NB - 1] = 0x40; return true; }
+        std::memcpy(out, rec, NB);
+        if (words_gt_half<P>(yw)) out[NB - 1] |= 0x80;
+    }
+    return true;
+}
+// n proofs -> octets (same bytes as proof_to_octets per item); status[i] = 1 or BBS_ST_NONCANONICAL
+template <class C>
+static int proofs_to_octets_batch(size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cm_off, uint8_t* out, uint64_t* out_off,
+                                  int8_t* status) {
+    constexpr size_t NB = 4 * C::FpP::NC, rec = 6 * NB + 128;
+    out_off[0] = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t u = (size_t)(cm_off[i + 1] - cm_off[i]);
+        uint8_t* o = out + out_off[i];
+        const uint8_t* r = pf + i * rec;
+        out_off[i + 1] = out_off[i] + 3 * NB + 32 * (4 + u);
+        bool ok = true;
+        for (int p = 0; p < 3; p++) ok &= g1_record_compress<C>(r + (size_t)p * 2 * NB, o + (size_t)p * NB);
+        o += 3 * NB;
+        for (int k = 0; k < 3; k++) codec::scalar_le_to_be(r + 6 * NB + 32 * k, o + 32 * k);
+        for (size_t k = 0; k < u; k++) codec::scalar_le_to_be(cm + (cm_off[i] + k) * 32, o + 96 + 32 * k);
+        codec::scalar_le_to_be(r + 6 * NB + 96, o + 96 + 32 * u);
+        status[i] = ok ? 1 : BBS_ST_NONCANONICAL;
+        if (!ok) std::memset(out + out_off[i], 0, (size_t)(out_off[i + 1] - out_off[i]));
+    }
+    return BBS_OK;
+}
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -514,6 +558,12 @@ int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t*
     if (!CURVE_OK(curve) || !octets || !pf_out || (cm_cap && !cm_out)) return BBS_E_ARG;
     return curve == BBS_CURVE_BLS12_381 ? proof_from_octets<BlsCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out)
                                         : proof_from_octets<BnCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out);
+}
+int bbs_proofs_to_octets_batch(int curve, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cm_off, uint8_t* out, uint64_t* out_off,
+                               int8_t* status) {
+    if (!CURVE_OK(curve) || !cm_off || !out_off || !status || (n && (!pf || !out))) return BBS_E_ARG;
+    return curve == BBS_CURVE_BLS12_381 ? proofs_to_octets_batch<BlsCurve>(n, pf, cm, cm_off, out, out_off, status)
+                                        : proofs_to_octets_batch<BnCurve>(n, pf, cm, cm_off, out, out_off, status);
 }
 int bbs_proofs_from_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* octets, const uint64_t* oct_off, uint8_t* pf_out, uint8_t* cm_out,
                                  uint64_t* cm_off_out, int8_t* status) {

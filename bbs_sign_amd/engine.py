@@ -414,6 +414,22 @@ class Engine:
                                                 st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_pippenger")
         return (None if inf.value else self._g1_dec(out.tobytes())), st[:n]
 
+    def proofs_to_octets_batch(self, proofs: Sequence[Proof]) -> List[bytes]:
+        """bbs_proofs_to_octets_batch: the octet strings of n proofs (host, one call)."""
+        n = len(proofs)
+        rec = b"".join(self._g1(p.a_bar) + self._g1(p.b_bar) + self._g1(p.d) + self._fr(p.e_cap) + self._fr(p.r1_cap)
+                       + self._fr(p.r3_cap) + self._fr(p.challenge) for p in proofs)
+        pf = _bytes_arr(rec)
+        cm, cmo = self._scalars([p.commitments for p in proofs])
+        total = sum(3 * self.fpb + 32 * (4 + len(p.commitments)) for p in proofs)
+        out = np.zeros(max(total, 1), dtype=np.uint8)
+        oo = np.zeros(n + 1, dtype=np.uint64)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_proofs_to_octets_batch(self.curve, n, _u8(pf), _u8(cm), _u64(cmo), _u8(out),
+                                                      _u64(oo), st.ctypes.data_as(_lib.c_i8p)), "bbs_proofs_to_octets_batch")
+        b = out.tobytes()
+        return [b[int(oo[i]):int(oo[i + 1])] if st[i] == 1 else None for i in range(n)]
+
     def proofs_from_octets_batch(self, octets: Sequence[bytes]):
         """bbs_proofs_from_octets_batch: n proof octet strings -> (list of Proof or None, int8 statuses); the point
         decompression and subgroup checks run on the device."""

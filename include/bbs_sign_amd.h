@@ -250,6 +250,10 @@ int bbs_proof_to_octets(int curve, const uint8_t* proof_fixed, const uint8_t* co
                         uint8_t* out /* 3 * fp_bytes + 32 * (4 + n_commitments) */);
 int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t* proof_fixed_out,
                           uint8_t* commitments_out, size_t commitments_cap, size_t* n_commitments_out);
+/* bbs_proof_to_octets for n proofs at once (host; no field arithmetic: byte order and the sign flag only).  out needs
+ * sum_i (3 * fp_bytes + 32 * (4 + U_i)) bytes; out_off: n + 1 byte offsets; status[i] = 1 or BBS_ST_NONCANONICAL. */
+int bbs_proofs_to_octets_batch(int curve, size_t n, const uint8_t* proofs_fixed, const uint8_t* commitments,
+                               const uint64_t* commit_off, uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
 /* bbs_proof_from_octets for n proofs at once: octets ragged (oct_off: n + 1 byte offsets); the 3 n points are
  * decompressed and checked (on curve, prime-order subgroup) on the device, scalars on the host.  status[i] = 1 or the
  * code bbs_proof_from_octets returns for item i; proofs_fixed_out: n records (zeros where status != 1);

@@ -159,6 +159,10 @@ def check_batch_decode(lib_path, curve_name):
     assert n_ok >= 11
     ps, st = eng.proofs_from_octets_batch([])
     assert ps == [] and len(st) == 0
+    # and back: the batch encoder gives the per-item encoder's bytes
+    good = [pr for pr in proofs if pr is not None]
+    assert eng.proofs_to_octets_batch(good) == [api.proof_to_octets(curve_name, pr, lib_path) for pr in good]
+    assert eng.proofs_to_octets_batch([]) == []
     eng.close()
 
 
