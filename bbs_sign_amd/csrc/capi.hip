@@ -559,6 +559,11 @@ int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t*
     return curve == BBS_CURVE_BLS12_381 ? proof_from_octets<BlsCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out)
                                         : proof_from_octets<BnCurve>(octets, len, pf_out, cm_out, cm_cap, n_cm_out);
 }
+int bbs_g1_decompress_batch(bbs_ctx* ctx, size_t n, const uint8_t* compressed, uint8_t* out_affine, int8_t* code) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, g1_decompress_batch<BlsCurve>(AS_BLS(ctx), n, compressed, out_affine, code),
+                    g1_decompress_batch<BnCurve>(AS_BN(ctx), n, compressed, out_affine, code));
+}
 int bbs_proofs_to_octets_batch(int curve, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cm_off, uint8_t* out, uint64_t* out_off,
                                int8_t* status) {
     if (!CURVE_OK(curve) || !cm_off || !out_off || !status || (n && (!pf || !out))) return BBS_E_ARG;

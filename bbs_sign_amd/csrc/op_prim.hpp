@@ -152,6 +152,28 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
     return BBS_OK;
 }
 
+// n compressed G1 points -> affine records (identity = zeros) with the device's decode stage; code[i]: 0 ok,
+// 1 ok and the identity, -40 malformed / non-canonical, -41 not on the curve / not in the prime-order subgroup
+template <class C>
+int g1_decompress_batch(Ctx<C>* ctx, size_t n, const uint8_t* in, uint8_t* out, int8_t* code) {
+    constexpr int NC = C::FpP::NC;
+    constexpr size_t NB = 4 * NC;
+    if (!code || (n && (!in || !out))) return BBS_E_ARG;
+    if (ctx->use()) return BBS_E_HIP;
+    DevBuf dIn, dOut, dCode;
+    if (dIn.alloc(std::max<size_t>(n, 1) * NB) || dOut.alloc((size_t)2 * NC * std::max<size_t>(n, 1) * 4) || dCode.alloc(n + 4)) return BBS_E_NOMEM;
+    if (rt::h2d(dIn.p, in, n * NB, ctx->stream)) return BBS_E_HIP;
+    G1DecodeArgs<C> a{n, dIn.as<uint8_t>(), dOut.as<uint32_t>(), dCode.as<int8_t>()};
+    if (rt::launch<G1Decode<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    std::vector<uint32_t> w((size_t)2 * NC * std::max<size_t>(n, 1));
+    if (n && (rt::d2h(w.data(), dOut.p, (size_t)2 * NC * n * 4, ctx->stream) || rt::d2h(code, dCode.p, n, ctx->stream))) return BBS_E_HIP;
+    for (size_t i = 0; i < n; i++) {
+        if (code[i] == 0) unpack_words_le(w, n, 0, i, 2 * NC, out + i * 2 * NB);
+        else std::memset(out + i * 2 * NB, 0, 2 * NB);
+    }
+    return BBS_OK;
+}
+
 // n proofs as octet strings -> the records of bbs_core_proof_verify_*: lengths and scalars on the host, the 3 n
 // compressed points on the device (codec_dev.hpp).  status[i] = 1 or the code bbs_proof_from_octets gives for item i
 // (same order of checks).  commit_off_out: n + 1 entries; commitments_out holds sum_i U_i scalars.

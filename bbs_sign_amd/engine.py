@@ -414,6 +414,16 @@ class Engine:
                                                 st.ctypes.data_as(_lib.c_i8p)), "bbs_g1_msm_pippenger")
         return (None if inf.value else self._g1_dec(out.tobytes())), st[:n]
 
+    def g1_decompress_batch(self, compressed: Sequence[bytes]):
+        """bbs_g1_decompress_batch -> (list of affine points / None for the identity or a rejected encoding, codes)."""
+        n = len(compressed)
+        buf = _bytes_arr(b"".join(compressed))
+        out = np.zeros(max(n, 1) * 2 * self.fpb, dtype=np.uint8)
+        code = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_g1_decompress_batch(self.h, n, _u8(buf), _u8(out), code.ctypes.data_as(_lib.c_i8p)), "bbs_g1_decompress_batch")
+        b = out.tobytes()
+        return [self._g1_dec(b[i * 2 * self.fpb:(i + 1) * 2 * self.fpb]) if code[i] == 0 else None for i in range(n)], code[:n]
+
     def proofs_to_octets_batch(self, proofs: Sequence[Proof]) -> List[bytes]:
         """bbs_proofs_to_octets_batch: the octet strings of n proofs (host, one call)."""
         n = len(proofs)

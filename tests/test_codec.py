@@ -159,6 +159,17 @@ def check_batch_decode(lib_path, curve_name):
     assert n_ok >= 11
     ps, st = eng.proofs_from_octets_batch([])
     assert ps == [] and len(st) == 0
+    # the decode stage as a primitive: random subgroup points (both roots), the identity, points outside the subgroup
+    pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in range(40)] + [None]
+    enc = [bytes(bbs.g1_compress(c, q)) for q in pts]
+    dec, code = eng.g1_decompress_batch(enc)
+    assert dec == pts and list(code) == [0] * 40 + [1]
+    if curve_name == "bls12_381":
+        h = 0x396c8c005555e1568c00aaab0000aaab
+        outside = [(0, 2), (x, y), c.g1_mul((x, y), c.r), c.g1_mul((x, y), c.r * (h // 11)), c.g1_mul((x, y), 3), c.g1_add((x, y), c.g1)]
+        outside = [q for q in outside if q is not None]
+        dec, code = eng.g1_decompress_batch([bytes(bbs.g1_compress(c, q)) for q in outside])
+        assert list(code) == [-41] * len(outside) and dec == [None] * len(outside) and len(outside) >= 4
     # and back: the batch encoder gives the per-item encoder's bytes
     good = [pr for pr in proofs if pr is not None]
     assert eng.proofs_to_octets_batch(good) == [api.proof_to_octets(curve_name, pr, lib_path) for pr in good]
