@@ -72,6 +72,7 @@ SIGNATURES = {
     "bbs_proof_to_octets": (ci, [ci, c_u8p, c_u8p, sz, c_u8p]),
     "bbs_proof_from_octets": (ci, [ci, c_u8p, sz, c_u8p, c_u8p, sz, ctypes.POINTER(sz)]),
     "bbs_g1_decompress_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
+    "bbs_signatures_from_octets_batch": (ci, [vp, sz, c_u8p, c_u8p, c_i8p]),
     "bbs_proofs_to_octets_batch": (ci, [ci, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_proofs_from_octets_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u8p, c_u64p, c_i8p]),
     "bbs_public_key_to_octets": (ci, [ci, c_u8p, ci, c_u8p]),

@@ -564,6 +564,11 @@ int bbs_g1_decompress_batch(bbs_ctx* ctx, size_t n, const uint8_t* compressed, u
     return DISPATCH(ctx, g1_decompress_batch<BlsCurve>(AS_BLS(ctx), n, compressed, out_affine, code),
                     g1_decompress_batch<BnCurve>(AS_BN(ctx), n, compressed, out_affine, code));
 }
+int bbs_signatures_from_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* octets, uint8_t* sig_records_out, int8_t* status) {
+    if (!ctx) return BBS_E_ARG;
+    return DISPATCH(ctx, signatures_from_octets_batch<BlsCurve>(AS_BLS(ctx), n, octets, sig_records_out, status),
+                    signatures_from_octets_batch<BnCurve>(AS_BN(ctx), n, octets, sig_records_out, status));
+}
 int bbs_proofs_to_octets_batch(int curve, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cm_off, uint8_t* out, uint64_t* out_off,
                                int8_t* status) {
     if (!CURVE_OK(curve) || !cm_off || !out_off || !status || (n && (!pf || !out))) return BBS_E_ARG;

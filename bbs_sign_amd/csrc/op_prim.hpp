@@ -174,6 +174,36 @@ int g1_decompress_batch(Ctx<C>* ctx, size_t n, const uint8_t* in, uint8_t* out, 
     return BBS_OK;
 }
 
+// n signatures as octet strings (compress(A) || e, fp_bytes + 32 each) -> records A || e; the point work on the device.
+// status[i] = 1 or the code bbs_signature_from_octets gives for item i (same order of checks)
+template <class C>
+int signatures_from_octets_batch(Ctx<C>* ctx, size_t n, const uint8_t* oct, uint8_t* rec_out, int8_t* status) {
+    constexpr size_t NB = 4 * C::FpP::NC, olen = NB + 32, rlen = 2 * NB + 32;
+    using R = typename C::FrP;
+    if (!status || (n && (!oct || !rec_out))) return BBS_E_ARG;
+    std::vector<uint8_t> cp(std::max<size_t>(n, 1) * NB), aff(std::max<size_t>(n, 1) * 2 * NB);
+    for (size_t i = 0; i < n; i++) std::memcpy(cp.data() + i * NB, oct + i * olen, NB);
+    std::vector<int8_t> code(n + 1);
+    const int rc = g1_decompress_batch<C>(ctx, n, cp.data(), aff.data(), code.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* r = rec_out + i * rlen;
+        std::memset(r, 0, rlen);
+        if (code[i] < 0) { status[i] = code[i]; continue; }
+        if (code[i] == 1) { status[i] = BBS_ST_INVALID_ENCODING; continue; }        // A must not be the identity
+        uint32_t w[8];
+        uint8_t* e = r + 2 * NB;
+        for (int k = 0; k < 32; k++) e[k] = oct[i * olen + NB + 31 - k];
+        bool zero = true;
+        for (int k = 0; k < 8; k++) { w[k] = le32(e + 4 * k); zero &= w[k] == 0; }
+        if (!limbs_lt_mod<R>(w)) { status[i] = BBS_ST_NONCANONICAL; std::memset(e, 0, 32); continue; }
+        if (zero) { status[i] = BBS_ST_INVALID_ENCODING; continue; }                // e = 0 is rejected
+        std::memcpy(r, aff.data() + i * 2 * NB, 2 * NB);
+        status[i] = 1;
+    }
+    return BBS_OK;
+}
+
 // n proofs as octet strings -> the records of bbs_core_proof_verify_*: lengths and scalars on the host, the 3 n
 // compressed points on the device (codec_dev.hpp).  status[i] = 1 or the code bbs_proof_from_octets gives for item i
 // (same order of checks).  commit_off_out: n + 1 entries; commitments_out holds sum_i U_i scalars.

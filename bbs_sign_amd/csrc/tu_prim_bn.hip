@@ -8,3 +8,4 @@ template int selftest_f12<BnCurve>(Ctx<BnCurve>*, int, const uint8_t*, const uin
 template int msm_pippenger<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint8_t*, uint8_t*, int*, int8_t*);
 template int proofs_from_octets_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, const uint64_t*, uint8_t*, uint8_t*, uint64_t*, int8_t*);
 template int g1_decompress_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, uint8_t*, int8_t*);
+template int signatures_from_octets_batch<BnCurve>(Ctx<BnCurve>*, size_t, const uint8_t*, uint8_t*, int8_t*);

@@ -424,6 +424,17 @@ class Engine:
         b = out.tobytes()
         return [self._g1_dec(b[i * 2 * self.fpb:(i + 1) * 2 * self.fpb]) if code[i] == 0 else None for i in range(n)], code[:n]
 
+    def signatures_from_octets_batch(self, octets: Sequence[bytes]):
+        """bbs_signatures_from_octets_batch -> (list of Signature or None, statuses)."""
+        n = len(octets)
+        buf = _bytes_arr(b"".join(octets))
+        rec = 2 * self.fpb + 32
+        out = np.zeros(max(n, 1) * rec, dtype=np.uint8)
+        st = np.zeros(max(n, 1), dtype=np.int8)
+        self._chk(self.lib.bbs_signatures_from_octets_batch(self.h, n, _u8(buf), _u8(out), st.ctypes.data_as(_lib.c_i8p)),
+                  "bbs_signatures_from_octets_batch")
+        return self._dec_sigs(out, st, n), st[:n]
+
     def proofs_to_octets_batch(self, proofs: Sequence[Proof]) -> List[bytes]:
         """bbs_proofs_to_octets_batch: the octet strings of n proofs (host, one call)."""
         n = len(proofs)

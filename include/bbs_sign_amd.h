@@ -254,6 +254,9 @@ int bbs_proof_from_octets(int curve, const uint8_t* octets, size_t len, uint8_t*
  * on-curve and prime-order-subgroup checks.  code[i]: 0 ok, 1 ok and the identity (record = zeros), BBS_ST_NONCANONICAL
  * malformed / not canonical, BBS_ST_NOT_ON_CURVE not on the curve or outside the subgroup. */
 int bbs_g1_decompress_batch(bbs_ctx* ctx, size_t n, const uint8_t* compressed, uint8_t* out_affine, int8_t* code);
+/* bbs_signature_from_octets for n signatures (fp_bytes + 32 bytes each) at once, the point work on the device;
+ * status[i] = 1 or the code bbs_signature_from_octets returns for item i; records zeroed where status != 1. */
+int bbs_signatures_from_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* octets, uint8_t* sig_records_out, int8_t* status);
 /* bbs_proof_to_octets for n proofs at once (host; no field arithmetic: byte order and the sign flag only).  out needs
  * sum_i (3 * fp_bytes + 32 * (4 + U_i)) bytes; out_off: n + 1 byte offsets; status[i] = 1 or BBS_ST_NONCANONICAL. */
 int bbs_proofs_to_octets_batch(int curve, size_t n, const uint8_t* proofs_fixed, const uint8_t* commitments,

@@ -170,6 +170,20 @@ def check_batch_decode(lib_path, curve_name):
         outside = [q for q in outside if q is not None]
         dec, code = eng.g1_decompress_batch([bytes(bbs.g1_compress(c, q)) for q in outside])
         assert list(code) == [-41] * len(outside) and dec == [None] * len(outside) and len(outside) >= 4
+    # signatures: the batch ingest against the per-item one, incl. identity A, e = 0, e >= r, a point outside G1
+    sig_oct = [bytes(bbs.g1_compress(c, q)) + bbs.scalar_be(c, rng.randrange(1, c.r)) for q in pts[:6]]
+    sig_oct.append(bytes(bbs.g1_compress(c, None)) + bbs.scalar_be(c, 5))
+    sig_oct.append(bytes(bbs.g1_compress(c, pts[0])) + bytes(32))
+    sig_oct.append(bytes(bbs.g1_compress(c, pts[1])) + c.r.to_bytes(32, "big"))
+    if curve_name == "bls12_381":
+        sig_oct.append(bytes(bbs.g1_compress(c, (0, 2))) + bbs.scalar_be(c, 9))
+    sigs, st2 = eng.signatures_from_octets_batch(sig_oct)
+    for i, o in enumerate(sig_oct):
+        try:
+            want = api.octets_to_signature(curve_name, o, lib_path)
+            assert int(st2[i]) == 1 and (sigs[i].a, sigs[i].e) == (want.a, want.e), i
+        except BbsError as e:
+            assert int(st2[i]) == e.status and sigs[i] is None, (i, int(st2[i]), e.status)
     # and back: the batch encoder gives the per-item encoder's bytes
     good = [pr for pr in proofs if pr is not None]
     assert eng.proofs_to_octets_batch(good) == [api.proof_to_octets(curve_name, pr, lib_path) for pr in good]
