@@ -305,15 +305,19 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
     g1_recode(k, u);
     const bool even = (k[0] & 1u) == 0;
     G1Jac<C> r = g1j_from_aff<C>(g1_tab_digit<C>(tab, u[7] >> 28));
+    // entry of step i (i = -1: the correction (k + 1) P - P of an even k); requested one step ahead of its addition
+    auto fetch = [&](int i) -> G1Aff<C> {
+        if (i >= 0) return g1_tab_digit<C>(tab, (u[i >> 3] >> (4 * (i & 7))) & 15u);
+        return even ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+    };
+    G1Aff<C> qn = fetch(62);
 #pragma unroll 1
     for (int i = 62; i >= -1; i--) {
-        G1Aff<C> q;
+        const G1Aff<C> q = qn;
+        if (i > -1) qn = fetch(i - 1);
         if (i >= 0) {
 #pragma unroll 1
             for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
-            q = g1_tab_digit<C>(tab, (u[i >> 3] >> (4 * (i & 7))) & 15u);
-        } else {
-            q = even ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();       // (k + 1) P - P
         }
         r = g1j_add_aff<C>(r, q);
     }
@@ -360,20 +364,26 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
     g1_recode(k0, u[0]); g1_recode(k1, u[1]); g1_recode(k2, u[2]);
     const bool even[3] = {(k0[0] & 1u) == 0, (k1[0] & 1u) == 0, (k2[0] & 1u) == 0};
     G1Jac<C> r = g1j_inf<C>();
+    // 65 rounds (digits 63 .. 0, then the even-scalar corrections) x 3 tables, flattened: step s = round * 3 + table;
+    // the entry of step s + 1 is requested before the addition of step s (HBM table reads hidden behind it)
+    constexpr int STEPS = 65 * 3;
+    auto fetch = [&](int s) -> G1Aff<C> {
+        const int rd = s / 3, j = s - 3 * rd, i = 63 - rd;
+        const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        if (i >= 0) return g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
+        return even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+    };
+    G1Aff<C> qn = fetch(0);
 #pragma unroll 1
-    for (int i = 63; i >= -1; i--) {
-        if (i >= 0 && i < 63) {
+    for (int s = 0; s < STEPS; s++) {
+        const G1Aff<C> q = qn;
+        if (s + 1 < STEPS) qn = fetch(s + 1);
+        const int rd = s / 3;
+        if (s == 3 * rd && rd >= 1 && rd <= 63) {
 #pragma unroll 1
-            for (int s = 0; s < 4; s++) r = g1j_dbl<C>(r);
+            for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
         }
-#pragma unroll 1
-        for (int j = 0; j < 3; j++) {
-            const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-            G1Aff<C> q;
-            if (i >= 0) q = g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
-            else q = even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
-            r = g1j_add_aff<C>(r, q);
-        }
+        r = g1j_add_aff<C>(r, q);
     }
     r.z = fe_mul<FP>(r.z, zall);
     out = r;

@@ -196,7 +196,8 @@ __host__ __device__ inline G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, cons
     G1Jac<C> acc = g1j_inf<C>();
     int k_cur = -1;
     uint32_t sc[8];
-    for (int t = t0; t < t1; t++) {
+    // table entry of term t (false: digit 0, nothing to add)
+    auto fetch = [&](int t, G1Aff<C>& q) -> bool {
         const int k = t / W, w = t - k * W;
         if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); k_cur = k; }
         // digit = bits [w*c, w*c + c) of the scalar
@@ -206,12 +207,21 @@ __host__ __device__ inline G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, cons
         if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
         uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
         if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
-        if (d == 0) continue;
+        if (d == 0) return false;
         const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
-        G1Aff<C> q;
 #pragma unroll
         for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
-        acc = g1j_add_aff<C>(acc, q);
+        return true;
+    };
+    // the entry of term t + 1 is requested before the addition of term t: the (random, HBM) table read of one
+    // term overlaps the ~11 multiplications of the previous one -- with one wavefront per SIMD nothing else hides it
+    G1Aff<C> qn = g1a_inf<C>();
+    bool hn = t0 < t1 ? fetch(t0, qn) : false;
+    for (int t = t0; t < t1; t++) {
+        const G1Aff<C> q = qn;
+        const bool h = hn;
+        hn = t + 1 < t1 ? fetch(t + 1, qn) : false;
+        if (h) acc = g1j_add_aff<C>(acc, q);
     }
     return acc;
 }
