@@ -88,6 +88,25 @@ static int selftest_fp4sqr(int hi, const uint8_t* a, const uint8_t* b, uint8_t* 
     return BBS_OK;
 }
 
+// host arithmetic self-test: k0 P0 + k1 P1 + k2 P2 by the joint chain of proof_verify's T1 (g1.hpp g1_mul3_aff), plain or GLV
+template <class C>
+static int selftest_mul3(int glv, const uint8_t* pts, const uint8_t* scal, uint8_t* out) {
+    constexpr int N = C::FpP::N;
+    constexpr size_t FPB = 4 * C::FpP::NC;
+    if (glv && !C::K::HAS_GLV) return BBS_E_ARG;
+    G1Aff<C> p[3];
+    uint32_t k[3][8];
+    for (int j = 0; j < 3; j++) {
+        if (!codec::g1_record_to_aff<C>(pts + j * 2 * FPB, p[j]) || !g1a_on_curve<C>(p[j])) return BBS_E_ARG;
+        for (int w = 0; w < 8; w++) k[j][w] = le32(scal + 32 * j + 4 * w);
+        if (!limbs_lt_mod<typename C::FrP>(k[j])) return BBS_E_ARG;
+    }
+    std::vector<uint32_t> tabs((size_t)3 * G1_TAB * 2 * N);
+    const G1Jac<C> r = g1_mul3_aff<C>(p[0], k[0], p[1], k[1], p[2], k[2], tabs.data(), 1, glv != 0);
+    codec::g1_aff_to_record<C>(g1j_to_aff<C>(r), out);
+    return BBS_OK;
+}
+
 // FromOkm (src/utils/utilities_helper.rs:15-40): 48 big-endian bytes -> scalar mod r, canonical LE out
 template <class C>
 static void scalar_from_okm(const uint8_t* okm48, uint8_t* out32) {
@@ -183,6 +202,26 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
 int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32) {
     if (!ctx) return BBS_E_ARG;
     return DISPATCH(ctx, AS_BLS(ctx)->set_batch_verification(enabled, seed32), AS_BN(ctx)->set_batch_verification(enabled, seed32));
+}
+int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched) {
+    if (!ctx) return BBS_E_ARG;
+    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->points_in_subgroup = vouched != 0; else AS_BN(ctx)->points_in_subgroup = vouched != 0;
+    return BBS_OK;
+}
+int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16) {
+    if (curve != BBS_CURVE_BLS12_381 || !k32 || !k1_16 || !k2_16) return BBS_E_ARG;
+    uint32_t k[8], k1[4], k2[4];
+    for (int j = 0; j < 8; j++) k[j] = le32(k32 + 4 * j);
+    if (!limbs_lt_mod<BlsCurve::FrP>(k)) return BBS_E_ARG;
+    glv_split<BlsCurve>(k, k1, k2);
+    for (int j = 0; j < 4; j++) { put_le32(k1_16 + 4 * j, k1[j]); put_le32(k2_16 + 4 * j, k2[j]); }
+    return BBS_OK;
+}
+int bbs_selftest_mul3(int curve, int glv, const uint8_t* points, const uint8_t* scalars, uint8_t* out_affine) {
+    if (!points || !scalars || !out_affine) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return selftest_mul3<BlsCurve>(glv, points, scalars, out_affine);
+    if (curve == BBS_CURVE_BN254) return selftest_mul3<BnCurve>(glv, points, scalars, out_affine);
+    return BBS_E_ARG;
 }
 int bbs_ctx_set_generators(bbs_ctx* ctx, const uint8_t* g, size_t count, const uint8_t* api_id, size_t api_id_len) {
     if (!ctx) return BBS_E_ARG;

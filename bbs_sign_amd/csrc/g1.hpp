@@ -325,12 +325,148 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
     return r;
 }
 
+// ---- GLV split (BLS12-381; opt-in: bbs_ctx_set_points_in_subgroup) ----------------------------
+// On the prime-order subgroup (beta x, y) = [lambda] (x, y) with lambda = x^2 - 1 ~ 2^127.4 a root of X^2 + X + 1
+// mod r, so k P = k1 P + k2 phi(P) with k2 = floor(k / lambda), k1 = k mod lambda, both below 2^128: half the
+// doublings (124 instead of 252) for the same number of table additions, the phi-table being the same table with
+// x multiplied by beta.  The identity phi(P) = lambda P holds ONLY on the subgroup: for an on-curve point outside it
+// the result is not k P, which is why the default path does not use it (the reference's types guarantee membership,
+// this ABI takes raw coordinates).  Same group element as the plain chain for every P in G1.
+template <class C>
+BBS_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
+    using K = typename C::K;
+    uint32_t mu[5], lam[4];
+#pragma unroll
+    for (int j = 0; j < 5; j++) mu[j] = K::GLV_MU[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) lam[j] = K::GLV_LAMBDA[j];
+    // q = floor(k mu / 2^256) with mu = floor(2^256 / lambda):  floor(k / lambda) - 2 < q <= floor(k / lambda)
+    uint32_t pr[13];
+#pragma unroll
+    for (int j = 0; j < 13; j++) pr[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            c += (uint64_t)pr[i + j] + (uint64_t)k[i] * mu[j];
+            pr[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        pr[i + 5] = (uint32_t)c;
+    }
+    uint32_t q[4] = {pr[8], pr[9], pr[10], pr[11]};
+    // rem = k - q lambda  (< 3 lambda < 2^130: five words)
+    uint32_t ql[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ql[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c += (uint64_t)ql[i + j] + (uint64_t)q[i] * lam[j];
+            ql[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        ql[i + 4] = (uint32_t)c;
+    }
+    uint32_t rem[5];
+    {
+        int64_t b = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            b += (int64_t)k[j] - (int64_t)ql[j];
+            rem[j] = (uint32_t)b;
+            b >>= 32;
+        }
+    }
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        uint32_t d[5];
+        int64_t b = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            b += (int64_t)rem[j] - (int64_t)(j < 4 ? lam[j] : 0u);
+            d[j] = (uint32_t)b;
+            b >>= 32;
+        }
+        const bool ge = b == 0;                 // no borrow: rem >= lambda
+        uint64_t c = ge ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < 5; j++) rem[j] = ge ? d[j] : rem[j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c += q[j];
+            q[j] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { k1[j] = rem[j]; k2[j] = q[j]; }
+}
+
+// 32 odd digits of a 128-bit h (made odd): u = ((h | 1) >> 1) | 2^127
+BBS_HD void g1_recode128(const uint32_t* h, uint32_t* u) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) u[i] = (h[i] >> 1) | (h[i + 1] << 31);
+    u[3] = (h[3] >> 1) | 0x80000000u;
+}
+
+template <class C>
+BBS_HD Fp<C> glv_beta() {
+    Fp<C> b;
+#pragma unroll
+    for (int i = 0; i < C::FpP::N; i++) b.v[i] = C::K::BETA_L_M[i];
+    return b;
+}
+
+// k * P for P in the prime-order subgroup: two 128-bit halves on one doubling chain (see above)
+template <class C>
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv(const G1Aff<C>& p, const uint32_t* k) {
+    TabPriv<C> tab;
+    Fp<C> zc;
+    if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
+    uint32_t h[2][4], u[2][4];
+    glv_split<C>(k, h[0], h[1]);
+    g1_recode128(h[0], u[0]);
+    g1_recode128(h[1], u[1]);
+    const bool even[2] = {(h[0][0] & 1u) == 0, (h[1][0] & 1u) == 0};
+    const Fp<C> beta = glv_beta<C>();
+    // 33 rounds (digits 31 .. 0, then the even-half corrections) x (P, phi P): step s = round * 2 + half
+    constexpr int STEPS = 33 * 2;
+    auto fetch = [&](int s) -> G1Aff<C> {
+        const int rd = s >> 1, j = s & 1, i = 31 - rd;
+        G1Aff<C> q;
+        if (i >= 0) q = g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
+        else q = even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+        return q;
+    };
+    G1Jac<C> r = g1j_inf<C>();
+    G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+    for (int s = 0; s < STEPS; s++) {
+        G1Aff<C> q = qn;
+        if (s + 1 < STEPS) qn = fetch(s + 1);
+        if (s & 1) q.x = fe_mul<FP>(q.x, beta);          // phi, applied after the next entry has been requested
+        const int rd = s >> 1;
+        if ((s & 1) == 0 && rd >= 1 && rd <= 31) {
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+        }
+        r = g1j_add_aff<C>(r, q);
+    }
+    r.z = fe_mul<FP>(r.z, zc);
+    return r;
+}
+
 // k0 P0 + k1 P1 + k2 P2 on ONE shared doubling chain (Straus): the three tables are brought to one common curve
 // (scale of table j times the other two tables' scales), ~252 doublings + 3 * 64 mixed additions.
 // The tables live in the caller's HBM buffer `tabs` (3 * G1_TAB * 2N words, stride apart).
 // Returns false (out untouched) when a table hit an exceptional case: the caller then sums three separate
 // multiplications (done there, not here, so that the rare path does not deepen this function's stack).
-template <class C>
+// GLV = true (points in the prime-order subgroup, BLS12-381): six 128-bit halves, ~124 doublings + 6 * 33 additions.
+template <class C, bool GLV = false>
 BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
                                        const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, G1Jac<C>& out) {
 #ifdef BBS_G1_MUL_NAF
@@ -360,30 +496,69 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
             tab.st(e, G1Aff<C>{fe_mul<FP>(q.x, t2), fe_mul<FP>(q.y, t3)});
         }
     }
-    uint32_t u[3][8];
-    g1_recode(k0, u[0]); g1_recode(k1, u[1]); g1_recode(k2, u[2]);
-    const bool even[3] = {(k0[0] & 1u) == 0, (k1[0] & 1u) == 0, (k2[0] & 1u) == 0};
     G1Jac<C> r = g1j_inf<C>();
-    // 65 rounds (digits 63 .. 0, then the even-scalar corrections) x 3 tables, flattened: step s = round * 3 + table;
-    // the entry of step s + 1 is requested before the addition of step s (HBM table reads hidden behind it)
-    constexpr int STEPS = 65 * 3;
-    auto fetch = [&](int s) -> G1Aff<C> {
-        const int rd = s / 3, j = s - 3 * rd, i = 63 - rd;
-        const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-        if (i >= 0) return g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
-        return even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
-    };
-    G1Aff<C> qn = fetch(0);
+    if constexpr (GLV) {
+        // terms t = 2 * table + half: (P_j, k_j mod lambda), (phi P_j, floor(k_j / lambda))
+        uint32_t u[6][4];
+        bool even[6];
+        const uint32_t* ks[3] = {k0, k1, k2};
 #pragma unroll 1
-    for (int s = 0; s < STEPS; s++) {
-        const G1Aff<C> q = qn;
-        if (s + 1 < STEPS) qn = fetch(s + 1);
-        const int rd = s / 3;
-        if (s == 3 * rd && rd >= 1 && rd <= 63) {
-#pragma unroll 1
-            for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+        for (int j = 0; j < 3; j++) {
+            uint32_t h0[4], h1[4];
+            glv_split<C>(ks[j], h0, h1);
+            g1_recode128(h0, u[2 * j]);
+            g1_recode128(h1, u[2 * j + 1]);
+            even[2 * j] = (h0[0] & 1u) == 0;
+            even[2 * j + 1] = (h1[0] & 1u) == 0;
         }
-        r = g1j_add_aff<C>(r, q);
+        const Fp<C> beta = glv_beta<C>();
+        constexpr int STEPS = 33 * 6;
+        auto fetch = [&](int s) -> G1Aff<C> {
+            const int rd = s / 6, t = s - 6 * rd, i = 31 - rd;
+            const TabHbm<C> tab{tabs + (size_t)(t >> 1) * G1_TAB * 2 * N * stride, stride};
+            G1Aff<C> q;
+            if (i >= 0) q = g1_tab_digit<C>(tab, (u[t][i >> 3] >> (4 * (i & 7))) & 15u);
+            else q = even[t] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+            return q;
+        };
+        G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+        for (int s = 0; s < STEPS; s++) {
+            G1Aff<C> q = qn;
+            if (s + 1 < STEPS) qn = fetch(s + 1);
+            if (s & 1) q.x = fe_mul<FP>(q.x, beta);      // phi (odd terms), applied after the next entry has been requested
+            const int rd = s / 6;
+            if (s == 6 * rd && rd >= 1 && rd <= 31) {
+#pragma unroll 1
+                for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+            }
+            r = g1j_add_aff<C>(r, q);
+        }
+    } else {
+        uint32_t u[3][8];
+        g1_recode(k0, u[0]); g1_recode(k1, u[1]); g1_recode(k2, u[2]);
+        const bool even[3] = {(k0[0] & 1u) == 0, (k1[0] & 1u) == 0, (k2[0] & 1u) == 0};
+        // 65 rounds (digits 63 .. 0, then the even-scalar corrections) x 3 tables, flattened: step s = round * 3 + table;
+        // the entry of step s + 1 is requested before the addition of step s (HBM table reads hidden behind it)
+        constexpr int STEPS = 65 * 3;
+        auto fetch = [&](int s) -> G1Aff<C> {
+            const int rd = s / 3, j = s - 3 * rd, i = 63 - rd;
+            const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+            if (i >= 0) return g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
+            return even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+        };
+        G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+        for (int s = 0; s < STEPS; s++) {
+            const G1Aff<C> q = qn;
+            if (s + 1 < STEPS) qn = fetch(s + 1);
+            const int rd = s / 3;
+            if (s == 3 * rd && rd >= 1 && rd <= 63) {
+#pragma unroll 1
+                for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+            }
+            r = g1j_add_aff<C>(r, q);
+        }
     }
     r.z = fe_mul<FP>(r.z, zall);
     out = r;
@@ -391,10 +566,25 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
 }
 template <class C>
 BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
-                             const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride) {
+                             const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, bool glv = false) {
     G1Jac<C> r;
+    if constexpr (C::K::HAS_GLV) {
+        if (glv) {
+            if (g1_mul3_aff_fast<C, true>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
+            return g1j_add<C>(g1j_add<C>(g1_mul_aff<C>(p0, k0), g1_mul_aff<C>(p1, k1)), g1_mul_aff<C>(p2, k2));
+        }
+    }
     if (g1_mul3_aff_fast<C>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
     return g1j_add<C>(g1j_add<C>(g1_mul_aff<C>(p0, k0), g1_mul_aff<C>(p1, k1)), g1_mul_aff<C>(p2, k2));
+}
+
+// k * P with the GLV split where the curve has it and the caller vouches for subgroup membership
+template <class C>
+BBS_HD G1Jac<C> g1_mul_aff_sel(const G1Aff<C>& p, const uint32_t* k, bool glv) {
+    if constexpr (C::K::HAS_GLV) {
+        if (glv) return g1_mul_aff_glv<C>(p, k);
+    }
+    return g1_mul_aff<C>(p, k);
 }
 
 #undef FP

@@ -308,6 +308,9 @@ struct Ctx : bbs_ctx {
     bool consts_dirty = true;
     // batch verification (pippenger.hpp): off by default = every item gets its own pairing product
     bool batch_verify = false;
+    // caller vouches that every G1 input is in the prime-order subgroup: variable-base multiplications of the
+    // verification paths use the GLV split where the curve has it (g1.hpp); off by default
+    bool points_in_subgroup = false;
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
     std::mutex mu;                   // uploads may come from several host threads: counter and constant sync

@@ -250,6 +250,7 @@ struct PvArgs {
     size_t n;
     int L, Rmax;
     const CtxConsts<C>* cc;
+    int glv;                  // inputs vouched to be in G1: GLV split for the variable-base terms (BLS12-381)
     // inputs (canonical limbs, SoA)
     const uint32_t* pts;      // [3][2NC][n] a_bar, b_bar, d (canonical words)
     const uint32_t* sc;       // [4][8][n]   e_cap, r1_cap, r3_cap, challenge
@@ -319,13 +320,13 @@ struct PvMsmPart {
             soa_ld<8>(a.sc + (size_t)3 * 8 * n, n, i, kc);
             soa_ld<8>(a.sc, n, i, ke);
             soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
-            g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n));
+            g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n, a.glv != 0));
         } else if (part == 1) {
             // r3^*D, the variable-base term of T2 (proof_verify.rs:175-182)
             G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * C::FpP::NC * n, n, i);
             uint32_t k[8];
             soa_ld<8>(a.sc + (size_t)2 * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff<C>(pd, k));
+            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(pd, k, a.glv != 0));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - PV_NVAR));
         }
@@ -553,6 +554,7 @@ struct VfArgs {
     size_t n;
     int L;
     const CtxConsts<C>* cc;
+    int glv;
     const uint32_t* sig_a;    // [2NC][n] canonical
     const uint32_t* sig_e;    // [8][n]
     const uint32_t* msgs;     // [L][8][n]
@@ -599,7 +601,7 @@ struct VfMsmPart {
             g1a_store_mont<C>(a.aff, n, i, A);
             uint32_t k[8];
             soa_ld<8>(a.sig_e, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff<C>(A, k));
+            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(A, k, a.glv != 0));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - 1));
         }
@@ -930,6 +932,7 @@ template <class C>
 struct MsmArgs {
     size_t n;
     int n_fixed, n_var;
+    int glv;                  // see PvArgs
     const CtxConsts<C>* cc;
     const uint32_t* fscal;    // [n_fixed][8][n]
     const uint32_t* vpts;     // [n_var][2NC][n] canonical
@@ -954,7 +957,7 @@ struct MsmPart {
             if (!g1a_on_curve<C>(p)) { a.status[i] = -41; g1j_store<C>(out, n, i, g1j_inf<C>()); return; }
             uint32_t k[8];
             soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.n_fixed, part - a.n_var));
         }

@@ -190,6 +190,10 @@ class Engine:
         buf = _bytes_arr(self._fr(sk))
         self._chk(self.lib.bbs_ctx_set_secret_key(self.h, _u8(buf)), "bbs_ctx_set_secret_key")
 
+    def set_points_in_subgroup(self, vouched: bool):
+        """bbs_ctx_set_points_in_subgroup: the caller vouches that every G1 input is in the prime-order subgroup."""
+        self._chk(self.lib.bbs_ctx_set_points_in_subgroup(self.h, 1 if vouched else 0), "bbs_ctx_set_points_in_subgroup")
+
     def set_batch_verification(self, enabled: bool, seed: Optional[bytes] = None):
         """Opt-in random-linear-combination batch verification for core_proof_verify (include/bbs_sign_amd.h);
         seed=None draws the secret seed from the operating system."""

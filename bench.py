@@ -246,6 +246,35 @@ def main():
             extras["bls12_381"]["verify_batch_verification"] = {"verify_per_s": n * 96 / (vms * 1e-3), "batches_in_flight": len(vj)}
             for j in vj:
                 j.free()
+            # opt-in subgroup vouching (bbs_ctx_set_points_in_subgroup: GLV split of the variable-base terms), alone and
+            # together with batch verification; same proofs, same booleans -- not the headline either
+            def checked(make, k):
+                js = [make() for _ in range(k)]
+                for j in js:
+                    j.run()
+                for j in js:
+                    j.wait()
+                    assert (j.status() == 1).all()
+                return js
+            eng.set_points_in_subgroup(True)
+            gj = checked(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 8)
+            gvj = checked(lambda: eng.core_verify_upload(sigs, msgs), 8)
+            eng.set_batch_verification(True)
+            gbig = checked(lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12)
+            eng.set_batch_verification(False)
+            eng.set_points_in_subgroup(False)
+            g1ms, g1stage = gj[0].run_timed(3, per_stage=True)
+            gms8, _ = Job.run_many_timed(gj, 32)
+            gvms8, _ = Job.run_many_timed(gvj, 32)
+            gbms, _ = Job.run_many_timed(gbig, 48)
+            extras["bls12_381"]["points_in_subgroup"] = {
+                "proof_verify_8_in_flight": n * 32 / (gms8 * 1e-3), "verify_8_in_flight": n * 32 / (gvms8 * 1e-3),
+                "proof_verify_single_batch_ms": g1ms / 3, "pv_msm_parts_ms_single_batch": g1stage.get("pv_msm_parts", 0) / 3,
+                "proof_verify_batch_verification_16384_per_s": 4 * n * 48 / (gbms * 1e-3),
+                "note": "bbs_ctx_set_points_in_subgroup: caller vouches G1 membership (as the reference's types do); "
+                        "variable-base terms use the GLV split; opt-in, not the headline"}
+            for j in gj + gvj + gbig:
+                j.free()
         # host-inclusive form: bbs_core_proof_verify_batch on host buffers = validation + packing (C++),
         # H2D of the proofs, kernels, D2H of the statuses -- never the headline, which starts from HBM-resident batches
         import ctypes

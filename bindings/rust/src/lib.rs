@@ -26,6 +26,7 @@ extern "C" {
     fn bbs_ctx_set_generators(ctx: *mut BbsCtx, gens: *const u8, count: usize, api_id: *const u8, api_id_len: usize) -> c_int;
     fn bbs_ctx_set_public_key(ctx: *mut BbsCtx, pk: *const u8, is_identity: c_int) -> c_int;
     fn bbs_ctx_set_batch_verification(ctx: *mut BbsCtx, enabled: c_int, seed32: *const u8) -> c_int;
+    fn bbs_ctx_set_points_in_subgroup(ctx: *mut BbsCtx, vouched: c_int) -> c_int;
     fn bbs_create_generators(curve: c_int, count: usize, api_id: *const u8, api_id_len: usize, out_affine: *mut u8) -> c_int;
     fn bbs_hash_to_scalar_batch(ctx: *mut BbsCtx, n: usize, msgs: *const u8, msg_off: *const u64,
                                 dst: *const u8, dst_len: usize, scalars_out: *mut u8) -> c_int;
@@ -99,6 +100,8 @@ where <E::G1Affine as AffineRepr>::BaseField: PrimeField, E::ScalarField: PrimeF
             if rc != 0 { bbs_ctx_destroy(ctx); return Err(rc); }
             let rc = bbs_ctx_set_public_key(ctx, pk_affine.as_ptr(), 0);
             if rc != 0 { bbs_ctx_destroy(ctx); return Err(rc); }
+            // every E::G1Affine inside a Proof<E> / Signature<E> is a checked subgroup member (ark-ec), so the shim can vouch
+            bbs_ctx_set_points_in_subgroup(ctx, 1);
             if batch_verification { bbs_ctx_set_batch_verification(ctx, 1, std::ptr::null()); }
             Ok(Self { ctx, api_id, fpb, _e: std::marker::PhantomData })
         }

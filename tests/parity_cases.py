@@ -514,6 +514,85 @@ def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
     batch.close()
 
 
+def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8):
+    """bbs_ctx_set_points_in_subgroup (GLV split of the variable-base terms on BLS12-381, no effect on BN254): same
+    statuses and group elements as the default path and the oracle for inputs in G1 -- valid proofs / signatures,
+    tampered scalars and points, edge scalars through the MSM primitive -- alone and together with batch verification."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    exact = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    fast = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    fast.set_points_in_subgroup(True)
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = exact.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    proofs, st = exact.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    # valid inputs
+    assert list(fast.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
+    assert list(fast.core_verify_batch(sigs, msgs, headers)) == [1] * n
+    op = proofs[0]
+    assert bbs.core_proof_verify(suite, pk, bbs.Proof(op.a_bar, op.b_bar, op.d, op.e_cap, op.r1_cap, op.r3_cap, op.commitments,
+                                                      op.challenge), gens, headers[0], phs[0], dm[0], disclosed[0], api_id) is True
+    # tampered (all points still in G1): scalars, swapped points, a proof of a forged signature, the identity
+    bad = [to_engine_proof(p_) for p_ in proofs]
+    bad[1].e_cap = (bad[1].e_cap + 1) % c.r
+    bad[2].r1_cap = 0
+    bad[3].r3_cap = c.r - 1
+    bad[4].d = c.g1_mul(bad[4].d, 2)
+    bad[5].a_bar, bad[5].b_bar = bad[5].b_bar, bad[5].a_bar
+    bad[6].a_bar = None
+    forged = [Signature(s_.a, s_.e) for s_ in sigs]
+    forged[7] = Signature(c.g1_add(sigs[7].a, c.g1), sigs[7].e)
+    fp, st = exact.core_proof_gen_batch(forged, msgs, disclosed, rnds, headers, phs)
+    bad[7] = to_engine_proof(fp[7])
+    want = list(exact.core_proof_verify_batch(bad, dm, disclosed, headers, phs))
+    assert want[0] == 1 and want[1:8] == [0] * 7 and want[8:] == [1] * (n - 8), want
+    assert list(fast.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == want
+    vs = [Signature(s_.a, s_.e) for s_ in sigs]
+    vs[0] = forged[7]
+    vs[1] = Signature(sigs[1].a, (sigs[1].e + 1) % c.r)
+    vs[2] = Signature(None, sigs[2].e)
+    want_v = list(exact.core_verify_batch(vs, msgs, headers))
+    assert want_v[:3] != [1, 1, 1] and want_v[3:] == [1] * (n - 3), want_v
+    assert list(fast.core_verify_batch(vs, msgs, headers)) == want_v
+    # the group elements themselves: variable-base terms with edge scalars through the MSM primitive
+    lam = (c.x_param * c.x_param - 1) if curve == "bls12_381" else (1 << 127)
+    edge = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam, c.r - 1, c.r - 2, (1 << 128) - 1, 1 << 128, c.r - lam]
+    ks = [k % c.r for k in edge] + [rng.randrange(c.r) for _ in range(12)]
+    pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in ks]
+    pts[-1] = None
+    fs = [[rng.randrange(c.r), 1] for _ in ks]
+    got, st = fast.g1_msm_batch(fs, [[p_] for p_ in pts], [[k] for k in ks])
+    ref, st_ref = exact.g1_msm_batch(fs, [[p_] for p_ in pts], [[k] for k in ks])
+    assert list(st) == list(st_ref) == [1] * len(ks)
+    assert got == ref
+    for i in (0, 3, 4, 7, len(ks) - 2):
+        fixed = c.g1_add(c.g1_mul(suite.p1, fs[i][0]), gens[0])
+        assert got[i] == c.g1_add(fixed, c.g1_mul(pts[i], ks[i])), i
+    # together with batch verification
+    fast.set_batch_verification(True, bytes(rng.randrange(256) for _ in range(32)))
+    assert list(fast.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == want
+    assert list(fast.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
+    assert list(fast.core_verify_batch(vs, msgs, headers)) == want_v
+    # and back to the default
+    fast.set_batch_verification(False)
+    fast.set_points_in_subgroup(False)
+    assert list(fast.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == want
+    exact.close()
+    fast.close()
+
+
 # ------------------------------------------------------------------------------------------------
 def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0, device=0):
     """SURVEY 8d synthetic workload: one issuer key (IKM [1u8;32]), item b has L 32-byte messages

@@ -114,3 +114,62 @@ def test_fp4_half_square(libs, cid, curve, xi0, nl):
                 assert lib.bbs_selftest_fp4sqr(cid, hi, _u8(ab), _u8(bbuf), _u8(out)) == 0
                 o = out.tobytes()
                 assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == want, (cid, hi, trial)
+
+
+def _glv_edge_scalars(r, lam, rng, count):
+    edge = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam, 2 * lam + 1, lam * lam % r, r - 1, r - 2, (1 << 128) - 1, 1 << 128,
+            (lam - 1) + lam * (lam - 1), 3 * lam - 1, r - lam, r - lam - 1]
+    return [k % r for k in edge] + [rng.randrange(r) for _ in range(count)]
+
+
+def test_glv_split(libs):
+    """k = k1 + k2 lambda with both halves below 2^128 (g1.hpp glv_split: Barrett quotient + two corrections)."""
+    c = BLS12_381
+    lam = c.x_param * c.x_param - 1
+    assert (lam * lam + lam + 1) % c.r == 0
+    rng = random.Random(4242)
+    for lib in libs:
+        for k in _glv_edge_scalars(c.r, lam, rng, 400):
+            kb = np.frombuffer(k.to_bytes(32, "little"), dtype=np.uint8).copy()
+            k1 = np.zeros(16, dtype=np.uint8)
+            k2 = np.zeros(16, dtype=np.uint8)
+            assert lib.bbs_selftest_glv_split(0, _u8(kb), _u8(k1), _u8(k2)) == 0
+            a, b = int.from_bytes(k1.tobytes(), "little"), int.from_bytes(k2.tobytes(), "little")
+            assert (a, b) == (k % lam, k // lam), hex(k)
+        bad = np.frombuffer(c.r.to_bytes(32, "little"), dtype=np.uint8).copy()
+        assert lib.bbs_selftest_glv_split(0, _u8(bad), _u8(k1), _u8(k2)) != 0
+        assert lib.bbs_selftest_glv_split(1, _u8(kb), _u8(k1), _u8(k2)) != 0
+
+
+@pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
+def test_joint_multiplication(libs, cid, curve):
+    """k0 P0 + k1 P1 + k2 P2 on the joint chain of proof_verify's T1, plain and with the GLV split, against the
+    oracle's double-and-add: random and edge scalars (zero, even, below lambda, r - 1), the identity and repeated
+    points among the inputs (those take the per-point fallback)."""
+    c = curve
+    fpb = c.fp_bytes
+    rng = random.Random(99 + cid)
+    lam = (BLS12_381.x_param * BLS12_381.x_param - 1) if cid == 0 else (1 << 127)
+    sc = _glv_edge_scalars(c.r, lam, rng, 8)
+
+    def rec(P):
+        return bytes(2 * fpb) if P is None else P[0].to_bytes(fpb, "little") + P[1].to_bytes(fpb, "little")
+
+    pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in range(4)]
+    cases = [([pts[0], pts[1], pts[2]], [rng.choice(sc) for _ in range(3)]) for _ in range(5)]
+    cases += [([pts[0], pts[1], pts[2]], [sc[i], sc[(i + 5) % len(sc)], sc[(i + 11) % len(sc)]]) for i in range(0, len(sc), 4)]
+    cases.append(([pts[0], pts[0], c.g1_neg(pts[0])], [5, 7, 12]))             # sums to the identity
+    cases.append(([pts[3], None, pts[1]], [rng.randrange(c.r), 3, rng.randrange(c.r)]))
+    for lib in libs:
+        for glv in ((0, 1) if cid == 0 else (0,)):
+            for P, k in cases:
+                pb = np.frombuffer(b"".join(rec(q) for q in P), dtype=np.uint8).copy()
+                kb = np.frombuffer(b"".join(x.to_bytes(32, "little") for x in k), dtype=np.uint8).copy()
+                out = np.zeros(2 * fpb, dtype=np.uint8)
+                assert lib.bbs_selftest_mul3(cid, glv, _u8(pb), _u8(kb), _u8(out)) == 0
+                want = None
+                for q, x in zip(P, k):
+                    want = c.g1_add(want, c.g1_mul(q, x))
+                assert out.tobytes() == rec(want), (glv, k)
+        if cid == 1:
+            assert lib.bbs_selftest_mul3(cid, 1, _u8(pb), _u8(kb), _u8(out)) != 0

@@ -44,6 +44,11 @@ def test_batch_verification(curve):
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_points_in_subgroup(curve):
+    pc.check_points_in_subgroup(curve, None)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_full_batch_4096(curve):
     pc.check_big_batch(curve, None, n=4096, L=32, R=8)
 

@@ -54,5 +54,10 @@ def test_batch_verification(twin, curve):
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_points_in_subgroup(twin, curve):
+    pc.check_points_in_subgroup(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_empty_batches(twin, curve):
     pc.check_empty_batches(curve, twin)

@@ -209,6 +209,45 @@ def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_d
         g_ += 1
     beta = pow(g_, (p - 1) // 3, p)
     s += arr("BETA_M", m(beta), n)
+    # GLV split (g1.hpp g1_mul_aff_glv; BLS12 only): lambda = x^2 - 1 is a root of X^2 + X + 1 mod r of half the
+    # length of r, so k = k1 + k2 lambda with k2 = floor(k / lambda), k1 = k mod lambda, both < 2^128.
+    # BETA_L: the cube root of unity with (BETA_L x, y) = [lambda] (x, y) on G1 (checked on the generator below).
+    lam = xabs * xabs - 1
+    has_glv = (lam * lam + lam + 1) % r == 0 and lam.bit_length() <= 128
+    s += "    static constexpr bool HAS_GLV = %s;\n" % ("true" if has_glv else "false")
+    if has_glv:
+        def aadd(P, Q):
+            if P is None:
+                return Q
+            if Q is None:
+                return P
+            (x1, y1), (x2, y2) = P, Q
+            if x1 == x2:
+                if (y1 + y2) % p == 0:
+                    return None
+                l_ = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+            else:
+                l_ = (y2 - y1) * pow(x2 - x1, -1, p) % p
+            x3 = (l_ * l_ - x1 - x2) % p
+            return (x3, (l_ * (x1 - x3) - y1) % p)
+
+        def amul(P, k):
+            R_ = None
+            while k:
+                if k & 1:
+                    R_ = aadd(R_, P)
+                P = aadd(P, P)
+                k >>= 1
+            return R_
+        lg = amul(g1, lam)
+        cands = [c for c in (beta, beta * beta % p) if lg == (c * g1[0] % p, g1[1])]
+        assert len(cands) == 1
+        mu = (1 << 256) // lam
+        assert mu.bit_length() <= 160
+        s += raw_arr("GLV_LAMBDA", [(lam >> (32 * i)) & 0xFFFFFFFF for i in range(4)])
+        s += "    // GLV_MU = floor(2^256 / lambda)\n"
+        s += raw_arr("GLV_MU", [(mu >> (32 * i)) & 0xFFFFFFFF for i in range(5)])
+        s += arr("BETA_L_M", m(cands[0]), n)
     s += arr("B3_M", m(3 * b), n)
     s += arr("G1X_M", m(g1[0]), n) + arr("G1Y_M", m(g1[1]), n)
     s += arr("P1X_M", m(p1[0]), n) + arr("P1Y_M", m(p1[1]), n)
