@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--window-bits", type=int, default=16)
+    ap.add_argument("--window-bits", type=int, default=20)
     ap.add_argument("--inflight", type=int, default=8, help="device-resident batches in flight per GPU")
     ap.add_argument("--batch-verify", action="store_true", help="time the opt-in batch-verification mode (one combined "
                     "pairing check per batch, per-item fallback) instead of the default per-item pairing products")
@@ -256,25 +256,28 @@ def main():
                     j.wait()
                     assert (j.status() == 1).all()
                 return js
+            # (one job set alive at a time: created, checked, timed, freed)
+            def measured(make, k, steps, single=False):
+                js = checked(make, k)
+                one = js[0].run_timed(3, per_stage=True) if single else None
+                Job.run_many_timed(js, 8)                  # untimed rounds, as the headline's warm-up
+                ms, _ = Job.run_many_timed(js, steps)
+                for j in js:
+                    j.free()
+                return ms, one
             eng.set_points_in_subgroup(True)
-            gj = checked(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 8)
-            gvj = checked(lambda: eng.core_verify_upload(sigs, msgs), 8)
+            gms8, (g1ms, g1stage) = measured(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 8, 32, single=True)
+            gvms8, _ = measured(lambda: eng.core_verify_upload(sigs, msgs), 8, 32)
             eng.set_batch_verification(True)
-            gbig = checked(lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12)
+            gbms, _ = measured(lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 48)
             eng.set_batch_verification(False)
             eng.set_points_in_subgroup(False)
-            g1ms, g1stage = gj[0].run_timed(3, per_stage=True)
-            gms8, _ = Job.run_many_timed(gj, 32)
-            gvms8, _ = Job.run_many_timed(gvj, 32)
-            gbms, _ = Job.run_many_timed(gbig, 48)
             extras["bls12_381"]["points_in_subgroup"] = {
                 "proof_verify_8_in_flight": n * 32 / (gms8 * 1e-3), "verify_8_in_flight": n * 32 / (gvms8 * 1e-3),
                 "proof_verify_single_batch_ms": g1ms / 3, "pv_msm_parts_ms_single_batch": g1stage.get("pv_msm_parts", 0) / 3,
                 "proof_verify_batch_verification_16384_per_s": 4 * n * 48 / (gbms * 1e-3),
                 "note": "bbs_ctx_set_points_in_subgroup: caller vouches G1 membership (as the reference's types do); "
                         "variable-base terms use the GLV split; opt-in, not the headline"}
-            for j in gj + gvj + gbig:
-                j.free()
         # host-inclusive form: bbs_core_proof_verify_batch on host buffers = validation + packing (C++),
         # H2D of the proofs, kernels, D2H of the statuses -- never the headline, which starts from HBM-resident batches
         import ctypes
@@ -326,7 +329,7 @@ def main():
         extras["bls12_381"]["proofs_from_octets"] = {"proofs_per_s": 4 * n / (time.perf_counter() - t1),
             "note": "bbs_proofs_from_octets_batch: 1040-byte proof octets -> records, 3 x 4096 G1 decompressions and "
                     "subgroup checks on the device, scalars on the host, one call at a time"}
-        _, eb, _, _, mb, db, rb = pc.bench_workload("bn254", n, L, R, None, 8, device=local_rank)
+        _, eb, _, _, mb, db, rb = pc.bench_workload("bn254", n, L, R, None, 16, device=local_rank)
         sb, st = eb.core_sign_batch(mb)
         assert (st == 1).all()
         pb, st = eb.core_proof_gen_batch(sb, mb, db, rb)

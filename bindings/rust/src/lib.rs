@@ -95,7 +95,7 @@ where <E::G1Affine as AffineRepr>::BaseField: PrimeField, E::ScalarField: PrimeF
             let mut ctx = std::ptr::null_mut();
             let rc = bbs_ctx_create(E::CURVE_ID, device, &mut ctx);
             if rc != 0 { return Err(rc); }
-            bbs_ctx_set_window_bits(ctx, 16);
+            bbs_ctx_set_window_bits(ctx, 20);   // 52 GB of tables for L = 32 on a 288 GB device; 16 -> 4 GB, a few % slower
             let rc = bbs_ctx_set_generators(ctx, gens.as_ptr(), l + 1, api_id.as_ptr(), api_id.len());
             if rc != 0 { bbs_ctx_destroy(ctx); return Err(rc); }
             let rc = bbs_ctx_set_public_key(ctx, pk_affine.as_ptr(), 0);

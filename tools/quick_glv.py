@@ -27,7 +27,7 @@ def jobs(glv, k=8, verify=False):
 
 
 sets = {"pv default": jobs(False), "pv vouched": jobs(True), "vf default": jobs(False, verify=True), "vf vouched": jobs(True, verify=True)}
-for rep in range(3):
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     for name, js in sets.items():
         ms, _ = Job.run_many_timed(js, 32)
         one, stg = js[0].run_timed(3, per_stage=True)

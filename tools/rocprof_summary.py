@@ -20,7 +20,7 @@ def short(name):
 
 
 with open(os.path.join(src, "stats", "stats_kernel_stats.csv")) as f, open(dst + "_kernel_stats.csv", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras  (MI355X, 8 batches of 4096 in flight, window 16)\n")
+    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras  (MI355X, 8 batches of 4096 in flight)\n")
     o.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in csv.DictReader(f):
         o.write('"%s",%s,%s,%d,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
@@ -38,7 +38,7 @@ for k, v in vals.items():
     mean[k] = sum(last) / len(last)
 with open(dst + "_pmc.csv", "w") as o:
     o.write("# rocprofv3 --kernel-trace --pmc <set> (4 separate passes, tools/run_profile.sh) -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras\n")
-    o.write("# mean of the last 3 launches of each kernel (one 4096-item batch, BLS12-381, L=32, R=8, window 16).\n")
+    o.write("# mean of the last 3 launches of each kernel (one 4096-item batch, BLS12-381, L=32, R=8).\n")
     o.write("# SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles; FETCH_SIZE / WRITE_SIZE are KiB as reported (FETCH_SIZE x2 on gfx950 for wide reads)\n")
     o.write("kernel,counter,mean_per_launch\n")
     for (k, c) in sorted(mean):
