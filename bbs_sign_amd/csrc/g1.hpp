@@ -247,6 +247,20 @@ struct TabHbm {
     }
 };
 
+// "where the table of a single multiplication lives", passed to the (non-inlined) multiplication routines
+template <class C>
+struct AtPriv {
+    using Tab = TabPriv<C>;
+    BBS_HD void init(Tab&) const {}
+};
+template <class C>
+struct AtHbm {
+    using Tab = TabHbm<C>;
+    uint32_t* base;
+    size_t stride;
+    BBS_HD void init(Tab& t) const { t.base = base; t.stride = stride; }
+};
+
 // table of the odd multiples of P as affine points of the curve isomorphic by `zc` (point (x', y') there is the
 // Jacobian point (x', y', zc) here); false if P is the identity or an exceptional case occurred.
 // (Inlined into its caller: as a separate function writing the caller's private table through pointers it
@@ -293,12 +307,14 @@ BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U) {
     return q;
 }
 
-template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
+// (the table lives where the caller says: AtPriv = the lane's private memory, AtHbm = a caller-provided buffer)
+template <class C, class W>
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
 #ifdef BBS_G1_MUL_NAF
     return g1_mul_aff_naf<C>(p, k);
 #endif
-    TabPriv<C> tab;
+    typename W::Tab tab;
+    where.init(tab);
     Fp<C> zc;
     if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
     uint32_t u[8];
@@ -324,6 +340,9 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) {
     r.z = fe_mul<FP>(r.z, zc);
     return r;
 }
+
+template <class C>
+BBS_HD G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) { return g1_mul_aff_tab<C, AtPriv<C>>(p, k, AtPriv<C>{}); }
 
 // ---- GLV split (BLS12-381; opt-in: bbs_ctx_set_points_in_subgroup) ----------------------------
 // On the prime-order subgroup (beta x, y) = [lambda] (x, y) with lambda = x^2 - 1 ~ 2^127.4 a root of X^2 + X + 1
@@ -422,9 +441,10 @@ BBS_HD Fp<C> glv_beta() {
 }
 
 // k * P for P in the prime-order subgroup: two 128-bit halves on one doubling chain (see above)
-template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv(const G1Aff<C>& p, const uint32_t* k) {
-    TabPriv<C> tab;
+template <class C, class W>
+BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
+    typename W::Tab tab;
+    where.init(tab);
     Fp<C> zc;
     if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
     uint32_t h[2][4], u[2][4];
@@ -569,14 +589,19 @@ BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<
                              const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, bool glv = false) {
     G1Jac<C> r;
     if constexpr (C::K::HAS_GLV) {
-        if (glv) {
-            if (g1_mul3_aff_fast<C, true>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
-            return g1j_add<C>(g1j_add<C>(g1_mul_aff<C>(p0, k0), g1_mul_aff<C>(p1, k1)), g1_mul_aff<C>(p2, k2));
-        }
+        if (glv && g1_mul3_aff_fast<C, true>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
     }
-    if (g1_mul3_aff_fast<C>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
-    return g1j_add<C>(g1j_add<C>(g1_mul_aff<C>(p0, k0), g1_mul_aff<C>(p1, k1)), g1_mul_aff<C>(p2, k2));
+    if (!glv && g1_mul3_aff_fast<C>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
+    // a table hit an exceptional case (identity, point of small order): three separate multiplications, each of
+    // which falls back to the generic chain on its own; their tables reuse the caller's buffer
+    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    const AtHbm<C> w0{tabs, stride}, w1{tabs + TW * stride, stride}, w2{tabs + 2 * TW * stride, stride};
+    return g1j_add<C>(g1j_add<C>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1)),
+                      g1_mul_aff_tab<C, AtHbm<C>>(p2, k2, w2));
 }
+
+template <class C>
+BBS_HD G1Jac<C> g1_mul_aff_glv(const G1Aff<C>& p, const uint32_t* k) { return g1_mul_aff_glv_tab<C, AtPriv<C>>(p, k, AtPriv<C>{}); }
 
 // k * P with the GLV split where the curve has it and the caller vouches for subgroup membership
 template <class C>
@@ -585,6 +610,14 @@ BBS_HD G1Jac<C> g1_mul_aff_sel(const G1Aff<C>& p, const uint32_t* k, bool glv) {
         if (glv) return g1_mul_aff_glv<C>(p, k);
     }
     return g1_mul_aff<C>(p, k);
+}
+// the same with the window table in a caller-provided HBM buffer (G1_TAB * 2N words, stride apart)
+template <class C>
+BBS_HD G1Jac<C> g1_mul_aff_sel_hbm(const G1Aff<C>& p, const uint32_t* k, bool glv, uint32_t* tab, size_t stride) {
+    if constexpr (C::K::HAS_GLV) {
+        if (glv) return g1_mul_aff_glv_tab<C, AtHbm<C>>(p, k, AtHbm<C>{tab, stride});
+    }
+    return g1_mul_aff_tab<C, AtHbm<C>>(p, k, AtHbm<C>{tab, stride});
 }
 
 #undef FP

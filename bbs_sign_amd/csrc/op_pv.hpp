@@ -92,7 +92,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     a.partials = job->template scratch<uint32_t>((size_t)PV_NPARTS * 3 * N * n, rc);
     a.aff = job->template scratch<uint32_t>((size_t)5 * 2 * N * n, rc);
     a.fmiller = job->template scratch<uint32_t>((size_t)2 * 12 * N * n, rc);
-    a.vtab = job->template scratch<uint32_t>((size_t)3 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);
+    a.vtab = job->template scratch<uint32_t>((size_t)4 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);   // T1's three tables + the one of D * r3^
     if (rc) return rc;
     if ((rc = job->finish_setup())) return rc;
     a.status = job->d_status.template as<int8_t>();

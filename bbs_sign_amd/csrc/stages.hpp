@@ -267,7 +267,7 @@ struct PvArgs {
     uint32_t* partials;       // [PV_NPARTS][3N][n] Jacobian
     uint32_t* aff;            // [5][2N][n] Montgomery affine: a_bar, b_bar, d, T1, T2
     uint32_t* fmiller;        // [2][12N][n]
-    uint32_t* vtab;           // [3][G1_TAB][2N][n] window tables of the joint multiplication (g1.hpp)
+    uint32_t* vtab;           // [4][G1_TAB][2N][n] window tables: three of the joint multiplication, one of D * r3^ (g1.hpp)
 };
 
 // stage 1 (lane per item): domain, fixed-base scalars
@@ -326,7 +326,9 @@ struct PvMsmPart {
             G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * C::FpP::NC * n, n, i);
             uint32_t k[8];
             soa_ld<8>(a.sc + (size_t)2 * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(pd, k, a.glv != 0));
+            // its window table in HBM next to the three of part 0 (a private table is 0.9 KB of scratch per lane of
+            // the whole kernel, and scratch x hardware queues is what limits the number of queues: DESIGN.md 5 rule 6)
+            g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(pd, k, a.glv != 0, a.vtab + (size_t)3 * G1_TAB * 2 * N * n + i, n));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - PV_NVAR));
         }
