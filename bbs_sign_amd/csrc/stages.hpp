@@ -719,6 +719,7 @@ struct PgArgs {
     size_t n;
     int L, Rmax;
     const CtxConsts<C>* cc;
+    int glv;                  // see PvArgs
     const uint32_t* sig_a;    // [2NC][n] canonical
     const uint32_t* sig_e;    // [8][n]
     const uint32_t* msgs;     // [L][8][n]
@@ -832,7 +833,7 @@ struct PgMsmPart {
             G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part < 4 ? 0 : 1) * 2 * N * n, n, i);
             uint32_t k[8];
             soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff<C>(p, k));
+            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal2, n, i, a.L + 2, part - PG_NVAR));
         }

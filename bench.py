@@ -268,12 +268,14 @@ def main():
             eng.set_points_in_subgroup(True)
             gms8, (g1ms, g1stage) = measured(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 8, 32, single=True)
             gvms8, _ = measured(lambda: eng.core_verify_upload(sigs, msgs), 8, 32)
+            gpms8, _ = measured(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 8, 32)
             eng.set_batch_verification(True)
             gbms, _ = measured(lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 48)
             eng.set_batch_verification(False)
             eng.set_points_in_subgroup(False)
             extras["bls12_381"]["points_in_subgroup"] = {
                 "proof_verify_8_in_flight": n * 32 / (gms8 * 1e-3), "verify_8_in_flight": n * 32 / (gvms8 * 1e-3),
+                "proof_gen_8_in_flight": n * 32 / (gpms8 * 1e-3),
                 "proof_verify_single_batch_ms": g1ms / 3, "pv_msm_parts_ms_single_batch": g1stage.get("pv_msm_parts", 0) / 3,
                 "proof_verify_batch_verification_16384_per_s": 4 * n * 48 / (gbms * 1e-3),
                 "note": "bbs_ctx_set_points_in_subgroup: caller vouches G1 membership (as the reference's types do); "

@@ -538,6 +538,12 @@ def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8):
     proofs, st = exact.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
     assert list(st) == [1] * n
     dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    # proof_gen under vouching produces the same proofs (its variable-base terms of A and B use the split too)
+    proofs_fast, st = fast.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    for pa, pb in zip(proofs, proofs_fast):
+        assert (pa.a_bar, pa.b_bar, pa.d, pa.e_cap, pa.r1_cap, pa.r3_cap, list(pa.commitments), pa.challenge) == \
+               (pb.a_bar, pb.b_bar, pb.d, pb.e_cap, pb.r1_cap, pb.r3_cap, list(pb.commitments), pb.challenge)
     # valid inputs
     assert list(fast.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
     assert list(fast.core_verify_batch(sigs, msgs, headers)) == [1] * n
