@@ -40,10 +40,10 @@ inline void stream_destroy(Stream&) {}
 inline int dmalloc(void** p, size_t b) { *p = std::calloc(b ? b : 1, 1); return *p ? 0 : -1; }
 inline void dfree(void* p, size_t, int) { std::free(p); }
 inline int current_device() { return 0; }
-inline int h2d(void* d, const void* h, size_t b, Stream&) { std::memcpy(d, h, b); return 0; }
-inline int d2h(void* h, const void* d, size_t b, Stream&) { std::memcpy(h, d, b); return 0; }
-inline int dmemset(void* d, int v, size_t b, Stream&) { std::memset(d, v, b); return 0; }
-inline int d2d_async(void* d, const void* s, size_t b, Stream&) { std::memcpy(d, s, b); return 0; }
+inline int h2d(void* d, const void* h, size_t b, Stream&) { if (b) std::memcpy(d, h, b); return 0; }
+inline int d2h(void* h, const void* d, size_t b, Stream&) { if (b) std::memcpy(h, d, b); return 0; }
+inline int dmemset(void* d, int v, size_t b, Stream&) { if (b) std::memset(d, v, b); return 0; }
+inline int d2d_async(void* d, const void* s, size_t b, Stream&) { if (b) std::memcpy(d, s, b); return 0; }
 inline int sync(Stream&) { return 0; }
 struct Event { };
 inline int event_create(Event*) { return 0; }

@@ -1,0 +1,33 @@
+#!/bin/bash
+# TEST-ONLY: AddressSanitizer + UBSan build of the host twin (CPU; GPU sanitizers are not available on this pool) and a
+# run of the parity cases through it.  ~20 min of compile time on 8 cores.  usage: tools/sanitize_twin.sh [outdir]
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$ROOT/bbs_sign_amd/build/san}; mkdir -p $OUT
+pids=()
+for tu in $ROOT/bbs_sign_amd/csrc/*.hip; do
+  hipcc -O1 -g --offload-host-only -x hip -DBBS_HOST_TWIN -DBBS_CHECK_BOUNDS -fPIC -fsanitize=address,undefined \
+        -fno-omit-frame-pointer -fno-sanitize=vptr -c $tu -o $OUT/$(basename $tu .hip).o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc -shared -fPIC --offload-host-only -fsanitize=address,undefined -shared-libsan $OUT/*.o -o $OUT/libbbs_hosttwin_san_TESTONLY.so
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+cat > $OUT/run_san.py <<PY
+import sys
+sys.path.insert(0, "$ROOT"); sys.path.insert(0, "$ROOT/tests")
+import parity_cases as pc
+lib = "$OUT/libbbs_hosttwin_san_TESTONLY.so"
+pc.check_kat_vectors(lib)
+for curve in ("bls12_381", "bn254"):
+    pc.check_golden(curve, lib, max_L=5)
+    pc.check_random_batch(curve, lib, n=6, L=3, seed=3)
+    pc.check_error_semantics(curve, lib)
+    pc.check_batch_verification(curve, lib)
+    pc.check_points_in_subgroup(curve, lib)
+    pc.check_pippenger(curve, lib, n=24)
+    pc.check_empty_batches(curve, lib)
+    print(curve, "ok", flush=True)
+print("sanitizer run ok")
+PY
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT python3 $OUT/run_san.py 2>&1 | tee $OUT/run.log | grep -E "runtime error|AddressSanitizer|ok" | sort | uniq -c
