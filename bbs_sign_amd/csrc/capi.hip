@@ -208,13 +208,21 @@ int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched) {
     if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->points_in_subgroup = vouched != 0; else AS_BN(ctx)->points_in_subgroup = vouched != 0;
     return BBS_OK;
 }
-int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16) {
-    if (curve != BBS_CURVE_BLS12_381 || !k32 || !k1_16 || !k2_16) return BBS_E_ARG;
+int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16, int* neg1, int* neg2) {
+    if ((curve != BBS_CURVE_BLS12_381 && curve != BBS_CURVE_BN254) || !k32 || !k1_16 || !k2_16 || !neg1 || !neg2) return BBS_E_ARG;
     uint32_t k[8], k1[4], k2[4];
+    bool n1 = false, n2 = false;
     for (int j = 0; j < 8; j++) k[j] = le32(k32 + 4 * j);
-    if (!limbs_lt_mod<BlsCurve::FrP>(k)) return BBS_E_ARG;
-    glv_split<BlsCurve>(k, k1, k2);
+    if (curve == BBS_CURVE_BLS12_381) {
+        if (!limbs_lt_mod<BlsCurve::FrP>(k)) return BBS_E_ARG;
+        glv_split<BlsCurve>(k, k1, k2, n1, n2);
+    } else {
+        if (!limbs_lt_mod<BnCurve::FrP>(k)) return BBS_E_ARG;
+        glv_split<BnCurve>(k, k1, k2, n1, n2);
+    }
     for (int j = 0; j < 4; j++) { put_le32(k1_16 + 4 * j, k1[j]); put_le32(k2_16 + 4 * j, k2[j]); }
+    *neg1 = n1 ? 1 : 0;
+    *neg2 = n2 ? 1 : 0;
     return BBS_OK;
 }
 int bbs_selftest_mul3(int curve, int glv, const uint8_t* points, const uint8_t* scalars, uint8_t* out_affine) {

@@ -300,9 +300,9 @@ BBS_HD void g1_recode(const uint32_t* k, uint32_t* u) {
     u[7] = (k[7] >> 1) | 0x80000000u;
 }
 template <class C, class T>
-BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U) {
-    const bool neg = U < 8;
-    G1Aff<C> q = tab.ld(neg ? 7u - U : U - 8u);
+BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U, bool flip = false) {      // flip: the digit of a negative half
+    const bool low = U < 8, neg = low != flip;
+    G1Aff<C> q = tab.ld(low ? 7u - U : U - 8u);
     q.y = fe_select<FP>(neg, fe_neg<FP>(q.y), q.y);
     return q;
 }
@@ -352,7 +352,7 @@ BBS_HD G1Jac<C> g1_mul_aff(const G1Aff<C>& p, const uint32_t* k) { return g1_mul
 // the result is not k P, which is why the default path does not use it (the reference's types guarantee membership,
 // this ABI takes raw coordinates).  Same group element as the plain chain for every P in G1.
 template <class C>
-BBS_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
+BBS_HD void glv_split_simple(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
     using K = typename C::K;
     uint32_t mu[5], lam[4];
 #pragma unroll
@@ -425,6 +425,101 @@ BBS_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
     for (int j = 0; j < 4; j++) { k1[j] = rem[j]; k2[j] = q[j]; }
 }
 
+// BN254: lambda is a full-length root of X^2 + X + 1 mod r; (k1, k2) = (k, 0) - c1 (a1, b1) - c2 (a2, b2) with a short
+// basis of {(x, y): x + y lambda = 0 mod r} and c_i = round(k b / r) taken as (k G_i + 2^319) >> 320 (params_gen.hpp,
+// derived and bounded in tools/gen_params.py: |k1|, |k2| < 2^127).  k = k1 + k2 lambda mod r holds for any integers
+// c1, c2, so the rounding only affects the lengths.  Halves come out as magnitude + sign.  Every on-curve point of a
+// cofactor-1 curve is in the subgroup, so this split needs no vouching (K::GLV_ALWAYS).
+template <class C>
+BBS_HD void glv_split_lattice(const uint32_t* k, uint32_t* k1, uint32_t* k2, bool& neg1, bool& neg2) {
+    using K = typename C::K;
+    // c = (k G + 2^319) >> 320 : words 10..13 of the 15-word product
+    auto quot = [&](const uint32_t* G, uint32_t* c) {
+        uint32_t pr[15];
+#pragma unroll
+        for (int j = 0; j < 15; j++) pr[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t cy = 0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                cy += (uint64_t)pr[i + j] + (uint64_t)k[i] * G[j];
+                pr[i + j] = (uint32_t)cy;
+                cy >>= 32;
+            }
+            pr[i + 7] = (uint32_t)cy;
+        }
+        uint64_t cy = (uint64_t)pr[9] + 0x80000000u;            // + 2^319
+        cy >>= 32;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cy += pr[10 + j]; c[j] = (uint32_t)cy; cy >>= 32; }
+    };
+    // acc (192-bit two's complement) -= / += c * a  (low six words; the final values are below 2^128 in magnitude)
+    auto mulacc = [&](uint32_t* acc, const uint32_t* c, const uint32_t* a, bool subtract) {
+        uint32_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint64_t cy = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cy += (uint64_t)t[i + j] + (uint64_t)c[i] * a[j];
+                t[i + j] = (uint32_t)cy;
+                cy >>= 32;
+            }
+            t[i + 4] = (uint32_t)cy;
+        }
+        int64_t b = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            b += (int64_t)acc[j] + (subtract ? -(int64_t)t[j] : (int64_t)t[j]);
+            acc[j] = (uint32_t)b;
+            b >>= 32;
+        }
+    };
+    auto finish = [&](uint32_t* acc, uint32_t* out, bool& neg) {
+        neg = (acc[5] >> 31) != 0;
+        uint64_t cy = neg ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cy += neg ? (uint32_t)~acc[j] : acc[j];
+            out[j] = (uint32_t)cy;
+            cy >>= 32;
+        }
+    };
+    uint32_t G1[7], G2[7], A1[4], B1[4], A2[4], B2[4];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { G1[j] = K::GLV_G1[j]; G2[j] = K::GLV_G2[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { A1[j] = K::GLV_A1[j]; B1[j] = K::GLV_B1[j]; A2[j] = K::GLV_A2[j]; B2[j] = K::GLV_B2[j]; }
+    uint32_t c1[4], c2[4];
+    quot(G1, c1);
+    quot(G2, c2);
+    uint32_t x[6], y[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { x[j] = k[j]; y[j] = 0; }
+    // k1 = k - c1 a1 - c2 a2 ; k2 = -c1 b1 - c2 b2   (c_i = +-|c_i|, a, b = +-|.|: a product is subtracted when its signs agree)
+    mulacc(x, c1, A1, K::GLV_C1_NEG == K::GLV_A1_NEG);
+    mulacc(x, c2, A2, K::GLV_C2_NEG == K::GLV_A2_NEG);
+    mulacc(y, c1, B1, K::GLV_C1_NEG == K::GLV_B1_NEG);
+    mulacc(y, c2, B2, K::GLV_C2_NEG == K::GLV_B2_NEG);
+    finish(x, k1, neg1);
+    finish(y, k2, neg2);
+}
+
+// k = (+-k1) + (+-k2) lambda mod r, k1, k2 < 2^128
+template <class C>
+BBS_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2, bool& neg1, bool& neg2) {
+    if constexpr (C::K::GLV_LATTICE) {
+        glv_split_lattice<C>(k, k1, k2, neg1, neg2);
+    } else {
+        glv_split_simple<C>(k, k1, k2);
+        neg1 = false;
+        neg2 = false;
+    }
+}
+
 // 32 odd digits of a 128-bit h (made odd): u = ((h | 1) >> 1) | 2^127
 BBS_HD void g1_recode128(const uint32_t* h, uint32_t* u) {
 #pragma unroll
@@ -448,7 +543,8 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k
     Fp<C> zc;
     if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
     uint32_t h[2][4], u[2][4];
-    glv_split<C>(k, h[0], h[1]);
+    bool neg[2];
+    glv_split<C>(k, h[0], h[1], neg[0], neg[1]);
     g1_recode128(h[0], u[0]);
     g1_recode128(h[1], u[1]);
     const bool even[2] = {(h[0][0] & 1u) == 0, (h[1][0] & 1u) == 0};
@@ -458,8 +554,8 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k
     auto fetch = [&](int s) -> G1Aff<C> {
         const int rd = s >> 1, j = s & 1, i = 31 - rd;
         G1Aff<C> q;
-        if (i >= 0) q = g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
-        else q = even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+        if (i >= 0) q = g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u, neg[j]);
+        else q = even[j] ? (neg[j] ? tab.ld(0) : g1a_neg<C>(tab.ld(0))) : g1a_inf<C>();
         return q;
     };
     G1Jac<C> r = g1j_inf<C>();
@@ -520,12 +616,12 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
     if constexpr (GLV) {
         // terms t = 2 * table + half: (P_j, k_j mod lambda), (phi P_j, floor(k_j / lambda))
         uint32_t u[6][4];
-        bool even[6];
+        bool even[6], neg[6];
         const uint32_t* ks[3] = {k0, k1, k2};
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {
             uint32_t h0[4], h1[4];
-            glv_split<C>(ks[j], h0, h1);
+            glv_split<C>(ks[j], h0, h1, neg[2 * j], neg[2 * j + 1]);
             g1_recode128(h0, u[2 * j]);
             g1_recode128(h1, u[2 * j + 1]);
             even[2 * j] = (h0[0] & 1u) == 0;
@@ -537,8 +633,8 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
             const int rd = s / 6, t = s - 6 * rd, i = 31 - rd;
             const TabHbm<C> tab{tabs + (size_t)(t >> 1) * G1_TAB * 2 * N * stride, stride};
             G1Aff<C> q;
-            if (i >= 0) q = g1_tab_digit<C>(tab, (u[t][i >> 3] >> (4 * (i & 7))) & 15u);
-            else q = even[t] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+            if (i >= 0) q = g1_tab_digit<C>(tab, (u[t][i >> 3] >> (4 * (i & 7))) & 15u, neg[t]);
+            else q = even[t] ? (neg[t] ? tab.ld(0) : g1a_neg<C>(tab.ld(0))) : g1a_inf<C>();
             return q;
         };
         G1Aff<C> qn = fetch(0);

@@ -106,7 +106,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     int rc = BBS_OK;
     PgArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && ctx->points_in_subgroup) ? 1 : 0;
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
     a.sig_a = job->up(sa.soa(), rc); a.sig_e = job->up(se.soa(), rc); a.msgs = job->up(sm.soa(), rc);
     a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
     a.rnd5 = job->up(rnd5.soa(), rc); a.mtilde = job->up(mt.soa(), rc);

@@ -94,7 +94,7 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     if (rc) return rc;
     MsmArgs<C> a;
     a.n = n; a.n_fixed = (int)nf; a.n_var = (int)nv; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && ctx->points_in_subgroup) ? 1 : 0;
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
     a.fscal = dF.as<uint32_t>(); a.vpts = dVP.as<uint32_t>(); a.vscal = dVS.as<uint32_t>();
     a.status = dSt.as<int8_t>(); a.partials = dPart.as<uint32_t>(); a.out = dOut.as<uint32_t>();
     if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;

@@ -82,7 +82,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     int rc = BBS_OK;
     PvArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && ctx->points_in_subgroup) ? 1 : 0;
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
     a.pts = job->up(pts.soa(), rc); a.sc = job->up(sc.soa(), rc); a.slots = job->up(slots.soa(), rc);
     a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);

@@ -44,7 +44,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     int rc = BBS_OK;
     VfArgs<C>& a = job->a;
     a.n = n; a.L = L; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && ctx->points_in_subgroup) ? 1 : 0;
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
     a.sig_a = job->up(sa.soa(), rc); a.sig_e = job->up(se.soa(), rc); a.msgs = job->up(sm.soa(), rc);
     a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);

@@ -94,8 +94,9 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
  * point.  vouched = 1 promises that every G1 point later handed to core_verify / core_proof_verify / core_proof_gen (and the generators given to
  * bbs_ctx_set_generators) through this context is in the subgroup (true for everything that came out of bbs_*_from_octets*, which check it): on BLS12-381
  * the variable-base multiplications of those paths then use the GLV endomorphism split (half the doublings).  Results
- * are identical for such inputs; for on-curve points outside the subgroup they are unspecified.  No effect on BN254
- * (cofactor 1, no split implemented).  Takes effect for jobs uploaded afterwards. */
+ * are identical for such inputs; for on-curve points outside the subgroup they are unspecified.  BN254 has cofactor 1
+ * (every on-curve point is in the subgroup), so there the split is always on and this setting changes nothing.
+ * Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched);
 
 /* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
@@ -293,12 +294,13 @@ int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, u
 /* Host arithmetic self-test (no GPU): x^-1 in the base field (scalar_field = 0, fp_bytes LE) or the scalar field
  * (1, 32 bytes LE) by the safegcd inversion the kernels use and by the Fermat power x^(p-2). */
 int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat);
-/* Host arithmetic self-test (no GPU, BLS12-381 only): the GLV split of a canonical scalar k (32 bytes LE) as the
- * kernels compute it: k = k1 + k2 * lambda mod r with lambda = x^2 - 1, k1 and k2 below 2^128 (16 bytes LE each). */
-int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16);
+/* Host arithmetic self-test (no GPU): the GLV split of a canonical scalar k (32 bytes LE) as the kernels compute it:
+ * k = (+-k1) + (+-k2) * lambda mod r, k1 and k2 below 2^128 (16 bytes LE each), *neg = 1 for a negative half.
+ * BLS12-381: lambda = x^2 - 1, k2 = floor(k / lambda), both halves non-negative; BN254: rounding against a short
+ * lattice basis (lambda = the cube root of unity whose words are GLV_LAMBDA in params_gen.hpp). */
+int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16, int* neg1, int* neg2);
 /* Host arithmetic self-test (no GPU): k0 P0 + k1 P1 + k2 P2 by the joint windowed chain proof_verify uses for T1
- * (src/proof_verify.rs:163-164), plain (glv = 0) or with the GLV split (glv = 1, BLS12-381 only, points must be in
- * the subgroup).  points: 3 affine records, scalars: 3 x 32 bytes LE canonical. */
+ * (src/proof_verify.rs:163-164), plain (glv = 0) or with the GLV split (glv = 1; BLS12-381 points must be in the subgroup).  points: 3 affine records, scalars: 3 x 32 bytes LE canonical. */
 int bbs_selftest_mul3(int curve, int glv, const uint8_t* points, const uint8_t* scalars, uint8_t* out_affine);
 /* Host arithmetic self-test (no GPU): one half of an Fp4 square as the pairing kernel computes it (four limb-column
  * products, one reduction pair): hi = 0: a^2 + xi b^2, hi = 1: 2 a b, for a, b in Fp2 (c0 || c1, canonical LE). */

@@ -122,23 +122,39 @@ def _glv_edge_scalars(r, lam, rng, count):
     return [k % r for k in edge] + [rng.randrange(r) for _ in range(count)]
 
 
-def test_glv_split(libs):
-    """k = k1 + k2 lambda with both halves below 2^128 (g1.hpp glv_split: Barrett quotient + two corrections)."""
-    c = BLS12_381
-    lam = c.x_param * c.x_param - 1
+def _bn_lambda():
+    """The cube root of unity mod r the BN254 split is built on (tools/gen_params.py picks it the same way)."""
+    r = BN254.r
+    g = 2
+    while pow(g, (r - 1) // 3, r) == 1:
+        g += 1
+    return pow(g, (r - 1) // 3, r)
+
+
+@pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
+def test_glv_split(libs, cid, curve):
+    """k = (+-k1) + (+-k2) lambda mod r with both halves below 2^128 (g1.hpp glv_split).  BLS12-381: Barrett quotient
+    by lambda = x^2 - 1 and two corrections, exact floor / remainder; BN254: rounding against a short lattice basis."""
+    c = curve
+    lam = (c.x_param * c.x_param - 1) if cid == 0 else _bn_lambda()
     assert (lam * lam + lam + 1) % c.r == 0
-    rng = random.Random(4242)
+    rng = random.Random(4242 + cid)
     for lib in libs:
         for k in _glv_edge_scalars(c.r, lam, rng, 400):
             kb = np.frombuffer(k.to_bytes(32, "little"), dtype=np.uint8).copy()
             k1 = np.zeros(16, dtype=np.uint8)
             k2 = np.zeros(16, dtype=np.uint8)
-            assert lib.bbs_selftest_glv_split(0, _u8(kb), _u8(k1), _u8(k2)) == 0
+            n1, n2 = ctypes.c_int(0), ctypes.c_int(0)
+            assert lib.bbs_selftest_glv_split(cid, _u8(kb), _u8(k1), _u8(k2), ctypes.byref(n1), ctypes.byref(n2)) == 0
             a, b = int.from_bytes(k1.tobytes(), "little"), int.from_bytes(k2.tobytes(), "little")
-            assert (a, b) == (k % lam, k // lam), hex(k)
+            if cid == 0:
+                assert (a, b, n1.value, n2.value) == (k % lam, k // lam, 0, 0), hex(k)
+            else:
+                sa, sb = (-a if n1.value else a), (-b if n2.value else b)
+                assert (sa + sb * lam - k) % c.r == 0 and a < (1 << 127) and b < (1 << 127), hex(k)
         bad = np.frombuffer(c.r.to_bytes(32, "little"), dtype=np.uint8).copy()
-        assert lib.bbs_selftest_glv_split(0, _u8(bad), _u8(k1), _u8(k2)) != 0
-        assert lib.bbs_selftest_glv_split(1, _u8(kb), _u8(k1), _u8(k2)) != 0
+        assert lib.bbs_selftest_glv_split(cid, _u8(bad), _u8(k1), _u8(k2), ctypes.byref(n1), ctypes.byref(n2)) != 0
+        assert lib.bbs_selftest_glv_split(2, _u8(kb), _u8(k1), _u8(k2), ctypes.byref(n1), ctypes.byref(n2)) != 0
 
 
 @pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
@@ -149,7 +165,7 @@ def test_joint_multiplication(libs, cid, curve):
     c = curve
     fpb = c.fp_bytes
     rng = random.Random(99 + cid)
-    lam = (BLS12_381.x_param * BLS12_381.x_param - 1) if cid == 0 else (1 << 127)
+    lam = (BLS12_381.x_param * BLS12_381.x_param - 1) if cid == 0 else _bn_lambda()
     sc = _glv_edge_scalars(c.r, lam, rng, 8)
 
     def rec(P):
@@ -161,7 +177,7 @@ def test_joint_multiplication(libs, cid, curve):
     cases.append(([pts[0], pts[0], c.g1_neg(pts[0])], [5, 7, 12]))             # sums to the identity
     cases.append(([pts[3], None, pts[1]], [rng.randrange(c.r), 3, rng.randrange(c.r)]))
     for lib in libs:
-        for glv in ((0, 1) if cid == 0 else (0,)):
+        for glv in (0, 1):
             for P, k in cases:
                 pb = np.frombuffer(b"".join(rec(q) for q in P), dtype=np.uint8).copy()
                 kb = np.frombuffer(b"".join(x.to_bytes(32, "little") for x in k), dtype=np.uint8).copy()
@@ -171,5 +187,3 @@ def test_joint_multiplication(libs, cid, curve):
                 for q, x in zip(P, k):
                     want = c.g1_add(want, c.g1_mul(q, x))
                 assert out.tobytes() == rec(want), (glv, k)
-        if cid == 1:
-            assert lib.bbs_selftest_mul3(cid, 1, _u8(pb), _u8(kb), _u8(out)) != 0

@@ -212,42 +212,108 @@ def curve_struct(tag, p, r, n, b, xi, twist, g1, g2, p1, xabs, xneg, loop_bits_d
     # GLV split (g1.hpp g1_mul_aff_glv; BLS12 only): lambda = x^2 - 1 is a root of X^2 + X + 1 mod r of half the
     # length of r, so k = k1 + k2 lambda with k2 = floor(k / lambda), k1 = k mod lambda, both < 2^128.
     # BETA_L: the cube root of unity with (BETA_L x, y) = [lambda] (x, y) on G1 (checked on the generator below).
-    lam = xabs * xabs - 1
-    has_glv = (lam * lam + lam + 1) % r == 0 and lam.bit_length() <= 128
-    s += "    static constexpr bool HAS_GLV = %s;\n" % ("true" if has_glv else "false")
-    if has_glv:
-        def aadd(P, Q):
-            if P is None:
-                return Q
-            if Q is None:
-                return P
-            (x1, y1), (x2, y2) = P, Q
-            if x1 == x2:
-                if (y1 + y2) % p == 0:
-                    return None
-                l_ = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
-            else:
-                l_ = (y2 - y1) * pow(x2 - x1, -1, p) % p
-            x3 = (l_ * l_ - x1 - x2) % p
-            return (x3, (l_ * (x1 - x3) - y1) % p)
+    def aadd(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            l_ = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            l_ = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (l_ * l_ - x1 - x2) % p
+        return (x3, (l_ * (x1 - x3) - y1) % p)
 
-        def amul(P, k):
-            R_ = None
-            while k:
-                if k & 1:
-                    R_ = aadd(R_, P)
-                P = aadd(P, P)
-                k >>= 1
-            return R_
-        lg = amul(g1, lam)
+    def amul(P, k):
+        R_ = None
+        while k:
+            if k & 1:
+                R_ = aadd(R_, P)
+            P = aadd(P, P)
+            k >>= 1
+        return R_
+
+    def beta_for(lam_):
+        lg = amul(g1, lam_)
         cands = [c for c in (beta, beta * beta % p) if lg == (c * g1[0] % p, g1[1])]
         assert len(cands) == 1
+        return cands[0]
+
+    lam = xabs * xabs - 1
+    simple = (lam * lam + lam + 1) % r == 0 and lam.bit_length() <= 128
+    s += "    static constexpr bool HAS_GLV = true;\n"
+    import math as _m
+    cof1 = r > p + 1 - 2 * _m.isqrt(p) - 2          # r within the Hasse interval: the group order is r itself (cofactor 1)
+    assert amul(g1, r) is None
+    s += "    static constexpr bool GLV_ALWAYS = %s;    // cofactor 1: every on-curve point is in the subgroup, no vouching needed\n" % ("true" if cof1 else "false")
+    s += "    static constexpr bool GLV_LATTICE = %s;   // false: k2 = floor(k / lambda); true: rounding against a short basis\n" % ("false" if simple else "true")
+    if simple:
         mu = (1 << 256) // lam
         assert mu.bit_length() <= 160
         s += raw_arr("GLV_LAMBDA", [(lam >> (32 * i)) & 0xFFFFFFFF for i in range(4)])
         s += "    // GLV_MU = floor(2^256 / lambda)\n"
         s += raw_arr("GLV_MU", [(mu >> (32 * i)) & 0xFFFFFFFF for i in range(5)])
-        s += arr("BETA_L_M", m(cands[0]), n)
+        s += arr("BETA_L_M", m(beta_for(lam)), n)
+    else:
+        # BN: lambda is a full-length root of X^2 + X + 1 mod r; short basis (a1, b1), (a2, b2) of the lattice
+        # {(x, y): x + y lambda = 0 mod r} from the extended Euclidean algorithm on (r, lambda) (Gallant-Lambert-
+        # Vanstone); k = k1 + k2 lambda with (k1, k2) = (k, 0) - c1 (a1, b1) - c2 (a2, b2), c1 = round(b2 k / r),
+        # c2 = round(-b1 k / r), computed as (k G + 2^319) >> 320 with G = round(2^320 |b| / r): the identity holds for
+        # ANY integers c1, c2, the rounding only decides how short (k1, k2) are -- asserted below over edge and random k.
+        gq = 2
+        while pow(gq, (r - 1) // 3, r) == 1:
+            gq += 1
+        lam = pow(gq, (r - 1) // 3, r)
+        assert (lam * lam + lam + 1) % r == 0
+        rows = [(r, 1, 0), (lam, 0, 1)]                    # (remainder, s, t): remainder = s r + t lambda
+        while rows[-1][0] != 0:
+            q_ = rows[-2][0] // rows[-1][0]
+            rows.append((rows[-2][0] - q_ * rows[-1][0], rows[-2][1] - q_ * rows[-1][1], rows[-2][2] - q_ * rows[-1][2]))
+        import math
+        sq = math.isqrt(r)
+        l_ = max(i for i, row in enumerate(rows) if row[0] >= sq)
+        v1 = (rows[l_ + 1][0], -rows[l_ + 1][2])
+        c_a, c_b = (rows[l_][0], -rows[l_][2]), (rows[l_ + 2][0], -rows[l_ + 2][2])
+        v2 = c_a if c_a[0] ** 2 + c_a[1] ** 2 <= c_b[0] ** 2 + c_b[1] ** 2 else c_b
+        (a1, b1), (a2, b2) = v1, v2
+        assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0 and a1 * b2 - a2 * b1 in (r, -r)
+        if a1 * b2 - a2 * b1 == -r:
+            (a1, b1), (a2, b2) = (a2, b2), (a1, b1)
+        SH = 320
+        G1c, G2c = (abs(b2) << SH) // r, (abs(b1) << SH) // r
+        G1c += 1 if ((abs(b2) << SH) % r) * 2 >= r else 0
+        G2c += 1 if ((abs(b1) << SH) % r) * 2 >= r else 0
+        c1neg, c2neg = b2 < 0, -b1 < 0
+
+        def split(k):
+            c1 = (k * G1c + (1 << (SH - 1))) >> SH
+            c2 = (k * G2c + (1 << (SH - 1))) >> SH
+            c1 = -c1 if c1neg else c1
+            c2 = -c2 if c2neg else c2
+            return k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
+        import random
+        rng = random.Random(1)
+        worst = 0
+        for k in [0, 1, 2, r - 1, r - 2, lam, lam + 1, r - lam, (r - 1) // 2, 1 << 128, (1 << 253) + 12345] + [rng.randrange(r) for _ in range(20000)]:
+            k1, k2 = split(k)
+            assert (k1 + k2 * lam - k) % r == 0
+            worst = max(worst, abs(k1), abs(k2))
+        assert worst.bit_length() <= 127, worst.bit_length()        # one bit of margin below the 128-bit recoding
+        for v in (a1, b1, a2, b2):
+            assert abs(v).bit_length() <= 128
+        assert G1c.bit_length() <= 224 and G2c.bit_length() <= 224
+        w32 = lambda v, cnt: [(abs(v) >> (32 * i)) & 0xFFFFFFFF for i in range(cnt)]
+        s += raw_arr("GLV_LAMBDA", w32(lam, 8))
+        s += raw_arr("GLV_A1", w32(a1, 4)) + raw_arr("GLV_B1", w32(b1, 4)) + raw_arr("GLV_A2", w32(a2, 4)) + raw_arr("GLV_B2", w32(b2, 4))
+        s += "    static constexpr bool GLV_A1_NEG = %s, GLV_B1_NEG = %s, GLV_A2_NEG = %s, GLV_B2_NEG = %s;\n" % tuple(
+            "true" if v < 0 else "false" for v in (a1, b1, a2, b2))
+        s += "    // c_i = +-((k GLV_Gi + 2^319) >> 320)\n"
+        s += raw_arr("GLV_G1", w32(G1c, 7)) + raw_arr("GLV_G2", w32(G2c, 7))
+        s += "    static constexpr bool GLV_C1_NEG = %s, GLV_C2_NEG = %s;\n" % ("true" if c1neg else "false", "true" if c2neg else "false")
+        s += arr("BETA_L_M", m(beta_for(lam)), n)
     s += arr("B3_M", m(3 * b), n)
     s += arr("G1X_M", m(g1[0]), n) + arr("G1Y_M", m(g1[1]), n)
     s += arr("P1X_M", m(p1[0]), n) + arr("P1Y_M", m(p1[1]), n)
