@@ -343,6 +343,21 @@ def main():
                            "proof_gen": rate(eb.core_proof_gen_upload(sb, mb, db, rb)), "proof_verify": rate(jb),
                            "proof_verify_8_in_flight": rate8(lambda: eb.core_proof_verify_upload(pb, dmb, db))}
         assert (jb.status() == 1).all()
+        # BASELINE configs[4] on one GPU: its share of the mixed batch is half BN254, half BLS12-381 -- four resident
+        # jobs of each curve in flight together (two contexts, every job on its own streams)
+        mj = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(4)] + \
+             [eb.core_proof_verify_upload(pb, dmb, db) for _ in range(4)]
+        for j in mj:
+            j.run()
+        for j in mj:
+            j.wait()
+            assert (j.status() == 1).all()
+        Job.run_many_timed(mj, 8)
+        mms, _ = Job.run_many_timed(mj, 64)                # 64 batch runs, round robin over the eight jobs
+        extras["mixed_curves"] = {"proof_verify_per_s": n * 64 / (mms * 1e-3),
+                                  "note": "BASELINE configs[4] per-GPU share: 4 BLS12-381 + 4 BN254 batches of %d in flight" % n}
+        for j in mj:
+            j.free()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([passed], dtype=torch.int64, device=red_dev)
