@@ -74,6 +74,15 @@ static int selftest_inv(const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fer
     return BBS_OK;
 }
 
+// host arithmetic self-test: 3 x0 +- 2 x1 in the base field by the run-time-sign chain of the cyclotomic square
+template <class P>
+static int selftest_lin_pm(int plus, const uint8_t* x0, const uint8_t* x1, uint8_t* out) {
+    Fe<P> a, b;
+    if (!fe_from_le_bytes<P>(x0, a) || !fe_from_le_bytes<P>(x1, b)) return BBS_E_ARG;
+    fe_to_le_bytes<P>(fe_lin_pm<P, 3, 2>(a, b, plus != 0), out);
+    return BBS_OK;
+}
+
 // host arithmetic self-test: one half of an Fp4 square by the four-column form (tower.hpp fp4_sqr_part)
 template <class C>
 static int selftest_fp4sqr(int hi, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -646,6 +655,13 @@ int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out
     if (!x || !out_safegcd || !out_fermat) return BBS_E_ARG;
     if (curve == BBS_CURVE_BLS12_381) return scalar_field ? selftest_inv<BlsFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BlsFpParams>(x, out_safegcd, out_fermat);
     if (curve == BBS_CURVE_BN254) return scalar_field ? selftest_inv<BnFrParams>(x, out_safegcd, out_fermat) : selftest_inv<BnFpParams>(x, out_safegcd, out_fermat);
+    return BBS_E_ARG;
+}
+
+int bbs_selftest_lin_pm(int curve, int plus, const uint8_t* x0, const uint8_t* x1, uint8_t* out) {
+    if (!x0 || !x1 || !out) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return selftest_lin_pm<BlsFpParams>(plus, x0, x1, out);
+    if (curve == BBS_CURVE_BN254) return selftest_lin_pm<BnFpParams>(plus, x0, x1, out);
     return BBS_E_ARG;
 }
 

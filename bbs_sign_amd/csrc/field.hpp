@@ -436,6 +436,40 @@ BBS_HD Fe<P> lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2, const Fe<P>&
     return r;
 }
 
+// C0 x0 + C1 x1 or C0 x0 - C1 x1, the sign chosen at run time (per lane) -- one chain instead of computing both forms
+// and selecting: the lift C1 * BOUND * p is always added (harmless for the sum: the quotient estimate absorbs it).
+template <class P, int C0, int C1>
+BBS_HD Fe<P> lin_pm(const Fe<P>& x0, const Fe<P>& x1, bool plus) {
+    constexpr int N = P::N;
+    static_assert(C0 > 0 && C1 > 0 && C0 + 2 * C1 <= 8, "lin_pm weight");
+    int32_t x[N];
+    const int32_t m = plus ? 0 : -1;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        BBS_BOUND_ASSERT(x0.v[i] <= MASK28 && x1.v[i] <= MASK28, "lin_pm operands normal");
+        x[i] = C0 * (int32_t)x0.v[i] + C1 * ((((int32_t)x1.v[i]) ^ m) - m) + C1 * (int32_t)P::MODB[i];
+    }
+    BBS_BOUND_ASSERT(x0.v[N - 1] <= P::MODB[N - 1] && x1.v[N - 1] <= P::MODB[N - 1], "lin_pm operands < BOUND*p");
+    int64_t T = x[N - 1];
+    if constexpr (P::QK == 2) T = T * (int64_t)(1 << 28) + x[N - 2];
+    T -= (C0 + 2 * C1 + 1);
+    const uint32_t q = T > 0 ? (uint32_t)(((uint64_t)T * P::RECIP) >> P::RSHIFT) : 0u;
+    Fe<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int64_t tt = (int64_t)x[i] - (int64_t)q * (int64_t)P::MOD[i] + c;
+        if (i < N - 1) {
+            r.v[i] = (uint32_t)tt & MASK28;
+            c = tt >> 28;
+        } else {
+            r.v[i] = (uint32_t)tt;
+            BBS_BOUND_ASSERT(tt >= 0 && (uint64_t)tt <= P::MOD2[N - 1], "lin_pm result in [0, 2p)");
+        }
+    }
+    return r;
+}
+
 // Reduce a lazily accumulated value given limb-wise by `limb(i)` (signed 64-bit, |limb| < 2^40, total
 // value in [0, weight * BOUND * p), `weight` = number of normal terms summed, negatives already
 // compensated by multiples of BOUND*p): reciprocal quotient estimate + one signed chain.
@@ -605,6 +639,12 @@ BBS_HD Fe<P> fe_lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2, const Fe<
         term(C0, x0); term(C1, x1); term(C2, x2); term(C3, x3);
         return acc;
     }
+}
+// C0 x0 + C1 x1 (plus) or C0 x0 - C1 x1, chosen at run time
+template <class P, int C0, int C1>
+BBS_HD Fe<P> fe_lin_pm(const Fe<P>& x0, const Fe<P>& x1, bool plus) {
+    if constexpr (P::W == 28) return r28::lin_pm<P, C0, C1>(x0, x1, plus);
+    else return fe_select<P>(plus, fe_lin<P, C0, C1, 0, 0>(x0, x1, x1, x1), fe_lin<P, C0, -C1, 0, 0>(x0, x1, x1, x1));
 }
 template <class P, int C0, int C1, int C2 = 0>
 BBS_HD Fe<P> fe_lin(const Fe<P>& x0, const Fe<P>& x1, const Fe<P>& x2) { return fe_lin<P, C0, C1, C2, 0>(x0, x1, x2, x2); }

@@ -333,7 +333,7 @@ BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     Fp2<C> t = d_coef<C>(L, sq, src);
     t = f2_sel<C>(L.m == 1, f2_mul_xi<C>(t), t);
     // odd lanes: 3 t + 2 g ; even lanes: 3 t - 2 g
-    return f2_sel<C>((L.m & 1) != 0, f2_lin<C, 3, 2>(t, g), f2_lin<C, 3, -2>(t, g));
+    return f2_lin_pm<C, 3, 2>(t, g, (L.m & 1) != 0);
 }
 
 template <class C, int K>

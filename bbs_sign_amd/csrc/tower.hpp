@@ -243,6 +243,11 @@ template <class C, int C0, int C1>
 BBS_HD Fp2<C> f2_lin(const Fp2<C>& x0, const Fp2<C>& x1) {
     return {fe_lin<FP, C0, C1>(x0.c0, x1.c0), fe_lin<FP, C0, C1>(x0.c1, x1.c1)};
 }
+// C0 x0 + C1 x1 (plus) or C0 x0 - C1 x1, the sign chosen at run time: one chain per component
+template <class C, int C0, int C1>
+BBS_HD Fp2<C> f2_lin_pm(const Fp2<C>& x0, const Fp2<C>& x1, bool plus) {
+    return {fe_lin_pm<FP, C0, C1>(x0.c0, x1.c0, plus), fe_lin_pm<FP, C0, C1>(x0.c1, x1.c1, plus)};
+}
 template <class C, int C0, int C1, int C2>
 BBS_HD Fp2<C> f2_lin(const Fp2<C>& x0, const Fp2<C>& x1, const Fp2<C>& x2) {
     return {fe_lin<FP, C0, C1, C2>(x0.c0, x1.c0, x2.c0), fe_lin<FP, C0, C1, C2>(x0.c1, x1.c1, x2.c1)};

@@ -294,6 +294,9 @@ int bbs_selftest_f12(bbs_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, u
 /* Host arithmetic self-test (no GPU): x^-1 in the base field (scalar_field = 0, fp_bytes LE) or the scalar field
  * (1, 32 bytes LE) by the safegcd inversion the kernels use and by the Fermat power x^(p-2). */
 int bbs_selftest_inv(int curve, int scalar_field, const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat);
+/* Host arithmetic self-test (no GPU): 3 x0 + 2 x1 (plus = 1) or 3 x0 - 2 x1 (plus = 0) in the base field (fp_bytes LE,
+ * canonical in and out) by the single reduction chain with a run-time sign that ends the cyclotomic square. */
+int bbs_selftest_lin_pm(int curve, int plus, const uint8_t* x0, const uint8_t* x1, uint8_t* out);
 /* Host arithmetic self-test (no GPU): the GLV split of a canonical scalar k (32 bytes LE) as the kernels compute it:
  * k = (+-k1) + (+-k2) * lambda mod r, k1 and k2 below 2^128 (16 bytes LE each), *neg = 1 for a negative half.
  * BLS12-381: lambda = x^2 - 1, k2 = floor(k / lambda), both halves non-negative; BN254: rounding against a short

@@ -187,3 +187,22 @@ def test_joint_multiplication(libs, cid, curve):
                 for q, x in zip(P, k):
                     want = c.g1_add(want, c.g1_mul(q, x))
                 assert out.tobytes() == rec(want), (glv, k)
+
+
+@pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
+def test_lin_pm(libs, cid, curve):
+    """3 x0 +- 2 x1 with the sign chosen at run time (field.hpp lin_pm: the last step of the cyclotomic square)."""
+    p = curve.p
+    fpb = curve.fp_bytes
+    rng = random.Random(5 + cid)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << (8 * fpb - 1)) % p]
+    vals = [(a, b) for a in edge for b in edge] + [(rng.randrange(p), rng.randrange(p)) for _ in range(300)]
+    for lib in libs:
+        for a, b in vals:
+            for plus in (0, 1):
+                xa = np.frombuffer(a.to_bytes(fpb, "little"), dtype=np.uint8).copy()
+                xb = np.frombuffer(b.to_bytes(fpb, "little"), dtype=np.uint8).copy()
+                out = np.zeros(fpb, dtype=np.uint8)
+                assert lib.bbs_selftest_lin_pm(cid, plus, _u8(xa), _u8(xb), _u8(out)) == 0
+                want = (3 * a + 2 * b) % p if plus else (3 * a - 2 * b) % p
+                assert int.from_bytes(out.tobytes(), "little") == want, (hex(a), hex(b), plus)
