@@ -5,9 +5,9 @@
 
 // Many independent batches are kept in flight, one HIP stream pair each.  The HIP runtime maps the streams of a
 // process onto 4 hardware queues unless told otherwise, and a long narrow kernel then blocks the streams sharing
-// its queue (measured on MI355X: 645k -> 780k proof_verify/s with 16 queues).  Takes effect only if this library
+// its queue (measured on MI355X: 645k -> 780k proof_verify/s; 14: DESIGN.md 5 rule 6).  Takes effect only if this library
 // is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
-__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "14", 0); }
 
 // =============================================================================================
 // C ABI

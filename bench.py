@@ -24,7 +24,7 @@ import os
 # streams of a process onto 4 hardware queues by default, so a long, narrow kernel (a batch's tail) blocks the
 # streams that share its queue; 16 queues let the batches overlap (measured: 645k -> 780k proof_verify/s).
 # Must be set before the first HIP call of the process (torch initialises HIP before the engine is loaded).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
 import argparse
 import json
 import os

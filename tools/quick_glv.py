@@ -1,7 +1,7 @@
 """A/B of bbs_ctx_set_points_in_subgroup on the bench workload: default and vouched jobs timed alternately
 (development aid; bench.py is the contract)."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import parity_cases as pc

@@ -1,6 +1,6 @@
 """Ad-hoc (GPU box): BASELINE config 5 on one GPU -- BN254 and BLS12-381 proof_verify batches in flight together."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_cases as pc

@@ -1,6 +1,6 @@
 """Does a job set built from recycled streams / buffers run as fast as a fresh one?  (development aid)"""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import parity_cases as pc
