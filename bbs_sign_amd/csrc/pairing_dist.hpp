@@ -408,17 +408,30 @@ __device__ __forceinline__ bool d_is_one(const Lane6& L, const Fp2<C>& g) {
     return all != 0;
 }
 
-// f^|x| (f cyclotomic)
+// f^|x| (f cyclotomic).  The running value must stay in registers across the 63 squarings.  Two things used to make
+// it a memory object for the whole loop, so that every squaring began with a scratch round trip (7 loads, wait, ...,
+// 7 stores): being the function's return slot, and being handed by reference to the non-inlined multiplication.
+// Hence the explicit output parameter and the copy `t`.
 template <class C>
-__device__ __attribute__((noinline)) Fp2<C> d_pow_xabs(const Lane6& L, const Fp2<C>& f) {
+__device__ __attribute__((noinline)) void d_pow_xabs_to(const Lane6& L, const Fp2<C>& f_in, Fp2<C>& out) {
+    const Fp2<C> f = f_in;
     Fp2<C> r = f;
     const uint64_t x = C::K::X_ABS;
     int top = 63;
     while (!((x >> top) & 1)) top--;
     for (int i = top - 1; i >= 0; i--) {
         r = d_cyclo_sqr<C>(L, r);
-        if ((x >> i) & 1) r = d_mul<C>(L, r, f);
+        if ((x >> i) & 1) {
+            const Fp2<C> t = r, h = f;
+            r = d_mul<C>(L, t, h);
+        }
     }
+    out = r;
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> d_pow_xabs(const Lane6& L, const Fp2<C>& f) {
+    Fp2<C> r;
+    d_pow_xabs_to<C>(L, f, r);
     return r;
 }
 template <class C>
