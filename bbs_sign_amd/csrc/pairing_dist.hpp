@@ -239,7 +239,8 @@ BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEnt
     // lx = nl * xP is the same on the six lanes of an item: each lane of a pair (m, m ^ 1) computes one of its two
     // components and fetches the other (one Fp product + 14 ds_bpermute instead of two products)
     const bool odd = (L.m & 1) != 0;
-    const Fp<C> mine = fe_mul<typename C::FpP>(fe_select<typename C::FpP>(odd, le.nl.c1, le.nl.c0), P.x);
+    // (inlined multiplier: the called one takes half of its operands on the stack -- a scratch round trip per line)
+    const Fp<C> mine = fe_mul_i<typename C::FpP>(fe_select<typename C::FpP>(odd, le.nl.c1, le.nl.c0), P.x);
     const Fp<C> other = fe_shfl<typename C::FpP>(mine, L.base + (L.m ^ 1));
     const Fp2<C> lx = {fe_select<typename C::FpP>(odd, other, mine), fe_select<typename C::FpP>(odd, mine, other)};
     F2Acc<C> acc;

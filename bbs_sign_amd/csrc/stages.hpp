@@ -1019,19 +1019,23 @@ struct PairDist {
         const bool skipB = g1a_is_inf<C>(Pb) | (cc->tab_bp2.q_is_identity != 0);
         Fp2<C> f = d_one<C>(L);
         if (!(skipA & skipB)) {
+            // the Miller accumulator is its own variable, never handed by reference to a non-inlined function: that
+            // would make it a memory object and put a scratch store / load of it around every step of the loop
+            Fp2<C> m = d_one<C>(L);
             int li = 0;
             const int nops = cc->sched.n_ops;
             for (int k = 0; k < nops; k++) {
                 if (cc->sched.op[k] == 0) {
-                    f = d_sqr<C>(L, f);
+                    m = d_sqr<C>(L, m);
                 } else {
-                    if (!skipA) f = d_mul_line<C>(L, f, cc->tab_pk.e[li], Pa);
-                    if (!skipB) f = d_mul_line<C>(L, f, cc->tab_bp2.e[li], Pb);
+                    if (!skipA) m = d_mul_line<C>(L, m, cc->tab_pk.e[li], Pa);
+                    if (!skipB) m = d_mul_line<C>(L, m, cc->tab_bp2.e[li], Pb);
                     li++;
                 }
             }
-            if constexpr (C::K::X_NEG) f = d_conj<C>(L, f);
-            f = d_final_exp<C>(L, f, &cc->frob[0][0][0][0]);
+            if constexpr (C::K::X_NEG) m = d_conj<C>(L, m);
+            const Fp2<C> mf = m;
+            f = d_final_exp<C>(L, mf, &cc->frob[0][0][0][0]);
         }
         const bool one = d_is_one<C>(L, f);
         if (L.m == 0) a.out[i] = one ? 1 : 0;
