@@ -564,7 +564,7 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k
     for (int s = 0; s < STEPS; s++) {
         G1Aff<C> q = qn;
         if (s + 1 < STEPS) qn = fetch(s + 1);
-        if (s & 1) q.x = fe_mul<FP>(q.x, beta);          // phi, applied after the next entry has been requested
+        if (s & 1) q.x = G1MUL<FP>(q.x, beta);          // phi, applied after the next entry has been requested
         const int rd = s >> 1;
         if ((s & 1) == 0 && rd >= 1 && rd <= 31) {
 #pragma unroll 1
@@ -642,7 +642,7 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
         for (int s = 0; s < STEPS; s++) {
             G1Aff<C> q = qn;
             if (s + 1 < STEPS) qn = fetch(s + 1);
-            if (s & 1) q.x = fe_mul<FP>(q.x, beta);      // phi (odd terms), applied after the next entry has been requested
+            if (s & 1) q.x = G1MUL<FP>(q.x, beta);      // phi (odd terms), applied after the next entry has been requested
             const int rd = s / 6;
             if (s == 6 * rd && rd >= 1 && rd <= 31) {
 #pragma unroll 1

@@ -42,12 +42,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue ceiling: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; every instruction of
 # this integer mix (v_mad_u64_u32 included) issues at that rate (tools/ubench/valu_int.hip, 0.5 G/s/SIMD)
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4
-# VALU wave-instructions per 4096-item launch, from rocprofv3 SQ_INSTS_VALU (profiles/r01_k_pmc.csv; measured at the
+# VALU wave-instructions per 4096-item launch, from rocprofv3 SQ_INSTS_VALU (profiles/r01_l_pmc.csv; measured at the
 # default --window-bits 20: other widths change the number of fixed-base additions and so pv_msm_parts' count)
 # FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (checked on PvScalars: 5984 KiB written
 # for 4096 x 36 scalars); FETCH_SIZE doubled per MI355X_MICROARCH.md (128-B requests tallied at 64 B)
-PMC = {"pairing_6lane": {"valu_insts": 7.482e8, "fetch_bytes": 2 * 2.0253e4 * 1024, "write_bytes": 6.132e4 * 1024},
-       "pv_msm_parts": {"valu_insts": 4.052e8, "fetch_bytes": 2 * 2.4986e5 * 1024, "write_bytes": 7.409e4 * 1024},
+PMC = {"pairing_6lane": {"valu_insts": 7.502e8, "fetch_bytes": 2 * 1.9274e4 * 1024, "write_bytes": 9.578e4 * 1024},
+       "pv_msm_parts": {"valu_insts": 4.052e8, "fetch_bytes": 2 * 2.5101e5 * 1024, "write_bytes": 7.38e4 * 1024},
        "pv_challenge": {"valu_insts": 1.126e7, "fetch_bytes": 2 * 6057 * 1024, "write_bytes": 6075 * 1024}}
 
 
@@ -390,14 +390,14 @@ def main():
                          "traffic": (pmc["fetch_bytes"] + pmc["write_bytes"]) * (n / 4096.0) if pmc else None,
                          "note": "algorithmic bytes/unit = %d (SURVEY 8d); kernel duration = HIP events with %d batches "
                                  "in flight; traffic = FETCH_SIZE(x2, gfx950) + WRITE_SIZE per launch from "
-                                 "profiles/r01_k_pmc.csv; the path is bound by integer VALU issue, not HBM "
+                                 "profiles/r01_l_pmc.csv; the path is bound by integer VALU issue, not HBM "
                                  "(see valu_issue and DESIGN.md)" % (ALG_BYTES_PER_PROOF_VERIFY, len(jobs))},
             # the binding resource: VALU wave-instructions issued per second vs the chip's issue ceiling
             "valu_issue": {"achieved_ginstr_s": valu_total * world * args.steps / dt / 1e9 / world,
                            "peak_ginstr_s": VALU_PEAK_GINSTR,
                            "frac": valu_total * args.steps / dt / 1e9 / VALU_PEAK_GINSTR,
                            "valu_wave_insts_per_step": valu_total,
-                           "source": "SQ_INSTS_VALU of pairing_6lane + pv_msm_parts + pv_challenge (profiles/r01_k_pmc.csv); peak = 1024 "
+                           "source": "SQ_INSTS_VALU of pairing_6lane + pv_msm_parts + pv_challenge (profiles/r01_l_pmc.csv); peak = 1024 "
                                      "SIMDs x 2.4 GHz / 4 cycles per wave-instruction"},
             # per kernel: launch duration (HIP events, this run), VALU wave-instructions and HBM bytes per launch (PMC)
             "kernels": [{"kernel": k, "ms_per_launch": stage_ms[k] / args.steps,
