@@ -308,15 +308,18 @@ BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U, bool flip = false) {     
 }
 
 // (the table lives where the caller says: AtPriv = the lane's private memory, AtHbm = a caller-provided buffer)
+// (result through `out`, the running point a plain local: as a named return value it is the caller's memory and every
+// doubling of the loop then starts with a scratch round trip -- DESIGN.md 5 rule 7b)
 template <class C, class W>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
+BBS_HD_NOINLINE void g1_mul_aff_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
 #ifdef BBS_G1_MUL_NAF
-    return g1_mul_aff_naf<C>(p, k);
+    out = g1_mul_aff_naf<C>(p, k);
+    return;
 #endif
     typename W::Tab tab;
     where.init(tab);
     Fp<C> zc;
-    if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
+    if (!g1_odd_table<C>(p, tab, zc)) { out = g1_mul_aff_naf<C>(p, k); return; }
     uint32_t u[8];
     g1_recode(k, u);
     const bool even = (k[0] & 1u) == 0;
@@ -338,6 +341,12 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_tab(const G1Aff<C>& p, const uint32_t* k, co
         r = g1j_add_aff<C>(r, q);
     }
     r.z = fe_mul<FP>(r.z, zc);
+    out = r;
+}
+template <class C, class W>
+BBS_HD G1Jac<C> g1_mul_aff_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
+    G1Jac<C> r;
+    g1_mul_aff_tab_to<C, W>(p, k, where, r);
     return r;
 }
 
@@ -537,11 +546,11 @@ BBS_HD Fp<C> glv_beta() {
 
 // k * P for P in the prime-order subgroup: two 128-bit halves on one doubling chain (see above)
 template <class C, class W>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
+BBS_HD_NOINLINE void g1_mul_aff_glv_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
     typename W::Tab tab;
     where.init(tab);
     Fp<C> zc;
-    if (!g1_odd_table<C>(p, tab, zc)) return g1_mul_aff_naf<C>(p, k);
+    if (!g1_odd_table<C>(p, tab, zc)) { out = g1_mul_aff_naf<C>(p, k); return; }
     uint32_t h[2][4], u[2][4];
     bool neg[2];
     glv_split<C>(k, h[0], h[1], neg[0], neg[1]);
@@ -573,6 +582,12 @@ BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k
         r = g1j_add_aff<C>(r, q);
     }
     r.z = fe_mul<FP>(r.z, zc);
+    out = r;
+}
+template <class C, class W>
+BBS_HD G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
+    G1Jac<C> r;
+    g1_mul_aff_glv_tab_to<C, W>(p, k, where, r);
     return r;
 }
 
