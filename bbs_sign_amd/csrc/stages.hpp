@@ -185,9 +185,11 @@ __host__ __device__ inline Fr<C> domain_from_header(const HashCtx& h, const uint
 // ---- multi-scalar multiplication parts --------------------------------------------------------
 // one chunk of the fixed-base sum: terms are (base k, window w) pairs, flattened index t = k*W + w,
 // chunk f of NFIX handles t in [f*T/NFIX, (f+1)*T/NFIX).
+// (result through `out`, the accumulator a plain local: where this function is not inlined, a named return value is
+// the caller's memory and every addition of the loop would start with a scratch round trip -- DESIGN.md 5 rule 7b)
 template <class C>
-__host__ __device__ inline G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
-                                                    int n_terms, int chunk) {
+__host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
+                                                   int n_terms, int chunk, G1Jac<C>& out) {
     constexpr int N = C::FpP::N;
     const int W = cc.n_windows, c = cc.win_bits;
     const int T = n_terms * W;
@@ -223,7 +225,13 @@ __host__ __device__ inline G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, cons
         hn = t + 1 < t1 ? fetch(t + 1, qn) : false;
         if (h) acc = g1j_add_aff<C>(acc, q);
     }
-    return acc;
+    out = acc;
+}
+template <class C>
+BBS_HD G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i, int n_terms, int chunk) {
+    G1Jac<C> r;
+    fixed_msm_chunk_to<C>(cc, fscal, n, i, n_terms, chunk, r);
+    return r;
 }
 
 // shared inversion for two Jacobian points -> affine (Montgomery trick), identities preserved
