@@ -402,13 +402,30 @@ static int run_fetch_free(bbs_job* job, int8_t* status) {
     return rc;
 }
 
+// upload (one asynchronous H2D copy + the ingest kernel) -> kernels -> asynchronous copy of the statuses to page-locked
+// memory; nothing waits for the device.  bbs_job_wait delivers the statuses to `status`.
+int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
+                                 const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
+                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
+                                 bbs_job** job_out) {
+    if (!status || !job_out) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = bbs_core_proof_verify_upload(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, &job);
+    if (rc) return rc;
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
 int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
                                 const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_core_proof_verify_upload(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, &job);
+    int rc = bbs_core_proof_verify_submit(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, status, &job);
     if (rc) return rc;
-    rc = run_fetch_free(job, status);
+    rc = job->wait();
     delete job;
     return rc;
 }

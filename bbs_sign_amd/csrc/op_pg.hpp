@@ -54,7 +54,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t rec = 2 * FPB + 32;
     auto job = std::unique_ptr<PgJob<C>>(new PgJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, 1);
+    job->status0.assign(n, ST_PENDING);
     job->undisclosed.resize(n);
     size_t rmax = 1;
     for (size_t i = 0; i < n; i++) rmax = std::max<size_t>(rmax, (size_t)(didx_off[i + 1] - didx_off[i]));

@@ -75,7 +75,7 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     if (ctx->use()) return BBS_E_HIP;
     Soa F, VP, VS;
     F.init(std::max<size_t>(nf, 1) * 8, n); VP.init(std::max<size_t>(nv, 1) * 2 * NC, n); VS.init(std::max<size_t>(nv, 1) * 8, n);
-    std::vector<int8_t> st0(n, 1);
+    std::vector<int8_t> st0(n, ST_PENDING);
     for (size_t i = 0; i < n; i++) {
         bool ok = true;
         for (size_t k = 0; k < nf; k++) ok &= pack_fe<R>(F, k * 8, i, fs + (i * nf + k) * 32);
@@ -100,6 +100,7 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
     std::vector<uint32_t> w((size_t)2 * NC * n);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
+    if (!statuses_final(status, n)) return BBS_E_STATE;
     for (size_t i = 0; i < n; i++) {
         if (status[i] == 1) unpack_words_le(w, n, 0, i, 2 * NC, out + i * 2 * FPB);
         else std::memset(out + i * 2 * FPB, 0, 2 * FPB);
@@ -119,7 +120,7 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
     if (ctx->use()) return BBS_E_HIP;
     Soa P, S;
     P.init(2 * NC, std::max<size_t>(n, 1)); S.init(8, std::max<size_t>(n, 1));
-    std::vector<int8_t> st0(std::max<size_t>(n, 1), 1);
+    std::vector<int8_t> st0(std::max<size_t>(n, 1), ST_PENDING);
     for (size_t i = 0; i < n; i++) {
         bool ok = pack_g1<C>(P, 0, i, pts + i * 2 * FPB);
         ok &= pack_fe<R>(S, 0, i, scal + i * 32);
@@ -145,6 +146,7 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
         return BBS_E_HIP;
     std::vector<uint32_t> w((size_t)2 * N);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
+    if (!statuses_final(status, n)) return BBS_E_STATE;
     G1Aff<C> r;
     for (int j = 0; j < N; j++) { r.x.v[j] = w[j]; r.y.v[j] = w[N + j]; }
     *out_inf = g1a_is_inf<C>(r) ? 1 : 0;
@@ -278,7 +280,7 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     if (ctx->use()) return BBS_E_HIP;
     Soa A, B;
     A.init(2 * NC, n); B.init(2 * NC, n);
-    std::vector<int8_t> st0(n, 1);
+    std::vector<int8_t> st0(n, ST_PENDING);
     for (size_t i = 0; i < n; i++) {
         bool ok = pack_g1<C>(A, 0, i, pa + i * 2 * FPB) & pack_g1<C>(B, 0, i, pb + i * 2 * FPB);
         if (!ok) st0[i] = BBS_ST_NONCANONICAL;
@@ -293,7 +295,7 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     PairPrep<C> pp{dA.as<uint32_t>(), dB.as<uint32_t>(), dAm.as<uint32_t>(), dBm.as<uint32_t>(), dSt.as<int8_t>(), n};
     PairArgs<C> a;
     a.n = n; a.cc = ctx->d_consts.template as<CtxConsts<C>>(); a.pa = dAm.as<uint32_t>(); a.pb = dBm.as<uint32_t>();
-    a.negate_b = 0; a.canonical = 0; a.gate_arr = dSt.as<int8_t>(); a.gate = 2; a.out = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
+    a.negate_b = 0; a.canonical = 0; a.gate_arr = dSt.as<int8_t>(); a.gate = ST_PAIRING; a.out = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
 #ifdef BBS_HOST_TWIN
     if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) || rt::launch<PairMiller<C>>(ctx->stream, a, n * 2) ||
         rt::launch<PairFinal<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
@@ -301,7 +303,8 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     if (rt::launch<PairPrep<C>>(ctx->stream, pp, n) ||
         rt::launch<PairDist<C>>(ctx->stream, a, ((n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64) || rt::sync(ctx->stream)) return BBS_E_HIP;
 #endif
-    return rt::d2h(status, dSt.p, n, ctx->stream) ? BBS_E_HIP : BBS_OK;
+    if (rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
+    return statuses_final(status, n) ? BBS_OK : BBS_E_STATE;
 }
 
 // GPU self-test of the lane-sliced Fp12: the reference result is computed by the SAME one-lane

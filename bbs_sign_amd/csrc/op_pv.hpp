@@ -10,7 +10,36 @@ struct PvJob : JobBase<C> {
     PvArgs<C> a{};
     PairArgs<C> pa{};
     PvFinishArgs fin{};
+    PvIngestArgs<C> ingest{};
     BvState<C> bv{};                  // batch verification only
+};
+
+// Ragged input arrays of one batch inside the staging image: offsets rebased to 0, sections 16-byte aligned.
+struct RaggedIn {
+    const uint64_t* off;      // n + 1 caller offsets, or nullptr (every item empty)
+    const uint8_t* data;
+    size_t elem;              // bytes per element
+    uint64_t total = 0;       // elements
+    size_t at_off = 0, at_data = 0;
+    // false: offsets decrease, or data missing
+    bool measure(size_t n) {
+        total = 0;
+        if (!off) return true;
+        for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+        total = off[n] - off[0];
+        return total == 0 || data != nullptr;
+    }
+    void place(size_t& cur, size_t n) {
+        at_off = cur; cur += ((n + 1) * 8 + 15) & ~(size_t)15;
+        at_data = cur; cur += ((size_t)total * elem + 4 + 15) & ~(size_t)15;
+    }
+    void fill(uint8_t* img, size_t n) const {
+        uint64_t* o = reinterpret_cast<uint64_t*>(img + at_off);
+        if (!off) { std::memset(o, 0, (n + 1) * 8); return; }
+        const uint64_t b = off[0];
+        for (size_t i = 0; i <= n; i++) o[i] = off[i] - b;
+        if (total) std::memcpy(img + at_data, data + b * elem, (size_t)total * elem);
+    }
 };
 
 template <class C>
@@ -21,7 +50,6 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     constexpr int N = C::FpP::N;        // internal limbs
     constexpr int NC = C::FpP::NC;      // canonical 32-bit words
     constexpr int FPB = 4 * NC;
-    using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!proofs_fixed || !commit_off || !dmsg_off || !didx_off))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
@@ -29,64 +57,39 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     const size_t rec = 6 * FPB + 128;
     auto job = std::unique_ptr<PvJob<C>>(new PvJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, 1);
-    size_t rmax = 1;
-    for (size_t i = 0; i < n; i++) rmax = std::max<size_t>(rmax, (size_t)(didx_off[i + 1] - didx_off[i]));
-    if (rmax > 0xFFFFFF) return BBS_E_ARG;
-    Soa pts, sc, slots, dmask, didx_s, rcount;
-    pts.init(3 * 2 * NC, n); sc.init(4 * 8, n); slots.init((size_t)std::max(L, 1) * 8, n);
-    dmask.init((size_t)(std::max(L, 1) + 31) / 32, n); didx_s.init(rmax, n); rcount.init(1, n);
-    std::vector<uint8_t> seen;
-    for (size_t i = 0; i < n; i++) {
-        int8_t& st = job->status0[i];
-        const size_t u = (size_t)(commit_off[i + 1] - commit_off[i]);
-        const size_t r = (size_t)(didx_off[i + 1] - didx_off[i]);
-        const size_t rm = (size_t)(dmsg_off[i + 1] - dmsg_off[i]);
-        const size_t l = u + r;
-        const uint64_t* idx = didx + didx_off[i];
-        // proof_verify.rs:139-150 (order of checks)
-        bool bad = false;
-        for (size_t k = 0; k < r; k++) if (idx[k] >= l) bad = true;
-        if (bad) { st = BBS_ST_INVALID_DISCLOSED_INDEX; continue; }
-        if (rm != r) { st = BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH; continue; }
-        if ((size_t)L != l) { st = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }
-        if (ctx->dst_too_long) { st = BBS_ST_PANIC_DST_TOO_LONG; continue; }
-        // duplicates make the undisclosed set larger than `commitments`: the reference indexes
-        // proof.commitments[i] out of bounds (proof_verify.rs:177-179) and panics
-        seen.assign(l, 0);
-        size_t distinct = 0;
-        for (size_t k = 0; k < r; k++) if (!seen[idx[k]]) { seen[idx[k]] = 1; distinct++; }
-        if (distinct != r) { st = BBS_ST_PANIC_INDEX_OUT_OF_BOUNDS; continue; }
-        const uint8_t* pf = proofs_fixed + i * rec;
-        bool ok = true;
-        for (int p = 0; p < 3; p++) ok &= pack_g1<C>(pts, (size_t)p * 2 * NC, i, pf + (size_t)p * 2 * FPB);
-        for (int k = 0; k < 4; k++) ok &= pack_fe<R>(sc, (size_t)k * 8, i, pf + 6 * FPB + 32 * k);
-        // slots: disclosed messages at their index, commitments at the sorted undisclosed indexes
-        for (size_t k = 0; k < r; k++) {
-            const size_t j = (size_t)idx[k];
-            ok &= pack_fe<R>(slots, j * 8, i, dmsgs + (dmsg_off[i] + k) * 32);
-            dmask.at(j >> 5, i) |= 1u << (j & 31);
-            didx_s.at(k, i) = (uint32_t)j;
-        }
-        size_t cu = 0;
-        for (size_t j = 0; j < l; j++) {
-            if (seen[j]) continue;
-            ok &= pack_fe<R>(slots, j * 8, i, commitments + (commit_off[i] + cu) * 32);
-            cu++;
-        }
-        rcount.at(0, i) = (uint32_t)r;
-        if (!ok) st = BBS_ST_NONCANONICAL;
-    }
-    BytePool hp, pp;
-    if (!hp.build(n, headers, hdr_off) || !pp.build(n, ph, ph_off)) return BBS_E_ARG;
+    // ---- the batch as one staging image in page-locked memory, one asynchronous copy; everything else (the
+    // reference's checks, range checks, unpacking, the SoA transposition) happens on the device: stage PvIngest
+    RaggedIn cm{commit_off, commitments, 32}, dm{dmsg_off, dmsgs, 32}, di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8},
+             hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
+    if (!cm.measure(n) || !dm.measure(n) || !di.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
+    if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
+    size_t cur = (n * rec + 15) & ~(size_t)15;
+    cm.place(cur, n); dm.place(cur, n); di.place(cur, n); hb.place(cur, n); pb.place(cur, n);
+    const size_t img_bytes = cur;
+    if (job->h_raw.alloc(img_bytes) || job->d_raw.alloc(img_bytes)) return BBS_E_NOMEM;
+    uint8_t* img = job->h_raw.template as<uint8_t>();
+    if (n) std::memcpy(img, proofs_fixed, n * rec);
+    cm.fill(img, n); dm.fill(img, n); di.fill(img, n); hb.fill(img, n); pb.fill(img, n);
+    if (rt::h2d_async(job->d_raw.p, img, img_bytes, job->stream())) return BBS_E_HIP;
+    const uint8_t* dimg = job->d_raw.template as<uint8_t>();
+    auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
+    auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };
     int rc = BBS_OK;
+    const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     PvArgs<C>& a = job->a;
-    a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
+    a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
-    a.pts = job->up(pts.soa(), rc); a.sc = job->up(sc.soa(), rc); a.slots = job->up(slots.soa(), rc);
-    a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
-    a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
-    a.ph_off = job->up(pp.off, rc); a.ph_len = job->up(pp.len, rc); a.ph_bytes = job->up(pp.bytes, rc);
+    uint32_t* pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * nn, rc);
+    uint32_t* sc = job->template scratch<uint32_t>((size_t)4 * 8 * nn, rc);
+    uint32_t* slots = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
+    uint32_t* dmask = job->template scratch<uint32_t>(((Lw + 31) / 32) * nn, rc);
+    uint32_t* didx_s = job->template scratch<uint32_t>(Lw * nn, rc);
+    uint32_t* rcount = job->template scratch<uint32_t>(nn, rc);
+    uint32_t* offs = job->template scratch<uint32_t>(4 * nn, rc);
+    if (rc) return rc;
+    a.pts = pts; a.sc = sc; a.slots = slots; a.dmask = dmask; a.didx = didx_s; a.rcount = rcount;
+    a.hdr_off = offs; a.hdr_len = offs + nn; a.ph_off = offs + 2 * nn; a.ph_len = offs + 3 * nn;
+    a.hdr_bytes = dimg + hb.at_data; a.ph_bytes = dimg + pb.at_data;
     a.dom = job->template scratch<uint32_t>(8 * n, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)PV_NPARTS * 3 * N * n, rc);
@@ -94,13 +97,24 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     a.fmiller = job->template scratch<uint32_t>((size_t)2 * 12 * N * n, rc);
     a.vtab = job->template scratch<uint32_t>((size_t)4 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);   // T1's three tables + the one of D * r3^
     if (rc) return rc;
-    if ((rc = job->finish_setup())) return rc;
+    if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
-    int8_t* pair_ok = job->template scratch<int8_t>(n ? n : 1, rc);
+    int8_t* pair_ok = job->template scratch<int8_t>(nn, rc);
     if (rc) return rc;
+    job->zero_on_reset.push_back({pair_ok, nn});          // a pairing lane that never ran reads as "product != 1"
+    PvIngestArgs<C>& ia = job->ingest;
+    ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0;
+    ia.rec = d32(0);
+    ia.cm_off = d64(cm.at_off); ia.dm_off = d64(dm.at_off); ia.di_off = d64(di.at_off);
+    ia.hdr_off64 = d64(hb.at_off); ia.ph_off64 = d64(pb.at_off);
+    ia.cm = d32(cm.at_data); ia.dm = d32(dm.at_data); ia.di = d64(di.at_data);
+    ia.pts = pts; ia.sc = sc; ia.slots = slots; ia.dmask = dmask; ia.didx = didx_s; ia.rcount = rcount;
+    ia.hdr_off = offs; ia.hdr_len = offs + nn; ia.ph_off = offs + 2 * nn; ia.ph_len = offs + 3 * nn;
+    ia.status0 = job->d_status0.template as<int8_t>();
+    if (rt::launch<PvIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
     PairArgs<C>& pa = job->pa;
     pa.n = n; pa.cc = a.cc; pa.pa = a.pts; pa.pb = a.pts + (size_t)2 * NC * n; pa.negate_b = 1;
-    pa.canonical = 1; pa.gate_arr = job->d_status0.template as<int8_t>(); pa.gate = 1; pa.out = pair_ok;
+    pa.canonical = 1; pa.gate_arr = job->d_status0.template as<int8_t>(); pa.gate = ST_PENDING; pa.out = pair_ok;
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
@@ -116,7 +130,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     } else {
         // batch verification (pippenger.hpp): one combined pairing check over the items whose challenge matched;
         // if it fails, the per-item kernel decides (its lanes return at once when the combined check passed)
-        pa.gate_arr = a.status; pa.gate = 2;                                     // fallback: items still pending
+        pa.gate_arr = a.status; pa.gate = ST_PAIRING;                            // fallback: items still pending
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         // a_bar, b_bar in Montgomery form, stored by PvMsmPart

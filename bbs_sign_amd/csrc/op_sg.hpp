@@ -37,7 +37,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     const int L = ctx->L;
     auto job = std::unique_ptr<SgJob<C>>(new SgJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, 1);
+    job->status0.assign(n, ST_PENDING);
     Soa sm;
     sm.init((size_t)std::max(L, 1) * 8, n);
     for (size_t i = 0; i < n; i++) {

@@ -26,7 +26,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t rec = 2 * FPB + 32;
     auto job = std::unique_ptr<VfJob<C>>(new VfJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, 1);
+    job->status0.assign(n, ST_PENDING);
     Soa sa, se, sm;
     sa.init(2 * NC, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
     for (size_t i = 0; i < n; i++) {
@@ -56,7 +56,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.status = job->d_status.template as<int8_t>();
     PairArgs<C>& pa = job->pa;
     pa.n = n; pa.cc = a.cc; pa.pa = a.aff; pa.pb = a.aff + (size_t)2 * N * n; pa.negate_b = 0;
-    pa.canonical = 0; pa.gate_arr = a.status; pa.gate = 2; pa.out = a.status; pa.fmiller = a.fmiller;
+    pa.canonical = 0; pa.gate_arr = a.status; pa.gate = ST_PAIRING; pa.out = a.status; pa.fmiller = a.fmiller;
     VfJob<C>* j = job.get();
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"vf_msm_parts", [j]() { return rt::launch<VfMsmPart<C>>(j->stream(), j->a, j->n * VF_NPARTS); }});

@@ -151,7 +151,7 @@ struct PipWindowSums {
 // ---- batch verification glue ------------------------------------------------------------------
 struct RlcArgs {
     size_t n, n_pad;
-    int8_t* status;           // 2 = challenge matched, pairing pending
+    int8_t* status;           // ST_PAIRING = challenge matched, pairing pending
     uint32_t seed[8];         // secret per-batch seed
     uint8_t* dig;             // [16][n_pad]
     const int8_t* batch_ok;   // [n_checks] results of the combined pairing checks
@@ -162,7 +162,7 @@ struct RlcArgs {
 struct RlcScalars {
     static __host__ __device__ void run(const RlcArgs& a, size_t i) {
         uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (a.status[i] == 2) {
+        if (a.status[i] == ST_PAIRING) {
             Sha256 s;
             sha256_init(s);
             for (int k = 0; k < 8; k++) sha256_word(s, a.seed[k]);
@@ -176,7 +176,7 @@ struct RlcScalars {
 // all combined checks passed: every pending item's pairing product is 1
 struct RlcApply {
     static __host__ __device__ void run(const RlcArgs& a, size_t i) {
-        if (a.status[i] != 2) return;
+        if (a.status[i] != ST_PAIRING) return;
         int ok = 1;
         for (int k = 0; k < a.n_checks; k++) ok &= (a.batch_ok[k] == 1);
         if (ok) a.status[i] = 1;
@@ -189,7 +189,7 @@ struct PipDigits {
     static __host__ __device__ void run(const PipDigitArgs& a, size_t i) {
         for (int w = 0; w < 32; w++) {
             const uint32_t l = a.scal[(size_t)(w >> 2) * a.n + i];
-            a.dig[(size_t)w * a.n_pad + i] = a.status[i] < 0 ? 0 : (uint8_t)(l >> (8 * (w & 3)));
+            a.dig[(size_t)w * a.n_pad + i] = a.status[i] != 1 ? 0 : (uint8_t)(l >> (8 * (w & 3)));
         }
     }
 };
@@ -200,9 +200,10 @@ struct PipPrep {
     const uint32_t* pts_c; uint32_t* pts; int8_t* status; size_t n;
     static __host__ __device__ void run(const PipPrep<C>& a, size_t i) {
         G1Aff<C> p = g1a_inf<C>();
-        if (a.status[i] >= 0) {
+        if (a.status[i] == ST_PENDING) {
             p = g1a_load_canon_to_mont<C>(a.pts_c, a.n, i);
             if (!g1a_on_curve<C>(p)) { a.status[i] = -41; p = g1a_inf<C>(); }
+            else a.status[i] = 1;
         }
         g1a_store_mont<C>(a.pts, a.n, i, p);
     }

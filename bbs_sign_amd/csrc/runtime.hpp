@@ -44,6 +44,10 @@ inline int h2d(void* d, const void* h, size_t b, Stream&) { if (b) std::memcpy(d
 inline int d2h(void* h, const void* d, size_t b, Stream&) { if (b) std::memcpy(h, d, b); return 0; }
 inline int dmemset(void* d, int v, size_t b, Stream&) { if (b) std::memset(d, v, b); return 0; }
 inline int d2d_async(void* d, const void* s, size_t b, Stream&) { if (b) std::memcpy(d, s, b); return 0; }
+inline int h2d_async(void* d, const void* h, size_t b, Stream&) { if (b) std::memcpy(d, h, b); return 0; }
+inline int d2h_async(void* h, const void* d, size_t b, Stream&) { if (b) std::memcpy(h, d, b); return 0; }
+inline int hmalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? 0 : -1; }
+inline void hfree(void* p, size_t) { std::free(p); }
 inline int sync(Stream&) { return 0; }
 struct Event { };
 inline int event_create(Event*) { return 0; }
@@ -87,6 +91,10 @@ struct Pools {
     std::map<hipStream_t, uint64_t> stream_index;
     uint64_t next_stream_index = 0;
     std::map<int, std::vector<hipEvent_t>> events;
+    // page-locked host staging buffers (one per batch: raw inputs in, statuses out), by size class; hipHostMalloc
+    // costs hundreds of microseconds, a batch call must not pay it
+    std::multimap<size_t, void*> pinned;
+    size_t pinned_bytes = 0;
     static Pools& get() { static Pools* p = new Pools(); return *p; }      // lives as long as the process
 };
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -129,6 +137,34 @@ inline int d2h(void* h, const void* d, size_t b, Stream& s) {
 inline int dmemset(void* d, int v, size_t b, Stream& s) { return (!b || hipMemsetAsync(d, v, b, s) == hipSuccess) ? 0 : -1; }
 inline int d2d_async(void* d, const void* s_, size_t b, Stream& s) {
     return (!b || hipMemcpyAsync(d, s_, b, hipMemcpyDeviceToDevice, s) == hipSuccess) ? 0 : -1;
+}
+// asynchronous copies from / to page-locked staging memory (hmalloc): the caller keeps the host buffer alive until the
+// stream has passed the copy
+inline int h2d_async(void* d, const void* h, size_t b, Stream& s) {
+    return (!b || hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, s) == hipSuccess) ? 0 : -1;
+}
+inline int d2h_async(void* h, const void* d, size_t b, Stream& s) {
+    return (!b || hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, s) == hipSuccess) ? 0 : -1;
+}
+constexpr size_t PINNED_POOL_MAX = (size_t)1 << 30;
+inline int hmalloc(void** p, size_t b) {
+    const size_t cls = size_class(b);
+    {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.pinned.find(cls);
+        if (it != P.pinned.end()) { *p = it->second; P.pinned.erase(it); P.pinned_bytes -= cls; return 0; }
+    }
+    return hipHostMalloc(p, cls, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+}
+inline void hfree(void* p, size_t b) {
+    const size_t cls = size_class(b);
+    {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.pinned_bytes + cls <= PINNED_POOL_MAX) { P.pinned.emplace(cls, p); P.pinned_bytes += cls; return; }
+    }
+    (void)hipHostFree(p);
 }
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 using Event = hipEvent_t;
@@ -212,6 +248,25 @@ struct DevBuf {
     int alloc(size_t b) { release(); bytes = b; dev = rt::current_device(); return rt::dmalloc(&p, b); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// page-locked host staging buffer with ownership
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    ~HostBuf() { release(); }
+    void release() { if (p) rt::hfree(p, bytes); p = nullptr; bytes = 0; }
+    int alloc(size_t b) { release(); bytes = b; return rt::hmalloc(&p, b); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// no internal state (stages.hpp ST_PENDING / ST_PAIRING) may leave the library: an item still in one was never decided
+inline bool statuses_final(const int8_t* st, size_t n) {
+    for (size_t i = 0; i < n; i++) if (st[i] == ST_PENDING || st[i] == ST_PAIRING) return false;
+    return true;
+}
 
 // =============================================================================================
 // host-side packing helpers
@@ -479,6 +534,11 @@ struct bbs_job {
     virtual int join_aux() = 0;                  // main stream waits for what the aux stream has issued
     virtual int reset() = 0;                     // restore the pre-run status so the job can run again
     virtual int fetch_status(int8_t*) = 0;
+    // submit form (bbs_core_*_submit): the statuses are copied to page-locked memory behind the last stage, and
+    // wait() hands them to the caller's buffer `deliver_to`
+    int8_t* deliver_to = nullptr;
+    virtual int enqueue_status_fetch() = 0;
+    virtual int deliver() = 0;
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
     virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }
     int run() {
@@ -492,14 +552,24 @@ struct bbs_job {
         }
         return BBS_OK;
     }
-    int wait() { return (use() || rt::sync(stream())) ? BBS_E_HIP : BBS_OK; }
+    int wait() {
+        if (use() || rt::sync(stream())) return BBS_E_HIP;
+        return deliver_to ? deliver() : BBS_OK;
+    }
 };
 
 template <class C>
 struct JobBase : bbs_job {
     Ctx<C>* ctx;
-    std::vector<int8_t> status0;     // host-validated initial status (1 placeholder = to compute)
+    std::vector<int8_t> status0;     // host-validated initial status (ST_PENDING = to compute)
     DevBuf d_status, d_status0;
+    HostBuf h_status;                // page-locked landing area of the submit form
+    // the batch as the caller handed it over: page-locked image (source of the ONE asynchronous H2D copy) and the same
+    // image on the device, which the ingest stage reads and where headers / presentation headers stay.  Members of
+    // this base so that they outlive the destructor's stream synchronisation.
+    HostBuf h_raw;
+    DevBuf d_raw;
+    std::vector<std::pair<void*, size_t>> zero_on_reset;   // device arrays cleared before every run (fail closed)
     std::vector<std::unique_ptr<DevBuf>> bufs;
     // every job owns its streams: independent jobs (batches) of one context overlap on the GPU
     rt::Stream main{}, aux{};
@@ -528,10 +598,25 @@ struct JobBase : bbs_job {
         return (rt::event_record(ev_join, aux) || rt::stream_wait(stream(), ev_join)) ? -1 : 0;
     }
     // device-to-device, asynchronous: back-to-back runs of one job never wait for the host
-    int reset() override { return rt::d2d_async(d_status.p, d_status0.p, n, stream()) ? BBS_E_HIP : BBS_OK; }
+    int reset() override {
+        if (rt::d2d_async(d_status.p, d_status0.p, n, stream())) return BBS_E_HIP;
+        for (auto& z : zero_on_reset) if (rt::dmemset(z.first, 0, z.second, stream())) return BBS_E_HIP;
+        return BBS_OK;
+    }
     int fetch_status(int8_t* out) override {
         if (use() || rt::sync(stream())) return BBS_E_HIP;
-        return rt::d2h(out, d_status.p, n, stream()) ? BBS_E_HIP : BBS_OK;
+        if (rt::d2h(out, d_status.p, n, stream())) return BBS_E_HIP;
+        return statuses_final(out, n) ? BBS_OK : BBS_E_STATE;
+    }
+    int enqueue_status_fetch() override {
+        if (!h_status.p && h_status.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        return rt::d2h_async(h_status.p, d_status.p, n, stream()) ? BBS_E_HIP : BBS_OK;
+    }
+    int deliver() override {                       // the stream has been synchronised
+        if (!h_status.p) return BBS_E_STATE;
+        if (!statuses_final(h_status.template as<int8_t>(), n)) return BBS_E_STATE;
+        if (n) std::memcpy(deliver_to, h_status.p, n);
+        return BBS_OK;
     }
     // upload a host vector, return device pointer (owned by the job)
     template <class T>
@@ -551,7 +636,14 @@ struct JobBase : bbs_job {
     }
     int finish_setup() {
         if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        if (rt::dmemset(d_status.p, (uint8_t)ST_PENDING, n, stream())) return BBS_E_HIP;     // a job never run has decided nothing
         if (rt::h2d(d_status0.p, status0.data(), n, stream())) return BBS_E_HIP;
+        return ctx->sync_consts();
+    }
+    // the initial statuses come from the device's ingest stage (no host validation pass, no synchronous copy)
+    int finish_setup_device() {
+        if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
+        if (rt::dmemset(d_status.p, (uint8_t)ST_PENDING, n, stream())) return BBS_E_HIP;
         return ctx->sync_consts();
     }
     template <class T>

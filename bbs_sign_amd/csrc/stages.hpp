@@ -32,6 +32,10 @@ namespace bbs {
 
 constexpr int NFIX = 8;          // fixed-base chunks per MSM (one lane each)
 constexpr int MAX_DST = 255;
+// Internal per-item states.  Neither is a value the C ABI may return: an item that no kernel has decided stays at one of
+// them and bbs_job_fetch_status / bbs_job_wait then fail with BBS_E_STATE instead of reporting Ok(true) (fail closed).
+constexpr int8_t ST_PENDING = -128;   // accepted by validation, nothing computed yet
+constexpr int8_t ST_PAIRING = -127;   // every check before the pairing passed: the pairing product decides
 #ifndef BBS_PAIR_WAVES
 #define BBS_PAIR_WAVES 1
 #endif
@@ -268,7 +272,7 @@ struct PvArgs {
     const uint32_t* rcount;   // [n]
     const uint32_t* hdr_off; const uint32_t* hdr_len; const uint8_t* hdr_bytes;
     const uint32_t* ph_off;  const uint32_t* ph_len;  const uint8_t* ph_bytes;
-    int8_t* status;           // [n]; < 0 preset by host validation; 2 = pairing pending
+    int8_t* status;           // [n]; ST_PENDING = to compute, ST_PAIRING = pairing pending, else final
     // intermediates
     uint32_t* dom;            // [8][n] domain, Montgomery
     uint32_t* fscal;          // [L+2][8][n] canonical fixed-base scalars
@@ -278,12 +282,106 @@ struct PvArgs {
     uint32_t* vtab;           // [4][G1_TAB][2N][n] window tables: three of the joint multiplication, one of D * r3^ (g1.hpp)
 };
 
+// stage 0 (lane per item, once per upload): the work the reference does before any arithmetic, on the raw batch as the
+// C ABI receives it (item-major records, ragged arrays with 64-bit offsets) -- proof_verify_init's checks in the
+// reference's order (src/proof_verify.rs:139-150), the duplicate test behind its out-of-bounds panic (:177-179), range
+// checks of every scalar and coordinate (arkworks' types cannot hold a non-canonical value), and the transposition
+// into the SoA arrays the later stages read.  Reads are strided by the record size, writes are coalesced.
+template <class C>
+struct PvIngestArgs {
+    size_t n;
+    int L, dst_too_long;
+    const uint32_t* rec;                  // n records a_bar || b_bar || d || e^ || r1^ || r3^ || c, little-endian words
+    const uint64_t *cm_off, *dm_off, *di_off, *hdr_off64, *ph_off64;   // n + 1 entries each, rebased to start at 0
+    const uint32_t* cm;                   // commitments, 8 words each
+    const uint32_t* dm;                   // disclosed messages, 8 words each
+    const uint64_t* di;                   // disclosed indexes
+    uint32_t *pts, *sc, *slots, *dmask, *didx, *rcount, *hdr_off, *hdr_len, *ph_off, *ph_len;   // PvArgs arrays
+    int8_t* status0;                      // ST_PENDING or the reference's Err / panic / a non-canonical input
+};
+
+template <class C>
+struct PvIngest {
+    static __host__ __device__ void run(const PvIngestArgs<C>& a, size_t i) {
+        using P = typename C::FpP;
+        using R = typename C::FrP;
+        constexpr int NC = P::NC;
+        constexpr int RECW = 6 * NC + 32;
+        const size_t n = a.n;
+        a.hdr_off[i] = (uint32_t)a.hdr_off64[i];
+        a.hdr_len[i] = (uint32_t)(a.hdr_off64[i + 1] - a.hdr_off64[i]);
+        a.ph_off[i] = (uint32_t)a.ph_off64[i];
+        a.ph_len[i] = (uint32_t)(a.ph_off64[i + 1] - a.ph_off64[i]);
+        const uint64_t u = a.cm_off[i + 1] - a.cm_off[i], r = a.di_off[i + 1] - a.di_off[i], rm = a.dm_off[i + 1] - a.dm_off[i];
+        const uint64_t l = u + r;
+        const uint64_t* idx = a.di + a.di_off[i];
+        const int MW = ((a.L > 1 ? a.L : 1) + 31) / 32;
+        for (int w = 0; w < MW; w++) a.dmask[(size_t)w * n + i] = 0;
+        a.rcount[i] = 0;
+        int8_t st = ST_PENDING;
+        bool bad = false;
+        for (uint64_t k = 0; k < r; k++) bad |= idx[k] >= l;
+        if (bad) st = -3;                                      // InvalidDisclosedIndex
+        else if (rm != r) st = -6;                             // InvalidIndicesAndMessagesLength
+        else if (l != (uint64_t)a.L) st = -1;                  // InvalidMessageAndGeneratorsLength
+        else if (a.dst_too_long) st = -23;
+        else {
+            // duplicates make the undisclosed set larger than `commitments`: the reference indexes
+            // proof.commitments[i] out of bounds (proof_verify.rs:177-179) and panics
+            uint64_t distinct = 0;
+            for (uint64_t k = 0; k < r; k++) {
+                const size_t j = (size_t)idx[k];
+                uint32_t* wp = a.dmask + (j >> 5) * n + i;
+                const uint32_t w = *wp, bit = 1u << (j & 31);
+                if (!(w & bit)) { *wp = w | bit; distinct++; }
+            }
+            if (distinct != r) st = -22;
+        }
+        if (st != ST_PENDING) { a.status0[i] = st; return; }
+        bool ok = true;
+        const uint32_t* pf = a.rec + i * (size_t)RECW;
+        for (int c = 0; c < 6; c++) {                          // six coordinates
+            uint32_t w[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) w[k] = pf[c * NC + k];
+            ok &= limbs_lt_mod<P>(w);
+            soa_st<NC>(a.pts + (size_t)c * NC * n, n, i, w);
+        }
+        for (int c = 0; c < 4; c++) {
+            uint32_t w[8];
+            soa_ld<8>(pf + 6 * NC + 8 * c, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.sc + (size_t)c * 8 * n, n, i, w);
+        }
+        // slots: disclosed messages at their index, commitments at the sorted undisclosed indexes
+        for (uint64_t k = 0; k < r; k++) {
+            const size_t j = (size_t)idx[k];
+            uint32_t w[8];
+            soa_ld<8>(a.dm + (a.dm_off[i] + k) * 8, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.slots + j * 8 * n, n, i, w);
+            a.didx[(size_t)k * n + i] = (uint32_t)j;
+        }
+        uint64_t cu = 0;
+        for (size_t j = 0; j < (size_t)l; j++) {
+            if ((a.dmask[(j >> 5) * n + i] >> (j & 31)) & 1u) continue;
+            uint32_t w[8];
+            soa_ld<8>(a.cm + (a.cm_off[i] + cu) * 8, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.slots + j * 8 * n, n, i, w);
+            cu++;
+        }
+        a.rcount[i] = (uint32_t)r;
+        a.status0[i] = ok ? ST_PENDING : (int8_t)-40;
+    }
+};
+
 // stage 1 (lane per item): domain, fixed-base scalars
 template <class C>
 struct PvScalars {
     static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
         using R = typename C::FrP;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         const size_t n = a.n;
         Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
         soa_st<8>(a.dom, n, i, dom.v);
@@ -312,7 +410,7 @@ struct PvMsmPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         if (part == 0) {
             // T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain
@@ -349,7 +447,7 @@ struct PvChallenge {
     static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> t1 = part(0);
         G1Jac<C> t2 = part(1);
@@ -381,7 +479,7 @@ struct PvChallenge {
         Fr<C> chal = fe_to_canonical<typename C::FrP>(fr_from_okm<C>(okm));
         Fr<C> c = fr_load_canon<C>(a.sc + (size_t)3 * 8 * n, n, i);
         // proof_verify.rs:108-110: mismatch -> Ok(false) before any pairing
-        a.status[i] = fe_eq<typename C::FrP>(chal, c) ? 2 : 0;
+        a.status[i] = fe_eq<typename C::FrP>(chal, c) ? ST_PAIRING : (int8_t)0;
     }
 };
 
@@ -411,7 +509,7 @@ BBS_HD G1Aff<C> pair_load_point(const PairArgs<C>& a, const uint32_t* base, size
 struct PvFinishArgs { size_t n; int8_t* status; const int8_t* pair_ok; };
 struct PvFinish {
     static __host__ __device__ void run(const PvFinishArgs& a, size_t i) {
-        if (a.status[i] == 2) a.status[i] = a.pair_ok[i];
+        if (a.status[i] == ST_PAIRING) a.status[i] = a.pair_ok[i] == 1 ? 1 : 0;
     }
 };
 
@@ -580,7 +678,7 @@ template <class C>
 struct VfScalars {
     static __host__ __device__ void run(const VfArgs<C>& a, size_t i) {
         using R = typename C::FrP;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         const size_t n = a.n;
         Fr<C> dom = fe_to_canonical<R>(domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]));
         Fr<C> one = fe_zero<R>();
@@ -603,7 +701,7 @@ struct VfMsmPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         if (part == 0) {
             G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
@@ -623,13 +721,13 @@ struct VfCombine {
     static __host__ __device__ void run(const VfArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> b = part(1);
         for (int f = 1; f < NFIX; f++) b = g1j_add<C>(b, part(1 + f));
         G1Jac<C> x = g1j_add<C>(part(0), g1j_neg<C>(b));          // e*A - B
         g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, g1j_to_aff<C>(x));
-        a.status[i] = 2;
+        a.status[i] = ST_PAIRING;
     }
 };
 
@@ -655,7 +753,7 @@ template <class C>
 struct SgScalars {
     static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
         using R = typename C::FrP;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         const size_t n = a.n;
         Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
         // e = hash_to_scalar(sk || m_1 .. m_L || domain)   (sign.rs:90-118)
@@ -697,7 +795,7 @@ struct SgMsmPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         g1j_store<C>(a.partials + (size_t)part * 3 * N * n, n, i,
                      fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part));
     }
@@ -708,7 +806,7 @@ struct SgCombine {
     static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_load<C>(a.partials, n, i);
         for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)f * 3 * N * n, n, i));
         g1a_store_canon<C>(a.out_a, n, i, g1j_to_aff<C>(acc));
@@ -757,7 +855,7 @@ template <class C>
 struct PgScalars {
     static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
         using R = typename C::FrP;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         const size_t n = a.n;
         Fr<C> r2c = fr_load_canon<C>(a.rnd5 + (size_t)1 * 8 * n, n, i);
         Fr<C> dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
@@ -806,7 +904,7 @@ struct PgBPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         g1j_store<C>(a.bpart + (size_t)part * 3 * N * n, n, i,
                      fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part));
     }
@@ -817,7 +915,7 @@ struct PgBCombine {
     static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_load<C>(a.bpart, n, i);
         for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.bpart + (size_t)f * 3 * N * n, n, i));
         g1a_store_mont<C>(a.baff, n, i, g1j_to_aff<C>(acc));
@@ -835,7 +933,7 @@ struct PgMsmPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         if (part < PG_NVAR) {
             G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part < 4 ? 0 : 1) * 2 * N * n, n, i);
@@ -854,7 +952,7 @@ struct PgFinalize {
         using R = typename C::FrP;
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> pj[5];
         pj[0] = part(4);                                              // Abar
@@ -961,7 +1059,7 @@ struct MsmPart {
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         if (part < a.n_var) {
             G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * C::FpP::NC * n, n, i);
@@ -980,7 +1078,7 @@ struct MsmCombine {
     static __host__ __device__ void run(const MsmArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        if (a.status[i] < 0) return;
+        if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_inf<C>();
         for (int p = 0; p < a.n_var + NFIX; p++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i));
         g1a_store_canon<C>(a.out, n, i, g1j_to_aff<C>(acc));
@@ -993,12 +1091,12 @@ template <class C>
 struct PairPrep {
     const uint32_t* pa_c; const uint32_t* pb_c; uint32_t* pa; uint32_t* pb; int8_t* status; size_t n;
     static __host__ __device__ void run(const PairPrep<C>& a, size_t i) {
-        if (a.status[i] < 0) return;     // flagged by host validation
+        if (a.status[i] != ST_PENDING) return;     // flagged by validation
         G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pa_c, a.n, i), q = g1a_load_canon_to_mont<C>(a.pb_c, a.n, i);
         if (!g1a_on_curve<C>(p) || !g1a_on_curve<C>(q)) { a.status[i] = -41; return; }
         g1a_store_mont<C>(a.pa, a.n, i, p);
         g1a_store_mont<C>(a.pb, a.n, i, q);
-        a.status[i] = 2;
+        a.status[i] = ST_PAIRING;
     }
 };
 

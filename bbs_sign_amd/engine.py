@@ -251,6 +251,21 @@ class Engine:
         self._chk(self.lib.bbs_core_proof_verify_upload(self.h, n, *args, ctypes.byref(j)), "bbs_core_proof_verify_upload")
         return Job(self, j, n)
 
+    def core_proof_verify_submit(self, proofs, disclosed_msgs, disclosed_idx, headers=None, phs=None) -> "Job":
+        """bbs_core_proof_verify_submit: everything enqueued, nothing waited for; ``job.wait()`` then ``job.result``."""
+        n, keep, args = self._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
+        return self.submit_packed(n, args)
+
+    def submit_packed(self, n, args) -> "Job":
+        """The same from already packed ctypes arguments (``_pv_inputs``): the per-batch host work of a serving loop."""
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_proof_verify_submit(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)),
+                  "bbs_core_proof_verify_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        return job
+
     def core_verify_batch(self, signatures, messages, headers=None) -> np.ndarray:
         """core_verify (src/verify.rs:53-93) over a batch."""
         n = len(signatures)
@@ -487,6 +502,7 @@ class Job:
     def __init__(self, eng: Engine, handle, n: int):
         self.eng, self.h, self.n = eng, handle, n
         self.total_msgs = 0
+        self.result = None          # submit form: the statuses, valid after wait()
 
     def run(self):
         Engine._chk(self.eng.lib.bbs_job_run(self.h), "bbs_job_run")

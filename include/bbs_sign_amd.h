@@ -18,6 +18,8 @@
  * Per-item status (int8): mirrors the reference's Result<bool|T, Error>:
  *     1  Ok(true) / Ok(value)        0  Ok(false)
  *   < 0  the Err variant, a reference panic, or an input the reference's types cannot hold.
+ * -128 and -127 are internal "not decided yet" states: the library never returns them -- a fetch that finds one
+ * fails with BBS_E_STATE instead (an item no kernel decided must not read as Ok(true)).
  * Function return: 0 on success, BBS_E_* on a batch-level failure (nothing was computed).
  */
 #ifndef BBS_SIGN_AMD_H
@@ -63,7 +65,7 @@ extern "C" {
 #define BBS_OK 0
 #define BBS_E_ARG (-100)
 #define BBS_E_HIP (-101)
-#define BBS_E_STATE (-102)       /* generators / public key / secret key not set */
+#define BBS_E_STATE (-102)       /* generators / public key / secret key not set; or an item left undecided */
 #define BBS_E_PUBLIC_KEY (-103)  /* public key not on the twist or not of order r */
 #define BBS_E_NO_DEVICE (-104)
 #define BBS_E_NOMEM (-105)
@@ -148,6 +150,20 @@ int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* proofs_fi
                                 const uint64_t* disclosed_idx, const uint64_t* didx_off,
                                 const uint8_t* headers, const uint64_t* hdr_off,
                                 const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
+
+/* Asynchronous form of bbs_core_proof_verify_batch, for a stream of batches from ONE submitting thread per GPU: the
+ * inputs are staged in page-locked memory (the caller's input buffers may be reused as soon as the call returns), then
+ * ONE host-to-device copy, the validation / unpacking kernel (the reference's checks of src/proof_verify.rs:139-150 and
+ * the range checks run on the device), the verification kernels and the copy of the statuses back are enqueued; the
+ * call returns without waiting for the device, so several submitted batches are in flight together.
+ * bbs_job_wait(job) blocks until `status` (n entries; must stay valid until then) has been written -- it returns
+ * BBS_E_STATE, and writes nothing, if any item was left undecided (fail closed); then bbs_job_free(job). */
+int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* proofs_fixed,
+                                 const uint8_t* commitments, const uint64_t* commit_off,
+                                 const uint8_t* disclosed_msgs, const uint64_t* dmsg_off,
+                                 const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                 const uint8_t* headers, const uint64_t* hdr_off,
+                                 const uint8_t* ph, const uint64_t* ph_off, int8_t* status, bbs_job** job_out);
 
 /* core_verify (src/verify.rs:53-93).  signatures: n records  A (G1 affine) || e (scalar). */
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
