@@ -61,6 +61,8 @@ SIGNATURES = {
     "bbs_job_run_timed": (ci, [vp, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
     "bbs_job_stage_name": (ctypes.c_char_p, [vp, ci]),
     "bbs_jobs_run_timed": (ci, [ctypes.POINTER(vp), ci, ci, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
+    "bbs_ctx_set_stage_timing": (ci, [vp, ci]),
+    "bbs_job_stage_times": (ci, [vp, c_f32p, c_f32p, ci, ctypes.POINTER(ci)]),
     "bbs_hash_to_scalar_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, sz, c_u8p]),
     "bbs_g1_msm_batch": (ci, [vp, sz, c_u8p, sz, c_u8p, c_u8p, sz, c_u8p, c_i8p]),
     "bbs_g1_msm_pippenger": (ci, [vp, sz, c_u8p, c_u8p, c_u8p, ctypes.POINTER(ci), c_i8p]),

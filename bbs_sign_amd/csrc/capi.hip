@@ -310,28 +310,11 @@ int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms,
     if (job->use()) return BBS_E_HIP;
     const int ns = (int)job->stages.size();
     if (n_stages) *n_stages = ns;
-    // per rep: one event before the first stage, then a (start, stop) pair around every stage, each
-    // recorded on the stream that stage is launched on; read back after one synchronisation
     const size_t per_rep = 1 + 2 * (size_t)ns;
     rt::EventList ev((size_t)reps * per_rep);
     if (rt::sync(job->stream())) return BBS_E_HIP;
-    bool any_aux = false;
-    for (int r = 0; r < reps; r++) {
-        if (job->reset()) return BBS_E_HIP;
-        if (ev.record(job->stream())) return BBS_E_HIP;
-        bool forked = false;
-        for (int k = 0; k < ns; k++) {
-            auto& s = job->stages[k];
-            if (s.aux && !forked) { if (job->fork_aux()) return BBS_E_HIP; forked = true; any_aux = true; }
-            if (s.join && forked) { if (job->join_aux()) return BBS_E_HIP; }
-            rt::Stream& st = s.aux ? job->stream_aux() : job->stream();
-            if (ev.record(st)) return BBS_E_HIP;
-            if (s.launch()) return BBS_E_HIP;
-            if (ev.record(st)) return BBS_E_HIP;
-        }
-    }
-    if (ev.finish(job->stream())) return BBS_E_HIP;
-    if (any_aux && rt::sync(job->stream_aux())) return BBS_E_HIP;
+    for (int r = 0; r < reps; r++) if (job->run_recorded(&ev)) return BBS_E_HIP;
+    if (ev.finish(job->stream()) || rt::sync(job->stream_aux())) return BBS_E_HIP;
     // the last stage of a rep is on the main stream: total = first event .. last stop
     if (total_ms) *total_ms = ev.ms(0, (size_t)reps * per_rep - 1);
     if (kernel_ms) {
@@ -358,21 +341,7 @@ int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, fl
     const size_t per_step = 1 + 2 * (size_t)ns;
     rt::EventList ev((size_t)steps * per_step);
     for (int j = 0; j < njobs; j++) if (rt::sync(jobs[j]->stream())) return BBS_E_HIP;
-    for (int k = 0; k < steps; k++) {
-        bbs_job* job = jobs[k % njobs];
-        if (job->reset()) return BBS_E_HIP;
-        if (ev.record(job->stream())) return BBS_E_HIP;
-        bool forked = false;
-        for (int s = 0; s < ns; s++) {
-            auto& st = job->stages[s];
-            if (st.aux && !forked) { if (job->fork_aux()) return BBS_E_HIP; forked = true; }
-            if (st.join && forked) { if (job->join_aux()) return BBS_E_HIP; }
-            rt::Stream& sm = st.aux ? job->stream_aux() : job->stream();
-            if (ev.record(sm)) return BBS_E_HIP;
-            if (st.launch()) return BBS_E_HIP;
-            if (ev.record(sm)) return BBS_E_HIP;
-        }
-    }
+    for (int k = 0; k < steps; k++) if (jobs[k % njobs]->run_recorded(&ev)) return BBS_E_HIP;
     for (int j = 0; j < njobs; j++) {
         if (rt::sync(jobs[j]->stream())) return BBS_E_HIP;
         if (rt::sync(jobs[j]->stream_aux())) return BBS_E_HIP;
@@ -394,6 +363,14 @@ int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, fl
         }
     }
     return BBS_OK;
+}
+int bbs_ctx_set_stage_timing(bbs_ctx* ctx, int enabled) {
+    if (!ctx) return BBS_E_ARG;
+    ctx->stage_timing = enabled != 0;
+    return BBS_OK;
+}
+int bbs_job_stage_times(bbs_job* job, float* total_ms, float* kernel_ms, int cap, int* n_stages) {
+    return job ? job->stage_times(total_ms, kernel_ms, cap, n_stages) : BBS_E_ARG;
 }
 
 static int run_fetch_free(bbs_job* job, int8_t* status) {

@@ -62,8 +62,9 @@ inline int launch(Stream&, const A& a, size_t nthreads) {
 // a list of time stamps recorded on the stream; read back after one synchronisation
 struct EventList {
     std::vector<std::chrono::steady_clock::time_point> t;
+    size_t used = 0;
     explicit EventList(size_t) {}
-    int record(Stream&) { t.push_back(std::chrono::steady_clock::now()); return 0; }
+    int record(Stream&) { t.push_back(std::chrono::steady_clock::now()); used++; return 0; }
     int finish(Stream&) { return 0; }
     float ms(size_t a, size_t b) { return std::chrono::duration<float, std::milli>(t[b] - t[a]).count(); }
 };
@@ -95,6 +96,7 @@ struct Pools {
     // costs hundreds of microseconds, a batch call must not pay it
     std::multimap<size_t, void*> pinned;
     size_t pinned_bytes = 0;
+    std::map<int, std::vector<hipEvent_t>> timing_events;      // events WITH timing (stage timers), recycled
     static Pools& get() { static Pools* p = new Pools(); return *p; }      // lives as long as the process
 };
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -226,8 +228,22 @@ inline int launch(Stream& s, const A& a, size_t nthreads) {
 struct EventList {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
-    explicit EventList(size_t cap) : ev(cap, nullptr) { for (auto& e : ev) (void)hipEventCreate(&e); }
-    ~EventList() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    int dev = 0;
+    explicit EventList(size_t cap) : ev(cap, nullptr), dev(current_device()) {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.timing_events[dev];
+        for (auto& e : ev) {
+            if (!v.empty()) { e = v.back(); v.pop_back(); }
+            else (void)hipEventCreate(&e);
+        }
+    }
+    ~EventList() {
+        Pools& P = Pools::get();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.timing_events[dev];
+        for (auto& e : ev) if (e) { if (v.size() < 4096) v.push_back(e); else (void)hipEventDestroy(e); }
+    }
     int record(Stream& s) { return (used < ev.size() && hipEventRecord(ev[used++], s) == hipSuccess) ? 0 : -1; }
     int finish(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
     float ms(size_t a, size_t b) { float m = 0; (void)hipEventElapsedTime(&m, ev[a], ev[b]); return m; }
@@ -352,6 +368,7 @@ struct BytePool {
 struct IJob;
 struct bbs_ctx {
     int curve = 0;
+    bool stage_timing = false;       // jobs created from now on record HIP events around every stage of every run
     virtual ~bbs_ctx() {}
 };
 
@@ -541,15 +558,37 @@ struct bbs_job {
     virtual int deliver() = 0;
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
     virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }
-    int run() {
-        if (use()) return BBS_E_HIP;
+    // One pass over the stages.  ev != nullptr: one event before the first stage, then a (start, stop) pair around
+    // every stage, each recorded on the stream that stage is launched on (1 + 2 * stages events per pass).
+    int run_recorded(rt::EventList* ev) {
         if (reset()) return BBS_E_HIP;
+        if (ev && ev->record(stream())) return BBS_E_HIP;
         bool forked = false;
         for (auto& s : stages) {
             if (s.aux && !forked) { if (fork_aux()) return BBS_E_HIP; forked = true; }
             if (s.join && forked) { if (join_aux()) return BBS_E_HIP; }
+            rt::Stream& st = s.aux ? stream_aux() : stream();
+            if (ev && ev->record(st)) return BBS_E_HIP;
             if (s.launch()) return BBS_E_HIP;
+            if (ev && ev->record(st)) return BBS_E_HIP;
         }
+        return BBS_OK;
+    }
+    bool timed = false;                          // set from bbs_ctx::stage_timing when the job is created
+    std::unique_ptr<rt::EventList> tev;          // events of the LAST run (timed jobs)
+    int run() {
+        if (use()) return BBS_E_HIP;
+        if (timed) tev.reset(new rt::EventList(1 + 2 * stages.size()));
+        return run_recorded(timed ? tev.get() : nullptr);
+    }
+    // stage durations of the last run of a timed job; call after wait()
+    int stage_times(float* total_ms, float* kernel_ms, int cap, int* n_stages) {
+        const int ns = (int)stages.size();
+        if (n_stages) *n_stages = ns;
+        if (!timed || !tev || tev->used != 1 + 2 * (size_t)ns) return BBS_E_STATE;
+        if (use() || rt::sync(stream()) || rt::sync(stream_aux())) return BBS_E_HIP;
+        if (total_ms) *total_ms = tev->ms(0, 2 * (size_t)ns);
+        for (int k = 0; kernel_ms && k < ns && k < cap; k++) kernel_ms[k] = tev->ms(1 + 2 * (size_t)k, 2 + 2 * (size_t)k);
         return BBS_OK;
     }
     int wait() {
@@ -575,7 +614,7 @@ struct JobBase : bbs_job {
     rt::Stream main{}, aux{};
     rt::Event ev_fork{}, ev_join{};
     bool main_ready = false, aux_ready = false;
-    explicit JobBase(Ctx<C>* c) : ctx(c) { main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); }
+    explicit JobBase(Ctx<C>* c) : ctx(c) { main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); timed = c->stage_timing; }
     ~JobBase() override {
         (void)ctx->use();            // streams and buffers go back to this device's pools
         if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }

@@ -203,6 +203,10 @@ class Engine:
         self._chk(self.lib.bbs_ctx_set_batch_verification(self.h, 1 if enabled else 0, _u8(buf) if buf is not None else None),
                   "bbs_ctx_set_batch_verification")
 
+    def set_stage_timing(self, enabled: bool):
+        """bbs_ctx_set_stage_timing: jobs created afterwards record HIP events around every stage (Job.stage_times)."""
+        self._chk(self.lib.bbs_ctx_set_stage_timing(self.h, 1 if enabled else 0), "bbs_ctx_set_stage_timing")
+
     def public_key(self):
         """sk_to_pk (src/key_gen.rs:83-90) of the secret key set on this context."""
         out = np.zeros(4 * self.fpb, dtype=np.uint8)
@@ -538,6 +542,15 @@ class Job:
                                                    ctypes.byref(ns)), "bbs_job_run_timed")
         names = [self.eng.lib.bbs_job_stage_name(self.h, k).decode() for k in range(ns.value)]
         return tot.value, ({names[k]: ks[k] for k in range(ns.value)} if per_stage else {})
+
+    def stage_times(self):
+        """-> (total_ms, {stage: ms}) of the last run of a job created under Engine.set_stage_timing(True); after wait()."""
+        tot = ctypes.c_float(0)
+        ks = (ctypes.c_float * 16)()
+        ns = ctypes.c_int(0)
+        Engine._chk(self.eng.lib.bbs_job_stage_times(self.h, ctypes.byref(tot), ks, 16, ctypes.byref(ns)), "bbs_job_stage_times")
+        names = [self.eng.lib.bbs_job_stage_name(self.h, k).decode() for k in range(ns.value)]
+        return tot.value, {names[k]: ks[k] for k in range(ns.value)}
 
     @staticmethod
     def run_many_timed(jobs, steps: int):

@@ -1,0 +1,105 @@
+"""core_proof_verify over a LIST of proofs of mixed curves, sharded over the GPUs of one node.
+
+The reference verifies one proof per call (src/proof_verify.rs:19-61); a caller with a list simply loops.  Here the
+list (BASELINE configs[4]: 65 536 proofs, half BN254, half BLS12-381) is partitioned by `sharding.shard_plan` --
+split by curve first, contiguous ranges per rank inside a curve -- every rank owns one context per curve, cuts its
+share into batches, keeps them in flight through bbs_core_proof_verify_submit, and the statuses (one int8 per item)
+are exchanged with ONE all_gather (RCCL over xGMI for backend nccl).  No other collective: items are independent.
+"""
+from typing import Callable, Dict, List, Sequence
+
+import numpy as np
+
+from .sharding import merge_status, shard_plan
+
+
+class PackedBatch:
+    """One batch of one curve, packed for bbs_core_proof_verify_submit (host buffers)."""
+
+    def __init__(self, eng, curve, ids, proofs, disclosed_msgs, disclosed_idx, headers=None, phs=None):
+        self.eng, self.curve, self.ids = eng, curve, list(ids)
+        self.n, self.keep, self.args = eng._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
+
+
+def prepare_rank(engines: Dict[str, object], plan_for_rank: Dict[str, List[int]],
+                 fetch_items: Callable[[str, Sequence[int]], tuple], batch: int = 4096) -> List[PackedBatch]:
+    """Cut this rank's share into batches of at most `batch` items per curve.  fetch_items(curve, ids) returns
+    (proofs, disclosed_msgs, disclosed_idx[, headers, phs]) for those global item ids."""
+    out = []
+    for curve in sorted(plan_for_rank):
+        ids = plan_for_rank[curve]
+        for lo in range(0, len(ids), batch):
+            part = ids[lo:lo + batch]
+            out.append(PackedBatch(engines[curve], curve, part, *fetch_items(curve, part)))
+    return out
+
+
+def run_rank(batches: List[PackedBatch], inflight: int = 8) -> Dict[str, np.ndarray]:
+    """Submit every batch (at most `inflight` outstanding, one submitting thread), return {curve: statuses in plan
+    order}.  Alternates curves so that BN254 and BLS12-381 batches overlap on the device."""
+    by_curve: Dict[str, List[PackedBatch]] = {}
+    for b in batches:
+        by_curve.setdefault(b.curve, []).append(b)
+    order = []
+    queues = [list(v) for _, v in sorted(by_curve.items())]
+    while any(queues):
+        for q in queues:
+            if q:
+                order.append(q.pop(0))
+    results = {id(b): None for b in batches}
+    pending = []
+    for b in order:
+        if len(pending) >= inflight:
+            ob, job = pending.pop(0)
+            job.wait()
+            results[id(ob)] = job.result.copy()
+            job.free()
+        pending.append((b, b.eng.submit_packed(b.n, b.args)))
+    for ob, job in pending:
+        job.wait()
+        results[id(ob)] = job.result.copy()
+        job.free()
+    out = {}
+    for curve, bs in by_curve.items():
+        out[curve] = np.concatenate([results[id(b)] for b in bs]) if bs else np.zeros(0, dtype=np.int8)
+    return out
+
+
+def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> List[int]:
+    """One all_gather of int8 statuses (each rank's share in plan order, padded to the largest share), then
+    sharding.merge_status.  dist=None: single process."""
+    world = len(plan)
+    curves = sorted({c for p in plan for c in p})
+    flat = np.concatenate([np.asarray(mine.get(c, np.zeros(0, dtype=np.int8)), dtype=np.int8) for c in curves]) \
+        if curves else np.zeros(0, dtype=np.int8)
+    sizes = [sum(len(p.get(c, [])) for c in curves) for p in plan]
+    assert len(flat) == sizes[rank], (len(flat), sizes[rank])
+    if dist is None or world == 1:
+        gathered = [flat]
+    else:
+        import torch
+        pad = max(sizes)
+        buf = np.full(pad, -128, dtype=np.int8)          # padding = the internal "undecided" value, never a result
+        buf[:len(flat)] = flat
+        t = torch.from_numpy(buf).to(device)
+        outs = [torch.empty(pad, dtype=torch.int8, device=device) for _ in range(world)]
+        dist.all_gather(outs, t)
+        gathered = [o.cpu().numpy()[:sizes[r]] for r, o in enumerate(outs)]
+    per_rank = []
+    for r, p in enumerate(plan):
+        d, at = {}, 0
+        for c in curves:
+            k = len(p.get(c, []))
+            d[c] = gathered[r][at:at + k]
+            at += k
+        per_rank.append(d)
+    return merge_status(plan, per_rank, n_items)
+
+
+def proof_verify_mixed(engines, curve_of_item: Sequence[str], fetch_items, world: int = 1, rank: int = 0, dist=None,
+                       device="cpu", batch: int = 4096, inflight: int = 8) -> List[int]:
+    """The whole path for one call: plan, pack, run, gather.  Every rank returns the merged statuses."""
+    plan = shard_plan(curve_of_item, world)
+    batches = prepare_rank(engines, plan[rank], fetch_items, batch)
+    mine = run_rank(batches, inflight)
+    return gather_statuses(plan, rank, mine, len(curve_of_item), dist, device)

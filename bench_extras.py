@@ -1,0 +1,145 @@
+"""Untimed legs of bench.py (rank 0, N = 1): the other three operations of the path, the second curve, the opt-in
+modes, the window-width comparison on distinct data and the reference's own bench sweeps.  Nothing here feeds `value`."""
+import time
+
+
+def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, device, submit_loop, make_slots):
+    from bbs_sign_amd import Job
+
+    def rate(j, reps=3):
+        j.run(); j.wait()
+        ms, _ = j.run_timed(reps, per_stage=False)
+        assert (j.status() == 1).all()
+        j.free()
+        return n / (ms / reps * 1e-3)
+
+    def rate_k(make, k=8, steps=32, expect_all_true=True):        # k device-resident batches in flight
+        js = [make() for _ in range(k)]
+        for j in js:
+            j.run()
+        for j in js:
+            j.wait()
+            if expect_all_true:
+                assert (j.status() == 1).all()
+        Job.run_many_timed(js, k)
+        ms, _ = Job.run_many_timed(js, steps)
+        size = js[0].n
+        for j in js:
+            j.free()
+        return size * steps / (ms * 1e-3)
+
+    out = {"unit": "items/s; single = one 4096-item resident batch at a time, *_8_in_flight = eight resident batches"}
+    bls = {"sign": rate(eng.core_sign_upload(msgs)), "verify": rate(eng.core_verify_upload(sigs, msgs)),
+           "proof_gen": rate(eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds)),
+           "sign_8_in_flight": rate_k(lambda: eng.core_sign_upload(msgs)),
+           "verify_8_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs)),
+           "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds))}
+    out["bls12_381"] = bls
+
+    # ---- the reference's only usable proof_verify bench sweep (benches/proof_verify.rs:145-175): L = 32, R in {1..32}
+    sweep = {}
+    for r in (1, 2, 4, 8, 16, 32):
+        d_r = [list(range(r))] * n
+        rn_r = [rn[:5 + L - r] for rn in rnds] if r >= R else None
+        if rn_r is None:                               # fewer disclosed -> more undisclosed scalars than the workload drew
+            rn_r = [pc.bbs.seeded_random_scalars(suite, b"bbs-bench-rnd-r%d-" % r + pc.i2osp(b, 8),
+                                                suite.api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + L - r) for b in range(n)]
+        pr, st = eng.core_proof_gen_batch(sigs, msgs, d_r, rn_r)
+        assert (st == 1).all()
+        dm_r = [m[:r] for m in msgs]
+        sweep["R=%d" % r] = {"proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(pr, dm_r, d_r)),
+                             "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, d_r, rn_r))}
+    bls["disclosed_sweep_L32"] = sweep
+
+    # ---- window widths on DISTINCT data (the 20-bit tables are 52 GB: every batch touches different entries)
+    cmp_w = {}
+    for w in sorted({16, 20} - {args.window_bits}):
+        s2, e2, _, _ = pc.bench_engine("bls12_381", L, None, w, device=device)
+        slots2, _ = make_slots(pc, s2, e2, n, L, R, max(1, args.inflight), first_item=0)
+        bad, _, _ = submit_loop(e2, slots2, len(slots2), len(slots2))
+        assert bad == 0
+        t0 = time.perf_counter()
+        bad, _, _ = submit_loop(e2, slots2, 64, len(slots2))
+        cmp_w[str(w)] = n * 64 / (time.perf_counter() - t0)
+        assert bad == 0
+        e2.close()
+    bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the "
+                                                "headline's own width (%d) is `value`" % (args.inflight, args.window_bits))
+
+    # ---- opt-in modes (not the headline): batch verification, subgroup vouching
+    eng.set_batch_verification(True)
+    bls["proof_verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32, 96)
+    bls["proof_verify_batch_verification_16384_items"] = rate_k(
+        lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 48)
+    bls["verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_verify_upload(sigs, msgs), 32, 96)
+    eng.set_batch_verification(False)
+    eng.set_points_in_subgroup(True)
+    bls["points_in_subgroup"] = {"proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed)),
+                                 "verify_8_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs)),
+                                 "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds))}
+    eng.set_points_in_subgroup(False)
+
+    # ---- ingest of octet strings: 3 n point decompressions + subgroup checks on the device
+    import numpy as np
+    from bbs_sign_amd import _lib as _l
+    from bbs_sign_amd import api as _api
+    from bbs_sign_amd.engine import _ragged_bytes
+    octs = [_api.proof_to_octets("bls12_381", p_) for p_ in proofs[:n]]
+    flat_o, off_o = _ragged_bytes(octs)
+    rec_o = 6 * eng.fpb + 128
+    pf_o = np.zeros(n * rec_o, dtype=np.uint8); cm_o = np.zeros(n * 32 * 32, dtype=np.uint8)
+    cmo_o = np.zeros(n + 1, dtype=np.uint64); st_o = np.zeros(n, dtype=np.int8)
+
+    def decode_call():
+        rc = eng.lib.bbs_proofs_from_octets_batch(eng.h, n, flat_o.ctypes.data_as(_l.c_u8p), off_o.ctypes.data_as(_l.c_u64p),
+                                                  pf_o.ctypes.data_as(_l.c_u8p), cm_o.ctypes.data_as(_l.c_u8p),
+                                                  cmo_o.ctypes.data_as(_l.c_u64p), st_o.ctypes.data_as(_l.c_i8p))
+        assert rc == 0 and (st_o == 1).all()
+    decode_call()
+    t1 = time.perf_counter()
+    for _ in range(4):
+        decode_call()
+    bls["proofs_from_octets_per_s"] = 4 * n / (time.perf_counter() - t1)
+
+    # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
+    sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)
+    mb, db, rb = pc.bench_items(sb_, eb, n, L, R, 0)
+    sb, st = eb.core_sign_batch(mb)
+    assert (st == 1).all()
+    pb, st = eb.core_proof_gen_batch(sb, mb, db, rb)
+    assert (st == 1).all()
+    dmb = [m[:R] for m in mb]
+    out["bn254"] = {"sign": rate(eb.core_sign_upload(mb)), "verify": rate(eb.core_verify_upload(sb, mb)),
+                    "proof_gen": rate(eb.core_proof_gen_upload(sb, mb, db, rb)), "proof_verify": rate(eb.core_proof_verify_upload(pb, dmb, db)),
+                    "sign_8_in_flight": rate_k(lambda: eb.core_sign_upload(mb)),
+                    "verify_8_in_flight": rate_k(lambda: eb.core_verify_upload(sb, mb)),
+                    "proof_gen_8_in_flight": rate_k(lambda: eb.core_proof_gen_upload(sb, mb, db, rb)),
+                    "proof_verify_8_in_flight": rate_k(lambda: eb.core_proof_verify_upload(pb, dmb, db))}
+    mj = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(4)] + \
+         [eb.core_proof_verify_upload(pb, dmb, db) for _ in range(4)]
+    for j in mj:
+        j.run()
+    for j in mj:
+        j.wait()
+        assert (j.status() == 1).all()
+    Job.run_many_timed(mj, 8)
+    mms, _ = Job.run_many_timed(mj, 64)
+    out["mixed_curves_resident"] = {"proof_verify_per_s": n * 64 / (mms * 1e-3),
+                                    "note": "4 BLS12-381 + 4 BN254 resident batches of %d in flight; the whole configs[4] "
+                                            "path (host buffers, sharding, gather) is bench.py --config mixed65536" % n}
+    for j in mj:
+        j.free()
+    eb.close()
+
+    # ---- the reference's message-count sweep for sign / verify (benches/sign.rs:40, benches/verify.rs:49), BN254 like
+    # the reference's benches, 16-bit windows, one resident batch at a time
+    msweep = {}
+    for Lm in (1, 2, 4, 8, 16, 64, 128):
+        sm_, em, _, _ = pc.bench_engine("bn254", Lm, None, 16, device=device)
+        mm, _, _ = pc.bench_items(sm_, em, n, Lm, min(R, Lm), 0)
+        sg, st = em.core_sign_batch(mm)
+        assert (st == 1).all()
+        msweep["msgs=%d" % Lm] = {"sign": rate(em.core_sign_upload(mm)), "verify": rate(em.core_verify_upload(sg, mm))}
+        em.close()
+    out["bn254"]["message_count_sweep"] = msweep
+    return out

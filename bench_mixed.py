@@ -1,0 +1,85 @@
+"""bench.py --config mixed65536: BASELINE.json configs[4] -- 65 536 proof_verify, half BN254 and half BLS12-381
+(split assumed 50/50), sharded over the GPUs of one node.
+
+A step = the whole list once: `sharding.shard_plan` splits it by curve and then into contiguous ranges per rank, every
+rank owns two contexts (BLS12-381 with --window-bits, BN254 with 16-bit windows), cuts its share into 4096-item
+batches in HOST buffers, runs them through bbs_core_proof_verify_submit (one submitting thread, --inflight outstanding,
+curves alternating), and the statuses are exchanged with ONE all_gather of int8 (RCCL for --backend nccl) and merged
+with `sharding.merge_status`.  Strong scaling: the list is fixed, `value` = 65 536 x steps / wall.  Every 16th item of
+the global list is corrupted (one commitment incremented) and the merged statuses are compared with that pattern on
+every rank after every step.
+
+Items are generated per rank for that rank's ids only (the global id decides the item: distinct data on every rank).
+"""
+import json
+import time
+
+
+def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, total=65536, lib_path=None, emit=None, L=32, R=8):
+    from bbs_sign_amd import mixed
+    from bbs_sign_amd.sharding import shard_plan
+    batch = args.batch
+    if emit is None:
+        def emit(line):
+            print(line, flush=True)
+    curve_of_item = ["bls12_381" if (i & 1) else "bn254" for i in range(total)]
+    plan = shard_plan(curve_of_item, world)
+    engines, suites = {}, {}
+    for curve, w in (("bls12_381", args.window_bits), ("bn254", min(args.window_bits, 16))):
+        suites[curve], engines[curve], _, _ = pc.bench_engine(curve, L, lib_path, w, device=local_rank)
+    expect = [0 if i % 16 == 0 else 1 for i in range(total)]
+
+    def fetch_items(curve, ids):
+        """The rank's items by global id (the SURVEY 8d workload with item number = global id)."""
+        suite, eng = suites[curve], engines[curve]
+        out_p, out_dm, out_di = [], [], []
+        for lo in range(0, len(ids), 2048):
+            part = ids[lo:lo + 2048]
+            msgs, disclosed, rnds = pc.bench_items(suite, eng, len(part), L, R, ids=part)
+            sigs, st = eng.core_sign_batch(msgs)
+            assert (st == 1).all()
+            proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+            assert (st == 1).all()
+            for g, p in zip(part, proofs):
+                if g % 16 == 0:
+                    p.commitments[0] = (p.commitments[0] + 1) % suite.curve.r
+            out_p += proofs; out_dm += [m[:R] for m in msgs]; out_di += disclosed
+        return out_p, out_dm, out_di
+
+    t_prep = time.perf_counter()
+    batches = mixed.prepare_rank(engines, plan[rank], fetch_items, batch)
+    t_prep = time.perf_counter() - t_prep
+
+    def step():
+        mine = mixed.run_rank(batches, args.inflight)
+        return mixed.gather_statuses(plan, rank, mine, total, dist, red_dev)
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        assert step() == expect, "warm-up statuses differ from the expected pattern"
+    steps = max(1, min(args.steps, 8))
+    barrier()
+    t0 = time.perf_counter()
+    results = [step() for _ in range(steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    for res in results:
+        assert res == expect, "merged statuses differ from the expected pattern"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        emit(json.dumps({
+            "metric": "BBS+ proof_verify/sec (mixed BN254 + BLS12-381 list of 65536)", "value": total * steps / dt,
+            "unit": "proof_verify/s", "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)),
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d proof_verify = %d BN254 + %d BLS12-381 (L=%d, R=%d), sharded by curve "
+                                   "then contiguously over %d GPU(s), %d-item batches from host buffers, one all_gather of int8 "
+                                   "statuses per step" % (total, total // 2, total // 2, L, R, world, batch),
+                       "batches_per_rank": len(batches), "batches_in_flight": args.inflight, "backend": args.backend if world > 1 else None,
+                       "fixed_base_window_bits": {"bls12_381": args.window_bits, "bn254": min(args.window_bits, 16)}},
+            "checks": {"merged_statuses_exact_every_step": True, "corrupted": "every 16th global item"},
+            "prepare_s_rank0": t_prep}))
+    for e in engines.values():
+        e.close()

@@ -222,6 +222,13 @@ const char* bbs_job_stage_name(const bbs_job* job, int stage);
 int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, float* kernel_ms,
                        int kernel_cap, int* n_stages_out);
 
+/* Stage timers for the submit / run forms: jobs created after bbs_ctx_set_stage_timing(ctx, 1) record a HIP event pair
+ * around every stage of every run, each on the stream the stage is launched on.  bbs_job_stage_times (after
+ * bbs_job_wait) reads the LAST run: total_ms = first stage start .. last stage stop, kernel_ms[k] = duration of stage
+ * k (names: bbs_job_stage_name).  BBS_E_STATE for a job created without timing or not yet run. */
+int bbs_ctx_set_stage_timing(bbs_ctx* ctx, int enabled);
+int bbs_job_stage_times(bbs_job* job, float* total_ms, float* kernel_ms, int kernel_cap, int* n_stages_out);
+
 /* ------------------------------------------------------------------------------------------
  * Unit-parity primitives (hash_to_scalar, G1 multi-scalar multiplication, pairing product).
  * ------------------------------------------------------------------------------------------ */

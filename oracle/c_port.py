@@ -18,8 +18,17 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 
 def build(force=False):
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.run(["gcc", "-O3", "-march=native", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+        # no -march flags: the .so built here travels to the GPU box, whose host CPU may differ
+        subprocess.run(["gcc", "-O3", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
     return LIB
+
+
+def port(curve):
+    """The C port of one curve as an object with sk_to_pk / core_sign / core_verify / core_proof_gen / core_proof_verify."""
+    import sys
+    if curve == "bls12_381":
+        return sys.modules[__name__]
+    raise NotImplementedError("oracle/c restates BLS12-381 only")
 
 
 def lib():

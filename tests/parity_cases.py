@@ -439,7 +439,7 @@ def check_pippenger(curve, lib_path=None, n=40):
     eng.close()
 
 
-def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
+def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5, window_bits=None):
     """Opt-in batch verification (one combined pairing check, per-item fallback) returns the same statuses as the
     default per-item mode and the oracle: all-valid batch; items that fail before the pairing (they are left out of
     the combination); a self-consistent proof of a forged signature (challenge matches, pairing fails: forces the
@@ -451,8 +451,8 @@ def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
     gens = gens_for(suite, L + 1)
     sk = rng.randrange(1, c.r)
     pk = bbs.sk_to_pk(suite, sk)
-    exact = make_engine(curve, gens, api_id, lib_path, sk=sk)
-    batch = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    exact = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    batch = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
     batch.set_batch_verification(True, bytes(rng.randrange(256) for _ in range(32)))
     msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
     headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 3, 40]))) for _ in range(n)]
@@ -514,7 +514,7 @@ def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5):
     batch.close()
 
 
-def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8):
+def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8, window_bits=None):
     """bbs_ctx_set_points_in_subgroup (GLV split of the variable-base terms on BLS12-381; BN254 has cofactor 1 and uses
     its split always, so there both engines run the same code and the comparison is against the oracle only): same
     statuses and group elements as the default path and the oracle for inputs in G1 -- valid proofs / signatures,
@@ -526,8 +526,8 @@ def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8):
     gens = gens_for(suite, L + 1)
     sk = rng.randrange(1, c.r)
     pk = bbs.sk_to_pk(suite, sk)
-    exact = make_engine(curve, gens, api_id, lib_path, sk=sk)
-    fast = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    exact = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    fast = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
     fast.set_points_in_subgroup(True)
     msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
     headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5]))) for _ in range(n)]
@@ -601,30 +601,44 @@ def check_points_in_subgroup(curve, lib_path=None, n=10, L=4, seed=8):
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0, device=0):
-    """SURVEY 8d synthetic workload: one issuer key (IKM [1u8;32]), item b has L 32-byte messages
-    derived from (b, j), empty header / ph, disclosed 0..R, proof_gen scalars from the seeded
-    expander.  Signatures and proofs are produced by the engine itself (checked by the caller)."""
+def bench_engine(curve, L=32, lib_path=None, window_bits=None, device=0):
+    """one issuer key (IKM [1u8;32], dst "BBS-SIG-KEYGEN-SALT-"), the suite's generators."""
     suite = bbs.SUITES[curve]
-    api_id = suite.api_id
     gens = gens_for(suite, L + 1)
     sk = bbs.key_gen(suite, bytes([1] * 32), b"", b"BBS-SIG-KEYGEN-SALT-")
-    eng = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits, device=device)
+    eng = make_engine(curve, gens, suite.api_id, lib_path, sk=sk, window_bits=window_bits, device=device)
+    return suite, eng, gens, sk
+
+
+def bench_items(suite, eng, n, L=32, R=8, first_item=0, ids=None):
+    """SURVEY 8d synthetic items b = first_item .. first_item + n (or the given ids): L 32-byte messages derived from
+    (b, j), disclosed 0..R, proof_gen scalars from the seeded expander (src/utils/core_utilities.rs:84-100)."""
+    api_id = suite.api_id
+    ids = list(range(first_item, first_item + n)) if ids is None else list(ids)
+    n = len(ids)
     raw = [expand_message(b"bbs-bench-msg" + i2osp(b, 8) + i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32)
-           for b in range(n) for j in range(L)]
+           for b in ids for j in range(L)]
     flat = eng.hash_to_scalar_batch(raw, api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
     msgs = [flat[b * L:(b + 1) * L] for b in range(n)]
     disclosed = [list(range(R))] * n
     rnds = [bbs.seeded_random_scalars(suite, b"bbs-bench-rnd" + i2osp(b, 8), api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + L - R)
-            for b in range(n)]
+            for b in ids]
+    return msgs, disclosed, rnds
+
+
+def bench_workload(curve, n, L=32, R=8, lib_path=None, window_bits=None, seed=0, device=0, first_item=0):
+    """SURVEY 8d synthetic workload (bench_engine + bench_items).  Signatures and proofs are produced by the engine
+    itself (checked by the caller)."""
+    suite, eng, gens, sk = bench_engine(curve, L, lib_path, window_bits, device)
+    msgs, disclosed, rnds = bench_items(suite, eng, n, L, R, first_item)
     return suite, eng, gens, sk, msgs, disclosed, rnds
 
 
-def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2):
+def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2, window_bits=None):
     """Full-size batch through size-independent properties: sign -> verify all true -> proof_gen ->
     proof_verify all true; every 16th item corrupted -> exactly those false; a few items spot-checked
     against the oracle."""
-    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, L, R, lib_path)
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, L, R, lib_path, window_bits)
     c = suite.curve
     pk = bbs.sk_to_pk(suite, sk)
     sigs, st = eng.core_sign_batch(msgs)
@@ -689,13 +703,13 @@ def check_mixed_curves_in_flight(lib_path=None, n=1024, per_curve=3, rounds=4):
         j.free()
 
 
-def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8):
+def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None):
     """EVERY item of a BASELINE-shaped batch against the plain-C oracle (oracle/c), bit for bit:
     signatures, proofs and proof_verify booleans incl. corrupted items."""
     import concurrent.futures as cf
     import os
     from oracle import c_port
-    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload("bls12_381", n, L, R, lib_path)
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload("bls12_381", n, L, R, lib_path, window_bits)
     c = suite.curve
     api_id = suite.api_id
     pk = c_port.sk_to_pk(sk)
@@ -728,4 +742,128 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8):
     # the opt-in batch-verification mode returns the same booleans on the same (partly corrupted) batch
     eng.set_batch_verification(True)
     assert [int(x) for x in eng.core_proof_verify_batch(proofs, dm, disclosed)] == [int(x) for x in st]
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def check_window_widths(curve, lib_path=None, widths=(5, 7, 11, 13), L=2, seed=31):
+    """Fixed-base tables at window widths whose digits straddle 32-bit words and whose last window is clamped at bit
+    256 (stages.hpp fixed_msm_chunk_to): the group elements of the MSM primitive with edge scalars, and one
+    sign -> verify -> proof_gen -> proof_verify round trip, against the oracle (src/proof_verify.rs:163-182)."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    bases = [suite.p1] + gens
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    for w in widths:
+        eng = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=w)
+        top = (1 << 256) - 1
+        edge = [0, 1, c.r - 1, (1 << w) - 1, 1 << w, (1 << (32 - 1)) | 1, ((1 << w) - 1) << (32 - w // 2),
+                top % c.r, (top >> 1) % c.r, ((1 << 255) | (1 << 254)) % c.r, (c.r - 1) >> 1]
+        fs = [[edge[(i + k) % len(edge)] for k in range(L + 2)] for i in range(len(edge))]
+        fs += [[rng.randrange(c.r) for _ in range(L + 2)] for _ in range(4)]
+        out, st = eng.g1_msm_batch(fs, [], [])
+        assert list(st) == [1] * len(fs)
+        for i, row in enumerate(fs):
+            want = None
+            for k in range(L + 2):
+                want = c.g1_add(want, c.g1_mul(bases[k], row[k]))
+            assert out[i] == want, (curve, w, i)
+        msgs = [rng.randrange(c.r) for _ in range(L)]
+        hdr, ph = b"hdr%d" % w, b"ph"
+        sig = eng.core_sign(hdr, msgs)
+        want = bbs.core_sign(suite, sk, gens, hdr, msgs, api_id)
+        assert (sig.a, sig.e) == (want.a, want.e), (curve, w, "sign")
+        assert eng.core_verify(sig, hdr, msgs) is True
+        rnd = [rng.randrange(1, c.r) for _ in range(5 + L - 1)]
+        proof = eng.core_proof_gen(sig, hdr, ph, msgs, [1], rnd)
+        wantp = bbs.core_proof_gen(suite, pk, want, hdr, gens, ph, msgs, [1], api_id, rnd)
+        assert proof_eq(proof, wantp), (curve, w, "proof_gen")
+        assert eng.core_proof_verify(proof, hdr, ph, [msgs[1]], [1]) is True
+        proof.commitments[0] = (proof.commitments[0] + 1) % c.r
+        assert eng.core_proof_verify(proof, hdr, ph, [msgs[1]], [1]) is False
+        eng.close()
+
+
+def check_fail_closed(curve, lib_path=None):
+    """A job whose kernels never ran has decided nothing: its statuses are the internal pending value, which the C ABI
+    refuses to return (BBS_E_STATE) -- it must never read as Ok(true).  After a run the same job reports normally."""
+    from bbs_sign_amd.engine import BbsRuntimeError
+    rng = random.Random(17)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    L = 3
+    gens = gens_for(suite, L + 1)
+    eng = make_engine(curve, gens, suite.api_id, lib_path, sk=rng.randrange(1, c.r))
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(3)]
+    sigs, st = eng.core_sign_batch(msgs)
+    assert list(st) == [1, 1, 1]
+    disclosed = [[0], [1, 2], []]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert list(st) == [1, 1, 1]
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(3)]
+    jobs = [eng.core_proof_verify_upload(proofs, dm, disclosed), eng.core_verify_upload(sigs, msgs), eng.core_sign_upload(msgs),
+            eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds)]
+    for job in jobs:
+        try:
+            st = job.status()
+        except BbsRuntimeError as e:
+            assert e.rc == -102, e.rc
+        else:
+            raise AssertionError("a job that never ran returned statuses %r" % list(st))
+        job.run(); job.wait()
+        assert list(job.status()) == [1, 1, 1]
+        job.free()
+    eng.close()
+
+
+def check_submit(curve, lib_path=None, n=7, L=4, seed=23):
+    """bbs_core_proof_verify_submit: several batches submitted back to back by one thread, statuses delivered at wait,
+    equal to the one-shot call and to the oracle -- including items the device-side validation rejects."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    batches = []
+    for b in range(3):
+        msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+        headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 3, 33]))) for _ in range(n)]
+        phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 7]))) for _ in range(n)]
+        disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+        rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+        sigs, st = eng.core_sign_batch(msgs, headers)
+        proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+        assert list(st) == [1] * n
+        dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+        idx = [list(d) for d in disclosed]
+        k = b % n
+        proofs[k].r3_cap = (proofs[k].r3_cap + 1) % c.r                  # Ok(false)
+        proofs[(k + 1) % n].e_cap = c.r                                   # not canonical: -40
+        idx[(k + 2) % n] = idx[(k + 2) % n] + [L + 3]                     # InvalidDisclosedIndex: -3
+        dm[(k + 2) % n] = dm[(k + 2) % n] + [5]
+        if len(idx[(k + 3) % n]) >= 1:
+            idx[(k + 3) % n] = idx[(k + 3) % n] + [idx[(k + 3) % n][0]]   # duplicate: the reference panics, -22 (or -1)
+            dm[(k + 3) % n] = dm[(k + 3) % n] + [7]
+        batches.append((proofs, dm, idx, headers, phs))
+    jobs = [eng.core_proof_verify_submit(*b) for b in batches]            # all in flight
+    for job, b in zip(jobs, batches):
+        job.wait()
+        got = [int(x) for x in job.result]
+        assert got == [int(x) for x in eng.core_proof_verify_batch(*b)], got
+        assert -40 in got and -3 in got and 0 in got and 1 in got, got
+        proofs, dm, idx, headers, phs = b
+        for i in range(n):
+            if got[i] in (0, 1):
+                p = proofs[i]
+                op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+                assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], idx[i], api_id)) == got[i]
+        job.free()
     eng.close()

@@ -38,23 +38,45 @@ def test_pippenger(curve):
     pc.check_pippenger(curve, None, n=200)
 
 
-@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
-def test_batch_verification(curve):
-    pc.check_batch_verification(curve, None)
+# Fixed-base window widths: 8 = the library default, 16 / 20 = what bench.py runs (BN254 / BLS12-381 headline).  Width 20
+# is the one whose digits straddle 32-bit words, whose last window is clamped and whose tables take 52 GB at L = 32.
+WIDTHS = [("bls12_381", 8), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 8), ("bn254", 16), ("bn254", 20)]
+
+
+@pytest.mark.parametrize("curve,window_bits", WIDTHS)
+def test_batch_verification(curve, window_bits):
+    pc.check_batch_verification(curve, None, window_bits=window_bits)
+
+
+@pytest.mark.parametrize("curve,window_bits", WIDTHS)
+def test_points_in_subgroup(curve, window_bits):
+    pc.check_points_in_subgroup(curve, None, window_bits=window_bits)
+
+
+@pytest.mark.parametrize("curve,window_bits", WIDTHS)
+def test_full_batch_4096(curve, window_bits):
+    pc.check_big_batch(curve, None, n=4096, L=32, R=8, window_bits=window_bits)
+
+
+@pytest.mark.parametrize("window_bits", [8, 16, 20])
+def test_every_item_against_c_oracle(window_bits):
+    pc.check_batch_vs_c_oracle(None, n=1024, window_bits=window_bits)
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
-def test_points_in_subgroup(curve):
-    pc.check_points_in_subgroup(curve, None)
+def test_window_widths(curve):
+    pc.check_window_widths(curve, None, widths=(5, 7, 11, 13, 17, 19, 20, 22), L=2)
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
-def test_full_batch_4096(curve):
-    pc.check_big_batch(curve, None, n=4096, L=32, R=8)
+def test_fail_closed(curve):
+    pc.check_fail_closed(curve, None)
 
 
-def test_every_item_against_c_oracle():
-    pc.check_batch_vs_c_oracle(None, n=1024)
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_submit(curve):
+    pc.check_submit(curve, None)
+    pc.check_submit(curve, None, n=130, L=6, seed=24)         # crosses wavefront boundaries
 
 
 def test_mixed_curves_in_flight():

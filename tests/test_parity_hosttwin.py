@@ -61,3 +61,19 @@ def test_points_in_subgroup(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_empty_batches(twin, curve):
     pc.check_empty_batches(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_window_widths(twin, curve):
+    # odd widths: digits straddle 32-bit words, the last window is clamped at bit 256
+    pc.check_window_widths(curve, twin, widths=(5, 7, 11, 13))
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_fail_closed(twin, curve):
+    pc.check_fail_closed(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_submit(twin, curve):
+    pc.check_submit(curve, twin)

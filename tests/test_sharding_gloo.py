@@ -1,6 +1,9 @@
-"""The N > 1 path on CPU: two gloo ranks shard a mixed batch, each 'verifies' its shard (the oracle
-stands in for the GPU engine here -- this test covers the partition + gather plumbing, not the
-kernels), rank 0 merges and compares with the unsharded answer."""
+"""The N > 1 path on CPU, world size 2 over gloo.
+ * test_two_rank_gloo_shard_and_gather: partition + gather plumbing with a stand-in per-item result.
+ * test_two_rank_engine_backed_mixed_list: bench.py --config mixed65536's own driver (bench_mixed.run_mixed) with each
+   rank running the HOST TWIN engine (the same stage code compiled for x86, tests/hosttwin) on its shard of a small
+   mixed BN254 + BLS12-381 list: two contexts per rank, distinct data per rank, submit path, one all_gather of int8
+   statuses, merge, comparison with the expected pattern on every rank."""
 import os
 import socket
 import sys
@@ -65,3 +68,52 @@ def test_two_rank_gloo_shard_and_gather():
     for p in procs:
         p.join(60)
     assert ok == (True, True)
+
+
+def _engine_worker(rank, world, port, twin, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import argparse
+    import json
+    import parity_cases as pc
+    import bench_mixed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(batch=5, inflight=3, window_bits=4, warmup=1, steps=2, backend="gloo")
+    lines = []
+    bench_mixed.run_mixed(args, pc, torch, dist, rank, 0, world, "cpu", dist.barrier, total=36, lib_path=twin,
+                          emit=lines.append, L=4, R=2)
+    if rank == 0:
+        q.put(json.loads(lines[0]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_engine_backed_mixed_list():
+    from bbs_sign_amd import build as b
+    twin = b.build(twin=True, verbose=False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, twin, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    line = None
+    for _ in range(120):
+        try:
+            line = q.get(timeout=5)
+            break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(60 if line is not None else 1)
+        if p.is_alive():
+            p.terminate()
+    assert line is not None, "a rank died: exit codes %r" % [p.exitcode for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["checks"]["merged_statuses_exact_every_step"] is True
+    assert line["config"]["batches_per_rank"] == 4          # 9 items per curve per rank in batches of 5
