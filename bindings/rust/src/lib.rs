@@ -1,147 +1,321 @@
-//! Host shim: the reference's `proof_verify` / `PublicKey::verify` / `SecretKey::sign` / `proof_gen` call sites
-//! (src/proof_verify.rs:19-61, src/verify.rs:18-50, src/sign.rs:32-60, src/proof_gen.rs:78-113) re-pointed at the
-//! MI355X engine through the C ABI of include/bbs_sign_amd.h.
+//! Host shim: the reference's four public entry points -- `SecretKey::sign` (src/sign.rs:32-60), `PublicKey::verify`
+//! (src/verify.rs:18-50), `proof_gen` (src/proof_gen.rs:78-113), `proof_verify` (src/proof_verify.rs:19-61) -- re-pointed
+//! at the MI355X engine through the C ABI of include/bbs_sign_amd.h, for BATCHES of items of one issuer.
 //!
-//! SOURCE ONLY: the build image has no Rust toolchain; this file has never been compiled.  It documents the
-//! binding a maintainer would add; the identical call sequence is what bbs_sign_amd/api.py does (tested).
+//! SOURCE ONLY: the build image has no Rust toolchain; this file has never been compiled.  The ABI it binds IS
+//! exercised by a non-Rust client that performs exactly this file's call sequence, argument for argument:
+//! tests/cpp/ffi_sequence.c (plain C against include/bbs_sign_amd.h; tests/test_ffi_sequence.py runs it on the CPU test
+//! build and on the GPU).  Every `unsafe` call below carries the step number of that file.
 //!
-//! Shape: a `GpuIssuer<E>` owns one engine context = (curve, generators for L messages, issuer public key).
-//! The reference recomputes `create_generators` on every call (sign.rs:49, verify.rs:35, proof_gen.rs:98,
-//! proof_verify.rs:40-43); here it is computed once by the library (`bbs_create_generators`) when the context is
-//! built.  Proofs are verified in batches: `verify_proofs` takes n proofs and returns n `Result<bool, _>`.
+//! Shape: a `GpuIssuer<E, F, C>` owns one engine context = (curve, generators for `l` messages, issuer key).  The
+//! reference recomputes `create_generators` on every call (sign.rs:49, verify.rs:35, proof_gen.rs:98,
+//! proof_verify.rs:40-43); here the library computes them once (`bbs_create_generators`) when the context is built.
+//! Types are the reference's own: `Signature<E, F>` (sign.rs:18-22), `Proof<E, F>` with `challenge: Challenge<F>`
+//! (proof_gen.rs:24-39), `PublicKey<E>` / `SecretKey<F>` (key_gen.rs:12-32), `SignatureError`, `ProofGenError`.
 use ark_ec::{pairing::Pairing, AffineRepr, CurveGroup};
 use ark_ff::{BigInteger, PrimeField};
+use std::marker::PhantomData;
 use std::os::raw::c_int;
 
-use bbs_plus::proof_gen::{Proof, ProofGenError};
+use bbs_plus::constants::Constants;
+use bbs_plus::key_gen::{PublicKey, SecretKey};
+use bbs_plus::proof_gen::{Challenge, Proof, ProofGenError};
+use bbs_plus::sign::{Signature, SignatureError};
+use bbs_plus::utils::core_utilities::calculate_random_scalars;
+use bbs_plus::utils::utilities_helper::FromOkm;
 
 #[repr(C)]
 pub struct BbsCtx { _p: [u8; 0] }
+#[repr(C)]
+pub struct BbsJob { _p: [u8; 0] }
 
+#[link(name = "bbs_sign_amd")]
 extern "C" {
     fn bbs_fp_bytes(curve: c_int) -> usize;
+    fn bbs_create_generators(curve: c_int, count: usize, api_id: *const u8, api_id_len: usize, out_affine: *mut u8) -> c_int;
     fn bbs_ctx_create(curve: c_int, device_id: c_int, out: *mut *mut BbsCtx) -> c_int;
     fn bbs_ctx_destroy(ctx: *mut BbsCtx);
     fn bbs_ctx_set_window_bits(ctx: *mut BbsCtx, bits: c_int) -> c_int;
     fn bbs_ctx_set_generators(ctx: *mut BbsCtx, gens: *const u8, count: usize, api_id: *const u8, api_id_len: usize) -> c_int;
     fn bbs_ctx_set_public_key(ctx: *mut BbsCtx, pk: *const u8, is_identity: c_int) -> c_int;
-    fn bbs_ctx_set_batch_verification(ctx: *mut BbsCtx, enabled: c_int, seed32: *const u8) -> c_int;
+    fn bbs_ctx_set_secret_key(ctx: *mut BbsCtx, sk32: *const u8) -> c_int;
     fn bbs_ctx_set_points_in_subgroup(ctx: *mut BbsCtx, vouched: c_int) -> c_int;
-    fn bbs_create_generators(curve: c_int, count: usize, api_id: *const u8, api_id_len: usize, out_affine: *mut u8) -> c_int;
     fn bbs_hash_to_scalar_batch(ctx: *mut BbsCtx, n: usize, msgs: *const u8, msg_off: *const u64,
                                 dst: *const u8, dst_len: usize, scalars_out: *mut u8) -> c_int;
-    fn bbs_core_proof_verify_batch(ctx: *mut BbsCtx, n: usize, proofs_fixed: *const u8,
+    fn bbs_core_sign_batch(ctx: *mut BbsCtx, n: usize, messages: *const u8, msg_off: *const u64,
+                           headers: *const u8, hdr_off: *const u64, signatures_out: *mut u8, status: *mut i8) -> c_int;
+    fn bbs_core_verify_batch(ctx: *mut BbsCtx, n: usize, signatures: *const u8, messages: *const u8, msg_off: *const u64,
+                             headers: *const u8, hdr_off: *const u64, status: *mut i8) -> c_int;
+    fn bbs_core_proof_gen_batch(ctx: *mut BbsCtx, n: usize, signatures: *const u8, messages: *const u8, msg_off: *const u64,
+                                disclosed_idx: *const u64, didx_off: *const u64, random_scalars: *const u8, rnd_off: *const u64,
+                                headers: *const u8, hdr_off: *const u64, ph: *const u8, ph_off: *const u64,
+                                proofs_fixed_out: *mut u8, commitments_out: *mut u8, commit_off_out: *mut u64, status: *mut i8) -> c_int;
+    fn bbs_core_proof_verify_submit(ctx: *mut BbsCtx, n: usize, proofs_fixed: *const u8,
         commitments: *const u8, commit_off: *const u64, disclosed_msgs: *const u8, dmsg_off: *const u64,
         disclosed_idx: *const u64, didx_off: *const u64, headers: *const u8, hdr_off: *const u64,
-        ph: *const u8, ph_off: *const u64, status: *mut i8) -> c_int;
-    // bbs_core_sign_batch / bbs_core_verify_batch / bbs_core_proof_gen_batch, the job API (upload / run / wait /
-    // fetch) and the octet codec follow the same pattern: see include/bbs_sign_amd.h
+        ph: *const u8, ph_off: *const u64, status: *mut i8, job_out: *mut *mut BbsJob) -> c_int;
+    fn bbs_job_wait(job: *mut BbsJob) -> c_int;
+    fn bbs_job_free(job: *mut BbsJob);
 }
 
 /// Curves the engine knows (BBS_CURVE_* of the header).
 pub trait GpuCurve: Pairing {
     const CURVE_ID: c_int;
-    const CIPHERSUITE_ID: &'static [u8];
 }
-impl GpuCurve for ark_bls12_381::Bls12_381 {
-    const CURVE_ID: c_int = 0;
-    const CIPHERSUITE_ID: &'static [u8] = b"BBS_BLS12381G1_XMD:SHA-256_SSWU_RO_";
-}
-impl GpuCurve for ark_bn254::Bn254 {
-    const CURVE_ID: c_int = 1;
-    const CIPHERSUITE_ID: &'static [u8] = b"BBS_QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_";
-}
+impl GpuCurve for ark_bls12_381::Bls12_381 { const CURVE_ID: c_int = 0; }
+impl GpuCurve for ark_bn254::Bn254 { const CURVE_ID: c_int = 1; }
 
-fn put_fr<F: PrimeField>(x: &F, out: &mut Vec<u8>) { out.extend(x.into_bigint().to_bytes_le()); }      // 32 B canonical LE
+// ---- canonical little-endian encodings of include/bbs_sign_amd.h ("Data formats") ------------------------------------
+fn put_fr<F: PrimeField>(x: &F, out: &mut Vec<u8>) { out.extend(x.into_bigint().to_bytes_le()); }          // 32 B
+fn get_fr<F: PrimeField>(b: &[u8]) -> F { F::from_le_bytes_mod_order(b) }                                   // canonical in, exact
 
 fn put_g1<E: Pairing>(p: &E::G1, fpb: usize, out: &mut Vec<u8>)
 where <E::G1Affine as AffineRepr>::BaseField: PrimeField {
     match p.into_affine().xy() {
-        None => out.extend(std::iter::repeat(0u8).take(2 * fpb)),                                      // identity = all zero
+        None => out.extend(std::iter::repeat(0u8).take(2 * fpb)),                                          // identity = all zero
         Some((x, y)) => { out.extend(x.into_bigint().to_bytes_le()); out.extend(y.into_bigint().to_bytes_le()); }
     }
 }
+fn get_g1<E: Pairing>(b: &[u8], fpb: usize) -> E::G1
+where <E::G1Affine as AffineRepr>::BaseField: PrimeField {
+    if b.iter().all(|&v| v == 0) { return E::G1::default(); }
+    let x = <<E::G1Affine as AffineRepr>::BaseField>::from_le_bytes_mod_order(&b[..fpb]);
+    let y = <<E::G1Affine as AffineRepr>::BaseField>::from_le_bytes_mod_order(&b[fpb..2 * fpb]);
+    E::G1Affine::new_unchecked(x, y).into_group()           // the engine only returns points it computed on the curve
+}
 
-/// Per-item status of the header -> the reference's Result (src/proof_gen.rs ProofGenError, proof_verify.rs:139-150).
-fn status_to_result(st: i8) -> Result<bool, ProofGenError> {
+/// Ragged byte strings -> flat buffer + n + 1 offsets.
+fn ragged(items: &[&[u8]]) -> (Vec<u8>, Vec<u64>) {
+    let (mut flat, mut off) = (Vec::new(), vec![0u64]);
+    for it in items { flat.extend_from_slice(it); off.push(flat.len() as u64); }
+    (flat, off)
+}
+
+/// Per-item status of the header -> the reference's errors.  BBS_ST_* values: -1 InvalidMessageAndGeneratorsLength,
+/// -2 InvalidDisclosedIndicesLength, -3 InvalidDisclosedIndex, -4 InvalidRandomScalarsAndUndisclosedIndicesLength,
+/// -5 InvalidUndisclosedIndicesLength, -6 InvalidIndicesAndMessagesLength; -20 .. -23 are the reference's panics
+/// (sign.rs:129, proof_gen.rs:346, proof_verify.rs:177-179, utilities_helper.rs:46-52) and are re-raised as panics.
+fn proof_error(st: i8) -> ProofGenError {
     match st {
-        1 => Ok(true),
-        0 => Ok(false),
-        -1 => Err(ProofGenError::InvalidDisclosedIndex),
-        -2 => Err(ProofGenError::InvalidIndicesAndMessagesLength),
-        -3 => Err(ProofGenError::InvalidMessageAndGeneratorsLength),
-        // -20.. are the reference's panics (dst too long, index out of bounds): re-raise them as panics
+        -1 => ProofGenError::InvalidMessageAndGeneratorsLength,
+        -2 => ProofGenError::InvalidDisclosedIndicesLength,
+        -3 => ProofGenError::InvalidDisclosedIndex,
+        -4 => ProofGenError::InvalidRandomScalarsAndUndisclosedIndicesLength,
+        -5 => ProofGenError::InvalidUndisclosedIndicesLength,
+        -6 => ProofGenError::InvalidIndicesAndMessagesLength,
+        other => panic!("bbs_sign_amd status {other}"),
+    }
+}
+fn signature_error(st: i8) -> SignatureError {
+    match st {
+        -1 => SignatureError::InvalidMessageAndGeneratorsLength,
         other => panic!("bbs_sign_amd status {other}"),
     }
 }
 
-pub struct GpuIssuer<E: GpuCurve> {
+pub struct GpuIssuer<E: GpuCurve, F: PrimeField, C> {
     ctx: *mut BbsCtx,
     api_id: Vec<u8>,
     fpb: usize,
-    _e: std::marker::PhantomData<E>,
+    l: usize,
+    _m: PhantomData<(E, F, C)>,
 }
 
-impl<E: GpuCurve> GpuIssuer<E>
-where <E::G1Affine as AffineRepr>::BaseField: PrimeField, E::ScalarField: PrimeField {
-    /// Context for proofs over `l` messages of issuer `pk_affine` (x.c0 | x.c1 | y.c0 | y.c1, canonical LE).
-    pub fn new(device: i32, l: usize, pk_affine: &[u8], batch_verification: bool) -> Result<Self, c_int> {
+impl<E, F, C> GpuIssuer<E, F, C>
+where
+    E: GpuCurve,
+    F: PrimeField + FromOkm<48, F>,
+    C: for<'a> Constants<'a, E>,
+    <E::G1Affine as AffineRepr>::BaseField: PrimeField,
+    <E::G2Affine as AffineRepr>::BaseField: ark_ff::Field,
+{
+    /// Context for items with `l` messages.  Call `set_public_key` (verify / proof_gen / proof_verify) or
+    /// `set_secret_key` (sign; also sets the public key) next.
+    pub fn new(device: i32, l: usize, window_bits: i32) -> Result<Self, c_int> {
         unsafe {
-            let fpb = bbs_fp_bytes(E::CURVE_ID);
-            let api_id = [E::CIPHERSUITE_ID, b"H2G_HM2S_"].concat();            // src/proof_verify.rs:35
+            let fpb = bbs_fp_bytes(E::CURVE_ID);                                                   // step 1
+            let api_id = [C::CIPHERSUITE_ID, b"H2G_HM2S_"].concat();                              // src/sign.rs:44
             let mut gens = vec![0u8; (l + 1) * 2 * fpb];
-            let rc = bbs_create_generators(E::CURVE_ID, l + 1, api_id.as_ptr(), api_id.len(), gens.as_mut_ptr());
+            let rc = bbs_create_generators(E::CURVE_ID, l + 1, api_id.as_ptr(), api_id.len(), gens.as_mut_ptr());   // step 2
             if rc != 0 { return Err(rc); }
             let mut ctx = std::ptr::null_mut();
-            let rc = bbs_ctx_create(E::CURVE_ID, device, &mut ctx);
+            let rc = bbs_ctx_create(E::CURVE_ID, device, &mut ctx);                               // step 3
             if rc != 0 { return Err(rc); }
-            bbs_ctx_set_window_bits(ctx, 20);   // 52 GB of tables for L = 32 on a 288 GB device; 16 -> 4 GB, a few % slower
-            let rc = bbs_ctx_set_generators(ctx, gens.as_ptr(), l + 1, api_id.as_ptr(), api_id.len());
+            bbs_ctx_set_window_bits(ctx, window_bits);                                             // step 4 (20: 52 GB of tables at l = 32)
+            let rc = bbs_ctx_set_generators(ctx, gens.as_ptr(), l + 1, api_id.as_ptr(), api_id.len());   // step 5
             if rc != 0 { bbs_ctx_destroy(ctx); return Err(rc); }
-            let rc = bbs_ctx_set_public_key(ctx, pk_affine.as_ptr(), 0);
-            if rc != 0 { bbs_ctx_destroy(ctx); return Err(rc); }
-            // every E::G1Affine inside a Proof<E> / Signature<E> is a checked subgroup member (ark-ec), so the shim can vouch
-            bbs_ctx_set_points_in_subgroup(ctx, 1);
-            if batch_verification { bbs_ctx_set_batch_verification(ctx, 1, std::ptr::null()); }
-            Ok(Self { ctx, api_id, fpb, _e: std::marker::PhantomData })
+            // every E::G1 inside a Proof<E, F> / Signature<E, F> is a checked subgroup member (ark-ec), so the shim can vouch
+            bbs_ctx_set_points_in_subgroup(ctx, 1);                                                // step 6
+            Ok(Self { ctx, api_id, fpb, l, _m: PhantomData })
         }
     }
 
-    /// `proof_verify` (src/proof_verify.rs:19-61) for n proofs at once: byte messages in, Result<bool> per item out.
-    pub fn verify_proofs(&self, proofs: &[Proof<E>], headers: &[&[u8]], phs: &[&[u8]],
-                         disclosed_msgs: &[&[&[u8]]], disclosed_idx: &[&[usize]]) -> Vec<Result<bool, ProofGenError>> {
-        let n = proofs.len();
-        // msg_to_scalars (interface_utilities.rs:76-88) for all disclosed messages of the batch in one device call
-        let (mut flat, mut off) = (Vec::new(), vec![0u64]);
-        for item in disclosed_msgs { for m in *item { flat.extend_from_slice(m); off.push(flat.len() as u64); } }
+    /// `sk` of `SecretKey::sign` (sign.rs:32); the library derives pk = sk * BP2 (key_gen.rs:83-90, sign.rs:81).
+    pub fn set_secret_key(&mut self, sk: &SecretKey<F>) -> Result<(), c_int> {
+        let mut b = Vec::new();
+        put_fr(&sk.sk, &mut b);
+        let rc = unsafe { bbs_ctx_set_secret_key(self.ctx, b.as_ptr()) };                          // step 8
+        if rc != 0 { Err(rc) } else { Ok(()) }
+    }
+
+    /// `pk` of verify / proof_gen / proof_verify (key_gen.rs:12-15): x.c0 | x.c1 | y.c0 | y.c1, canonical LE.
+    pub fn set_public_key(&mut self, pk: &PublicKey<E>) -> Result<(), c_int>
+    where <E::G2Affine as AffineRepr>::BaseField: ark_ff::Field<BasePrimeField = <E::G1Affine as AffineRepr>::BaseField> {
+        let a = pk.pk.into_affine();
+        let rc = match a.xy() {
+            None => unsafe { bbs_ctx_set_public_key(self.ctx, std::ptr::null(), 1) },
+            Some((x, y)) => {
+                let mut b = Vec::new();
+                for c in x.to_base_prime_field_elements().chain(y.to_base_prime_field_elements()) {
+                    b.extend(c.into_bigint().to_bytes_le());
+                }
+                unsafe { bbs_ctx_set_public_key(self.ctx, b.as_ptr(), 0) }                         // step 9 (get) / alt
+            }
+        };
+        if rc != 0 { Err(rc) } else { Ok(()) }
+    }
+
+    /// msg_to_scalars (interface_utilities.rs:76-88) of every message of every item in one device call:
+    /// flat scalars (32 B LE each) + per-item offsets in scalars.
+    fn msg_to_scalars(&self, items: &[&[&[u8]]]) -> (Vec<u8>, Vec<u64>) {
+        let (mut flat, mut off, mut item_off) = (Vec::new(), vec![0u64], vec![0u64]);
+        for item in items {
+            for m in *item { flat.extend_from_slice(m); off.push(flat.len() as u64); }
+            item_off.push((off.len() - 1) as u64);
+        }
         let dst = [self.api_id.as_slice(), b"MAP_MSG_TO_SCALAR_AS_HASH_"].concat();
-        let mut dm = vec![0u8; 32 * (off.len() - 1)];
-        unsafe { bbs_hash_to_scalar_batch(self.ctx, off.len() - 1, flat.as_ptr(), off.as_ptr(), dst.as_ptr(), dst.len(), dm.as_mut_ptr()); }
-        // records: a_bar | b_bar | d | e_cap | r1_cap | r3_cap | challenge, then ragged commitments / indexes / bytes
-        let (mut fixed, mut cm, mut cm_off) = (Vec::new(), Vec::new(), vec![0u64]);
-        let (mut dm_off, mut di, mut di_off) = (vec![0u64], Vec::new(), vec![0u64]);
-        let (mut hb, mut h_off, mut pb, mut p_off) = (Vec::new(), vec![0u64], Vec::new(), vec![0u64]);
+        let mut sc = vec![0u8; 32 * (off.len() - 1)];
+        let rc = unsafe { bbs_hash_to_scalar_batch(self.ctx, off.len() - 1, flat.as_ptr(), off.as_ptr(), dst.as_ptr(), dst.len(), sc.as_mut_ptr()) };   // step 10
+        assert_eq!(rc, 0, "bbs_hash_to_scalar_batch: {rc}");
+        (sc, item_off)
+    }
+
+    fn put_signatures(&self, sigs: &[Signature<E, F>]) -> Vec<u8> {
+        let mut out = Vec::new();
+        for s in sigs { put_g1::<E>(&s.a, self.fpb, &mut out); put_fr(&s.e, &mut out); }
+        out
+    }
+
+    /// `SecretKey::sign` (src/sign.rs:32-60) for n items.
+    pub fn sign(&self, messages: &[&[&[u8]]], headers: &[&[u8]]) -> Vec<Result<Signature<E, F>, SignatureError>> {
+        let n = messages.len();
+        let (ms, mo) = self.msg_to_scalars(messages);
+        let (hb, ho) = ragged(headers);
+        let rec = 2 * self.fpb + 32;
+        let (mut out, mut st) = (vec![0u8; n * rec], vec![0i8; n]);
+        let rc = unsafe { bbs_core_sign_batch(self.ctx, n, ms.as_ptr(), mo.as_ptr(), hb.as_ptr(), ho.as_ptr(), out.as_mut_ptr(), st.as_mut_ptr()) };   // step 11
+        assert_eq!(rc, 0, "bbs_core_sign_batch: {rc}");
+        (0..n).map(|i| if st[i] == 1 {
+            let r = &out[i * rec..(i + 1) * rec];
+            Ok(Signature { a: get_g1::<E>(r, self.fpb), e: get_fr::<F>(&r[2 * self.fpb..]) })
+        } else { Err(signature_error(st[i])) }).collect()
+    }
+
+    /// `PublicKey::verify` (src/verify.rs:18-50) for n items.
+    pub fn verify(&self, signatures: &[Signature<E, F>], headers: &[&[u8]], messages: &[&[&[u8]]]) -> Vec<Result<bool, SignatureError>> {
+        let n = signatures.len();
+        let sg = self.put_signatures(signatures);
+        let (ms, mo) = self.msg_to_scalars(messages);
+        let (hb, ho) = ragged(headers);
+        let mut st = vec![0i8; n];
+        let rc = unsafe { bbs_core_verify_batch(self.ctx, n, sg.as_ptr(), ms.as_ptr(), mo.as_ptr(), hb.as_ptr(), ho.as_ptr(), st.as_mut_ptr()) };   // step 12
+        assert_eq!(rc, 0, "bbs_core_verify_batch: {rc}");
+        st.into_iter().map(|s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(signature_error(e)) }).collect()
+    }
+
+    /// `proof_gen` (src/proof_gen.rs:78-113) for n items.  The random scalars are drawn here exactly as the reference does
+    /// (`calculate_random_scalars(5 + l - r)`, proof_gen.rs:145-149, with r the UN-deduplicated number of indexes) and
+    /// passed in, so the engine stays deterministic.
+    pub fn proof_gen(&self, signatures: &[Signature<E, F>], headers: &[&[u8]], phs: &[&[u8]], messages: &[&[&[u8]]],
+                     disclosed_indexes: &[&[usize]]) -> Vec<Result<Proof<E, F>, ProofGenError>> {
+        let n = signatures.len();
+        let sg = self.put_signatures(signatures);
+        let (ms, mo) = self.msg_to_scalars(messages);
+        let (hb, ho) = ragged(headers);
+        let (pb, po) = ragged(phs);
+        let (mut di, mut dio, mut rs, mut ro) = (Vec::new(), vec![0u64], Vec::new(), vec![0u64]);
+        for i in 0..n {
+            di.extend(disclosed_indexes[i].iter().map(|&x| x as u64));
+            dio.push(di.len() as u64);
+            let (l, r) = (messages[i].len(), disclosed_indexes[i].len());
+            // r > l is the reference's first error (proof_gen.rs:135-137): the engine reports it; draw nothing
+            let count = if r <= l { 5 + l - r } else { 0 };
+            for s in calculate_random_scalars::<48, F>(count) { put_fr(&s, &mut rs); }
+            ro.push((rs.len() / 32) as u64);
+        }
+        let rec = 6 * self.fpb + 128;
+        let total: usize = messages.iter().map(|m| m.len()).sum();
+        let (mut pf, mut cm, mut cmo, mut st) = (vec![0u8; n * rec], vec![0u8; 32 * total.max(1)], vec![0u64; n + 1], vec![0i8; n]);
+        let rc = unsafe {
+            bbs_core_proof_gen_batch(self.ctx, n, sg.as_ptr(), ms.as_ptr(), mo.as_ptr(), di.as_ptr(), dio.as_ptr(), rs.as_ptr(), ro.as_ptr(),
+                                     hb.as_ptr(), ho.as_ptr(), pb.as_ptr(), po.as_ptr(), pf.as_mut_ptr(), cm.as_mut_ptr(), cmo.as_mut_ptr(),
+                                     st.as_mut_ptr())                                               // step 14
+        };
+        assert_eq!(rc, 0, "bbs_core_proof_gen_batch: {rc}");
+        (0..n).map(|i| if st[i] == 1 {
+            let r = &pf[i * rec..(i + 1) * rec];
+            let f = self.fpb;
+            let sc = |k: usize| get_fr::<F>(&r[6 * f + 32 * k..6 * f + 32 * (k + 1)]);
+            Ok(Proof {
+                a_bar: get_g1::<E>(&r[..2 * f], f), b_bar: get_g1::<E>(&r[2 * f..4 * f], f), d: get_g1::<E>(&r[4 * f..6 * f], f),
+                e_cap: sc(0), r1_cap: sc(1), r3_cap: sc(2),
+                commitments: (cmo[i] as usize..cmo[i + 1] as usize).map(|k| get_fr::<F>(&cm[32 * k..32 * (k + 1)])).collect(),
+                challenge: Challenge { scalar: sc(3) },
+            })
+        } else { Err(proof_error(st[i])) }).collect()
+    }
+
+    /// `proof_verify` (src/proof_verify.rs:19-61) for n proofs: the asynchronous form, so that a serving loop keeps
+    /// several batches in flight -- `submit` returns at once, `PendingVerify::wait` yields the n results.
+    pub fn proof_verify_submit(&self, proofs: &[Proof<E, F>], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
+                               disclosed_indexes: &[&[usize]]) -> PendingVerify {
+        let n = proofs.len();
+        let (dm, dmo) = self.msg_to_scalars(disclosed_messages);
+        let (mut fixed, mut cm, mut cmo, mut di, mut dio) = (Vec::new(), Vec::new(), vec![0u64], Vec::new(), vec![0u64]);
         for (i, p) in proofs.iter().enumerate() {
             put_g1::<E>(&p.a_bar, self.fpb, &mut fixed); put_g1::<E>(&p.b_bar, self.fpb, &mut fixed); put_g1::<E>(&p.d, self.fpb, &mut fixed);
-            put_fr(&p.e_cap, &mut fixed); put_fr(&p.r1_cap, &mut fixed); put_fr(&p.r3_cap, &mut fixed); put_fr(&p.challenge, &mut fixed);
+            put_fr(&p.e_cap, &mut fixed); put_fr(&p.r1_cap, &mut fixed); put_fr(&p.r3_cap, &mut fixed); put_fr(&p.challenge.scalar, &mut fixed);
             for c in &p.commitments { put_fr(c, &mut cm); }
-            cm_off.push((cm.len() / 32) as u64);
-            dm_off.push(dm_off[i] + disclosed_msgs[i].len() as u64);
-            di.extend(disclosed_idx[i].iter().map(|&x| x as u64)); di_off.push(di.len() as u64);
-            hb.extend_from_slice(headers[i]); h_off.push(hb.len() as u64);
-            pb.extend_from_slice(phs[i]); p_off.push(pb.len() as u64);
+            cmo.push((cm.len() / 32) as u64);
+            di.extend(disclosed_indexes[i].iter().map(|&x| x as u64));
+            dio.push(di.len() as u64);
         }
-        let mut status = vec![0i8; n];
+        let (hb, ho) = ragged(headers);
+        let (pb, po) = ragged(phs);
+        let mut status = vec![-128i8; n].into_boxed_slice();      // stays valid (heap) until wait()
+        let mut job = std::ptr::null_mut();
         let rc = unsafe {
-            bbs_core_proof_verify_batch(self.ctx, n, fixed.as_ptr(), cm.as_ptr(), cm_off.as_ptr(), dm.as_ptr(), dm_off.as_ptr(),
-                                        di.as_ptr(), di_off.as_ptr(), hb.as_ptr(), h_off.as_ptr(), pb.as_ptr(), p_off.as_ptr(),
-                                        status.as_mut_ptr())
+            bbs_core_proof_verify_submit(self.ctx, n, fixed.as_ptr(), cm.as_ptr(), cmo.as_ptr(), dm.as_ptr(), dmo.as_ptr(), di.as_ptr(),
+                                         dio.as_ptr(), hb.as_ptr(), ho.as_ptr(), pb.as_ptr(), po.as_ptr(), status.as_mut_ptr(), &mut job)   // step 15
         };
-        assert_eq!(rc, 0, "bbs_core_proof_verify_batch: {rc}");
-        status.into_iter().map(status_to_result).collect()
+        assert_eq!(rc, 0, "bbs_core_proof_verify_submit: {rc}");
+        PendingVerify { job, status }                               // the input buffers may be dropped: the library staged them
     }
+
+    /// Synchronous convenience: one batch, wait.
+    pub fn proof_verify(&self, proofs: &[Proof<E, F>], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
+                        disclosed_indexes: &[&[usize]]) -> Vec<Result<bool, ProofGenError>> {
+        self.proof_verify_submit(proofs, headers, phs, disclosed_messages, disclosed_indexes).wait()
+    }
+
+    pub fn messages_per_item(&self) -> usize { self.l }
 }
 
-impl<E: GpuCurve> Drop for GpuIssuer<E> {
-    fn drop(&mut self) { unsafe { bbs_ctx_destroy(self.ctx) } }
+/// A submitted proof_verify batch.
+pub struct PendingVerify { job: *mut BbsJob, status: Box<[i8]> }
+impl PendingVerify {
+    pub fn wait(mut self) -> Vec<Result<bool, ProofGenError>> {
+        let rc = unsafe { bbs_job_wait(self.job) };                                                // step 16
+        unsafe { bbs_job_free(self.job) };                                                         // step 17
+        self.job = std::ptr::null_mut();
+        assert_eq!(rc, 0, "bbs_job_wait: {rc} (-102: an item was left undecided; the library fails closed)");
+        self.status.iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
+    }
+}
+impl Drop for PendingVerify {
+    fn drop(&mut self) { if !self.job.is_null() { unsafe { bbs_job_wait(self.job); bbs_job_free(self.job); } } }
+}
+
+impl<E: GpuCurve, F: PrimeField, C> Drop for GpuIssuer<E, F, C> {
+    fn drop(&mut self) { unsafe { bbs_ctx_destroy(self.ctx) } }                                     // step 18
 }

@@ -1,0 +1,174 @@
+/*
+ * The call sequence of bindings/rust/src/lib.rs (GpuIssuer::new / set_secret_key / set_public_key / sign / verify /
+ * proof_gen / proof_verify_submit / PendingVerify::wait / Drop), argument for argument, from a plain-C client of
+ * include/bbs_sign_amd.h -- so that the ABI the Rust shim binds is exercised by something that is neither Python
+ * (ctypes) nor C++.  No Rust toolchain exists in this image; the step numbers are the ones quoted in the shim.
+ *
+ * What the shim's callers see is checked: statuses of valid items, of tampered items (Ok(false)), of the reference's
+ * Err variants (src/proof_verify.rs:139-150, src/proof_gen.rs:133-143, src/sign.rs:77-79), the round trip
+ * sign -> verify -> proof_gen -> proof_verify, two submitted batches in flight, and that the buffers handed to
+ * bbs_core_proof_verify_submit may be reused as soon as it returns.
+ *
+ * Build (tests/test_ffi_sequence.py): gcc -std=c99 -I include tests/cpp/ffi_sequence.c -l:<library> ; run: ./a.out
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bbs_sign_amd.h"
+
+#define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
+
+enum { L = 3, N = 4 };                 /* messages per item, items per batch */
+
+static const char* SUITE_ID[2] = {"BBS_BLS12381G1_XMD:SHA-256_SSWU_RO_", "BBS_QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_"};
+
+/* the shim's msg_to_scalars(): every message of every item in one bbs_hash_to_scalar_batch call */
+static void msg_to_scalars(bbs_ctx* ctx, const char* api_id, const char* const* msgs, size_t count, uint8_t* out) {
+    uint8_t flat[1024];
+    uint64_t off[64];
+    char dst[160];
+    size_t at = 0;
+    off[0] = 0;
+    for (size_t k = 0; k < count; k++) { memcpy(flat + at, msgs[k], strlen(msgs[k])); at += strlen(msgs[k]); off[k + 1] = at; }
+    snprintf(dst, sizeof dst, "%sMAP_MSG_TO_SCALAR_AS_HASH_", api_id);
+    CHECK(bbs_hash_to_scalar_batch(ctx, count, flat, off, (const uint8_t*)dst, strlen(dst), out) == BBS_OK);           /* step 10 */
+}
+
+static int run_curve(int curve) {
+    const size_t fpb = bbs_fp_bytes(curve);                                                                             /* step 1 */
+    const size_t sig_rec = 2 * fpb + 32, pf_rec = 6 * fpb + 128;
+    char api_id[128];
+    snprintf(api_id, sizeof api_id, "%sH2G_HM2S_", SUITE_ID[curve]);
+    const size_t alen = strlen(api_id);
+
+    uint8_t* gens = calloc(L + 1, 2 * fpb);
+    CHECK(bbs_create_generators(curve, L + 1, (const uint8_t*)api_id, alen, gens) == BBS_OK);                            /* step 2 */
+    bbs_ctx* ctx = NULL;
+    CHECK(bbs_ctx_create(curve, 0, &ctx) == BBS_OK && ctx);                                                              /* step 3 */
+    CHECK(bbs_ctx_set_window_bits(ctx, 5) == BBS_OK);                                                                    /* step 4 */
+    CHECK(bbs_ctx_set_generators(ctx, gens, L + 1, (const uint8_t*)api_id, alen) == BBS_OK);                             /* step 5 */
+    CHECK(bbs_ctx_set_points_in_subgroup(ctx, 1) == BBS_OK);                                                             /* step 6 */
+
+    uint8_t ikm[32], sk[32];
+    memset(ikm, 7, sizeof ikm);
+    CHECK(bbs_key_gen(curve, ikm, 32, NULL, 0, (const uint8_t*)"BBS-SIG-KEYGEN-SALT-", 20, sk) == BBS_OK);               /* step 7 */
+    CHECK(bbs_ctx_set_secret_key(ctx, sk) == BBS_OK);                                                                    /* step 8 */
+    uint8_t pk[4 * 48];
+    int pk_inf = -1;
+    CHECK(bbs_ctx_get_public_key(ctx, pk, &pk_inf) == BBS_OK && pk_inf == 0);                                            /* step 9 */
+    /* a verifier-side context: public key only (GpuIssuer::set_public_key) */
+    bbs_ctx* vctx = NULL;
+    CHECK(bbs_ctx_create(curve, 0, &vctx) == BBS_OK);
+    CHECK(bbs_ctx_set_window_bits(vctx, 5) == BBS_OK);
+    CHECK(bbs_ctx_set_generators(vctx, gens, L + 1, (const uint8_t*)api_id, alen) == BBS_OK);
+    CHECK(bbs_ctx_set_points_in_subgroup(vctx, 1) == BBS_OK);
+    CHECK(bbs_ctx_set_public_key(vctx, pk, 0) == BBS_OK);
+
+    /* ---- SecretKey::sign for N items; the last item has L - 1 messages (SignatureError) -------------------------- */
+    const char* raw[N * L] = {"message1", "message2", "msg3", "a", "", "ccc", "x1", "x2", "x3", "only-two", "here", NULL};
+    const size_t n_msgs = N * L - 1;
+    uint8_t scal[N * L * 32];
+    msg_to_scalars(ctx, api_id, raw, n_msgs, scal);
+    uint64_t mo[N + 1] = {0, L, 2 * L, 3 * L, 4 * L - 1};
+    const uint8_t hdr_bytes[] = "hdr0hdr-two";
+    uint64_t ho[N + 1] = {0, 4, 4, 11, 11};                 /* item 1 and 3: empty header */
+    uint8_t sigs[N * (2 * 48 + 32)];
+    int8_t st[N];
+    memset(st, 99, sizeof st);
+    CHECK(bbs_core_sign_batch(ctx, N, scal, mo, hdr_bytes, ho, sigs, st) == BBS_OK);                                     /* step 11 */
+    CHECK(st[0] == 1 && st[1] == 1 && st[2] == 1 && st[3] == BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH);
+
+    /* ---- PublicKey::verify: items 0..2; item 1's first message altered -> Ok(false) ------------------------------- */
+    uint8_t scal_v[3 * L * 32];
+    memcpy(scal_v, scal, sizeof scal_v);
+    scal_v[L * 32] ^= 1;
+    memset(st, 99, sizeof st);
+    CHECK(bbs_core_verify_batch(vctx, 3, sigs, scal_v, mo, hdr_bytes, ho, st) == BBS_OK);                                /* step 12 */
+    CHECK(st[0] == 1 && st[1] == 0 && st[2] == 1);
+
+    /* ---- proof_gen: disclosed {0, 2}, {1}, {} ; item 3 (copy of item 0) discloses index L -> InvalidDisclosedIndex - */
+    uint8_t sig4[N * (2 * 48 + 32)], scal4[N * L * 32];
+    memcpy(sig4, sigs, 3 * sig_rec); memcpy(sig4 + 3 * sig_rec, sigs, sig_rec);
+    memcpy(scal4, scal, 3 * L * 32); memcpy(scal4 + 3 * L * 32, scal, L * 32);
+    uint64_t mo4[N + 1] = {0, L, 2 * L, 3 * L, 4 * L};
+    uint64_t di[] = {0, 2, 1, L};
+    uint64_t dio[N + 1] = {0, 2, 3, 3, 4};
+    /* random scalars: what calculate_random_scalars does -- 48 random bytes through FromOkm (step 13) */
+    uint8_t rnd[N * (5 + L) * 32];
+    uint64_t ro[N + 1];
+    size_t nr = 0;
+    uint32_t lcg = 12345u + (uint32_t)curve;
+    ro[0] = 0;
+    for (int i = 0; i < N; i++) {
+        const size_t r = (size_t)(dio[i + 1] - dio[i]);
+        for (size_t k = 0; k < 5 + L - r; k++) {
+            uint8_t okm[48];
+            for (int b = 0; b < 48; b++) { lcg = lcg * 1664525u + 1013904223u; okm[b] = (uint8_t)(lcg >> 24); }
+            CHECK(bbs_scalar_from_okm(curve, okm, rnd + 32 * nr) == BBS_OK);                                             /* step 13 */
+            nr++;
+        }
+        ro[i + 1] = nr;
+    }
+    const uint8_t ph_bytes[] = "ph";
+    uint64_t po[N + 1] = {0, 2, 2, 2, 2};
+    uint64_t ho4[N + 1] = {0, 4, 4, 11, 15};
+    const uint8_t hdr4[] = "hdr0hdr-twohdr0";
+    uint8_t* pf = calloc(N, pf_rec);
+    uint8_t cm[N * L * 32];
+    uint64_t cmo[N + 1];
+    memset(st, 99, sizeof st);
+    CHECK(bbs_core_proof_gen_batch(vctx, N, sig4, scal4, mo4, di, dio, rnd, ro, hdr4, ho4, ph_bytes, po, pf, cm, cmo, st) == BBS_OK);   /* step 14 */
+    CHECK(st[0] == 1 && st[1] == 1 && st[2] == 1 && st[3] == BBS_ST_INVALID_DISCLOSED_INDEX);
+    CHECK(cmo[0] == 0 && cmo[1] == 1 && cmo[2] == 3 && cmo[3] == 6 && cmo[4] == 6);
+
+    /* ---- proof_verify: two batches submitted before either is waited for ------------------------------------------ */
+    /* batch A: items 0..2 as generated.  batch B: item 0 with a commitment altered (Ok(false)), item 1 with an index
+     * >= l (InvalidDisclosedIndex), item 2 with one disclosed message too many (InvalidIndicesAndMessagesLength) */
+    uint8_t dm[4 * 32];
+    memcpy(dm, scal + 0 * 32, 32); memcpy(dm + 32, scal + 2 * 32, 32); memcpy(dm + 64, scal + (L + 1) * 32, 32);
+    uint64_t dmo[4] = {0, 2, 3, 3};
+    uint64_t dio3[4] = {0, 2, 3, 3};
+    int8_t stA[3], stB[3];
+    memset(stA, 99, 3); memset(stB, 99, 3);
+    bbs_job *jobA = NULL, *jobB = NULL;
+    CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph_bytes, po, stA, &jobA) == BBS_OK && jobA);   /* step 15 */
+    uint8_t* cmB = malloc(sizeof cm);
+    memcpy(cmB, cm, sizeof cm);
+    cmB[0] ^= 1;
+    uint64_t diB[] = {0, 2, L + 4};
+    memcpy(dm + 96, scal, 32);
+    uint64_t dmoB[4] = {0, 2, 3, 4};
+    CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cmB, cmo, dm, dmoB, diB, dio3, hdr4, ho4, ph_bytes, po, stB, &jobB) == BBS_OK && jobB);
+    memset(cmB, 0xEE, sizeof cm);                    /* inputs were staged by the call: the caller may reuse its buffers */
+    free(cmB);
+    CHECK(bbs_job_wait(jobA) == BBS_OK);                                                                                 /* step 16 */
+    CHECK(bbs_job_wait(jobB) == BBS_OK);
+    bbs_job_free(jobA);                                                                                                  /* step 17 */
+    bbs_job_free(jobB);
+    CHECK(stA[0] == 1 && stA[1] == 1 && stA[2] == 1);
+    CHECK(stB[0] == 0 && stB[1] == BBS_ST_INVALID_DISCLOSED_INDEX && stB[2] == BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH);
+    /* the synchronous form returns the same */
+    int8_t stC[3];
+    CHECK(bbs_core_proof_verify_batch(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph_bytes, po, stC) == BBS_OK);
+    CHECK(stC[0] == 1 && stC[1] == 1 && stC[2] == 1);
+    /* a different presentation header must fail */
+    const uint8_t ph2[] = "pX";
+    CHECK(bbs_core_proof_verify_batch(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph2, po, stC) == BBS_OK);
+    CHECK(stC[0] == 0 && stC[1] == 1 && stC[2] == 1);     /* only item 0 carries a presentation header */
+
+    bbs_ctx_destroy(vctx);                                                                                               /* step 18 */
+    bbs_ctx_destroy(ctx);
+    free(gens); free(pf);
+    printf("curve %d: ffi sequence ok\n", curve);
+    return 0;
+}
+
+int main(void) {
+    printf("%s\n", bbs_version());
+    run_curve(BBS_CURVE_BLS12_381);
+    run_curve(BBS_CURVE_BN254);
+    printf("all checks passed\n");
+    return 0;
+}

@@ -54,17 +54,18 @@ def disassemble(co):
 
 
 def loop_mask(insts):
-    """True for instructions inside a backward-branch loop of this symbol."""
+    """True for instructions inside a backward-branch loop of this symbol (target = pc + 4 + 4 * simm16)."""
     addr_index = {a: i for i, (a, _, _) in enumerate(insts)}
     inside = [False] * len(insts)
     for i, (a, op, args) in enumerate(insts):
         if op.startswith("s_cbranch") or op == "s_branch":
-            m = re.search(r"<.*\+0x([0-9a-f]+)>|<[^+>]+>$", args)
-            # objdump prints the target as  <symbol+0xOFF>  after the encoded offset
-            t = re.search(r"\+0x([0-9a-f]+)>", args)
-            if t is None:
+            try:
+                imm = int(args.split()[0])
+            except (ValueError, IndexError):
                 continue
-            target = insts[0][0] + int(t.group(1), 16)
+            if imm >= 0x8000:
+                imm -= 0x10000
+            target = a + 4 + 4 * imm
             if target <= a and target in addr_index:
                 for k in range(addr_index[target], i + 1):
                     inside[k] = True
