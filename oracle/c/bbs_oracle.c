@@ -1,6 +1,9 @@
 /*
  * ORACLE (test infrastructure, see oracle/__init__.py) -- plain-C restatement of the reference's
- * BLS12-381 path, 64-bit limbs, reference operation order.  Used (a) as the CPU baseline of
+ * path, 64-bit limbs, reference operation order.  One source, two builds: BLS12-381 (default) and BN254 (-DORC_BN254:
+ * 4-limb Fp, xi = 9 + u, D-type twist, Miller loop over 6x + 2 plus the two Frobenius line steps, Devegili-Scott-Dahab
+ * hard part, ark-serialize's little-endian compressed encodings -- the BN254 byte formats rest on crate knowledge, see
+ * the reference holds no BN254 byte vector).  Used (a) as the CPU baseline of
  * bench.py (`cpu_baseline.kind = "port"`), (b) to check FULL 4096-item GPU batches item by item.
  * It is pinned against the pure-Python oracle (itself pinned by the reference's known-answer
  * vectors) in tests/test_oracle_c.py.  Never linked into the product.
@@ -23,11 +26,19 @@ typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
 /* ------------------------------------------------------------------ Fp (6 limbs) / Fr (4 limbs) */
+#ifdef ORC_BN254
+#define NP 4
+#define NR 4
+static const u64 P[NP] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 RM[NR] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+#else
 #define NP 6
 #define NR 4
 static const u64 P[NP] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
                           0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
 static const u64 RM[NR] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+#endif
+#define FPB (8 * NP)                 /* bytes of a canonical Fp element */
 static u64 P_INV, R_INV;            /* -m^-1 mod 2^64 */
 static u64 P_R2[NP], P_ONE[NP], R_R2[NR], R_ONE[NR], R_R3[NR];
 
@@ -112,8 +123,8 @@ static fp fp_pow(fp a, const u64* e, int n) {
 static fp fp_inv(fp a) { u64 e[NP]; memcpy(e, P, sizeof e); e[0] -= 2; return fp_pow(a, e, NP); }
 static fp fp_from_raw(const u64* w) { fp a, r2; memcpy(a.v, w, sizeof a.v); memcpy(r2.v, P_R2, sizeof r2.v); return fp_mul(a, r2); }
 static void fp_to_raw(fp a, u64* w) { fp one; memset(&one, 0, sizeof one); one.v[0] = 1; fp r = fp_mul(a, one); memcpy(w, r.v, sizeof r.v); }
-static fp fp_from_le(const uint8_t* b) { u64 w[NP]; memcpy(w, b, 48); return fp_from_raw(w); }
-static void fp_to_le(fp a, uint8_t* b) { u64 w[NP]; fp_to_raw(a, w); memcpy(b, w, 48); }
+static fp fp_from_le(const uint8_t* b) { u64 w[NP]; memcpy(w, b, FPB); return fp_from_raw(w); }
+static void fp_to_le(fp a, uint8_t* b) { u64 w[NP]; fp_to_raw(a, w); memcpy(b, w, FPB); }
 
 static fr fr_mul(fr a, fr b) { fr r; mont_mul(r.v, a.v, b.v, RM, R_INV, NR); return r; }
 static fr fr_add(fr a, fr b) { fr r; mod_add(r.v, a.v, b.v, RM, NR); return r; }
@@ -136,7 +147,7 @@ static void init_consts(void) {
     if (done) return;
     P_INV = neg_inv64(P[0]); R_INV = neg_inv64(RM[0]);
     /* R mod m and R^2 mod m by repeated doubling */
-    u64 t[NP] = {1, 0, 0, 0, 0, 0};
+    u64 t[NP] = {1};
     for (int i = 0; i < 2 * 64 * NP; i++) { mod_add(t, t, t, P, NP); if (i == 64 * NP - 1) memcpy(P_ONE, t, sizeof t); }
     memcpy(P_R2, t, sizeof t);
     u64 s[NR] = {1, 0, 0, 0};
@@ -170,7 +181,12 @@ static fp2 f2_mul(fp2 a, fp2 b) {
 }
 static fp2 f2_sqr(fp2 a) { return f2_mul(a, a); }
 static fp2 f2_mul_fp(fp2 a, fp s) { fp2 r = {fp_mul(a.c0, s), fp_mul(a.c1, s)}; return r; }
+#ifdef ORC_BN254
+static fp fp_mul9(fp a) { fp t = fp_dbl(fp_dbl(fp_dbl(a))); return fp_add(t, a); }
+static fp2 f2_mul_xi(fp2 a) { fp2 r = {fp_sub(fp_mul9(a.c0), a.c1), fp_add(fp_mul9(a.c1), a.c0)}; return r; }   /* xi = 9 + u */
+#else
 static fp2 f2_mul_xi(fp2 a) { fp2 r = {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; return r; }   /* xi = 1 + u */
+#endif
 static fp2 f2_inv(fp2 a) {
     fp n = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
     fp2 r = {fp_mul(a.c0, n), fp_neg(fp_mul(a.c1, n))};
@@ -230,7 +246,7 @@ static void init_frob(void) {
     u64 e[NP]; memcpy(e, P, sizeof e); e[0] -= 1;
     u128 rem = 0;
     for (int i = NP - 1; i >= 0; i--) { u128 cur = (rem << 64) | e[i]; e[i] = (u64)(cur / 6); rem = cur % 6; }
-    fp2 xi = {fp_one(), fp_one()};
+    fp2 xi = f2_mul_xi(f2_one());
     fp2 g = f2_pow_u64s(xi, e, NP);
     FROB1[0] = f2_one();
     for (int i = 1; i < 6; i++) FROB1[i] = f2_mul(FROB1[i - 1], g);
@@ -303,14 +319,14 @@ static g1j g1_mul(g1j p, fr k) {
 }
 static g1a g1a_from_le(const uint8_t* b) {
     g1a r; int z = 1;
-    for (int i = 0; i < 96; i++) if (b[i]) z = 0;
+    for (int i = 0; i < 2 * FPB; i++) if (b[i]) z = 0;
     r.inf = z;
-    r.x = fp_from_le(b); r.y = fp_from_le(b + 48);
+    r.x = fp_from_le(b); r.y = fp_from_le(b + FPB);
     return r;
 }
 static void g1a_to_le(g1a p, uint8_t* b) {
-    if (p.inf) { memset(b, 0, 96); return; }
-    fp_to_le(p.x, b); fp_to_le(p.y, b + 48);
+    if (p.inf) { memset(b, 0, 2 * FPB); return; }
+    fp_to_le(p.x, b); fp_to_le(p.y, b + FPB);
 }
 static int fp_gt_half(fp a) {             /* canonical a > (p-1)/2 */
     u64 w[NP], h[NP]; fp_to_raw(a, w);
@@ -320,6 +336,13 @@ static int fp_gt_half(fp a) {             /* canonical a > (p-1)/2 */
     for (int i = NP - 1; i >= 0; i--) { if (w[i] > h[i]) return 1; if (w[i] < h[i]) return 0; }
     return 0;
 }
+#ifdef ORC_BN254
+static void g1_compress(g1a p, uint8_t* out) {      /* ark-serialize: 32 B little-endian x, flags in the LAST byte */
+    if (p.inf) { memset(out, 0, FPB); out[FPB - 1] = 0x40; return; }
+    fp_to_le(p.x, out);
+    if (fp_gt_half(p.y)) out[FPB - 1] |= 0x80;
+}
+#else
 static void g1_compress(g1a p, uint8_t* out) {      /* 48 B big-endian, flags in the first byte */
     if (p.inf) { memset(out, 0, 48); out[0] = 0xC0; return; }
     uint8_t le[48]; fp_to_le(p.x, le);
@@ -327,6 +350,7 @@ static void g1_compress(g1a p, uint8_t* out) {      /* 48 B big-endian, flags in
     out[0] |= 0x80;
     if (fp_gt_half(p.y)) out[0] |= 0x20;
 }
+#endif
 
 /* ----------------------------------------------------------------------------------- G2 */
 typedef struct { fp2 x, y; int inf; } g2a;
@@ -356,9 +380,17 @@ static g2a g2_mul(g2a q, fr k) {
 }
 static g2a g2a_from_le(const uint8_t* b, int inf) {
     g2a r; r.inf = inf;
-    r.x.c0 = fp_from_le(b); r.x.c1 = fp_from_le(b + 48); r.y.c0 = fp_from_le(b + 96); r.y.c1 = fp_from_le(b + 144);
+    r.x.c0 = fp_from_le(b); r.x.c1 = fp_from_le(b + FPB); r.y.c0 = fp_from_le(b + 2 * FPB); r.y.c1 = fp_from_le(b + 3 * FPB);
     return r;
 }
+#ifdef ORC_BN254
+static void g2_compress(g2a q, uint8_t* out) {      /* x.c0 || x.c1 little-endian, flags in the last byte */
+    if (q.inf) { memset(out, 0, 2 * FPB); out[2 * FPB - 1] = 0x40; return; }
+    fp_to_le(q.x.c0, out); fp_to_le(q.x.c1, out + FPB);
+    int big = fp_is_zero(q.y.c1) ? fp_gt_half(q.y.c0) : fp_gt_half(q.y.c1);
+    if (big) out[2 * FPB - 1] |= 0x80;
+}
+#else
 static void g2_compress(g2a q, uint8_t* out) {      /* x.c1 || x.c0 big-endian, flags first byte */
     if (q.inf) { memset(out, 0, 96); out[0] = 0xC0; return; }
     uint8_t le[48];
@@ -368,9 +400,14 @@ static void g2_compress(g2a q, uint8_t* out) {      /* x.c1 || x.c0 big-endian, 
     int big = fp_is_zero(q.y.c1) ? fp_gt_half(q.y.c0) : fp_gt_half(q.y.c1);
     if (big) out[0] |= 0x20;
 }
+#endif
 
 /* ------------------------------------------------------------------------------- pairing */
+#ifdef ORC_BN254
+#define X_ABS 0x44e992b44a6909f1ULL            /* x = 4965661367192848881 > 0 */
+#else
 #define X_ABS 0xd201000000010000ULL
+#endif
 /* Miller loop with homogeneous projective G2 steps (no inversions).  Lines are scaled by factors in
  * Fp2 (killed by the final exponentiation); M-type twist, line * w^3 = l0 + l1 v + l4 v w:
  *   tangent at T = (X, Y, Z):  l0 = 3 X^3 - 2 Y^2 Z,  l1 = -3 X^2 Z xP,  l4 = 2 Y Z^2 yP
@@ -379,7 +416,13 @@ static void g2_compress(g2a q, uint8_t* out) {      /* x.c1 || x.c0 big-endian, 
 typedef struct { fp2 x, y, z; } g2p;
 static fp12 line_val(fp2 l0, fp2 l1, fp2 l4) {
     fp12 l; memset(&l, 0, sizeof l);
+#ifdef ORC_BN254
+    /* D-type twist: the same three values sit at  yP-term w^0,  xP-term w^1,  constant term w^3
+     * (l = yP + (-lambda xP) w + (lambda xT - yT) w^3, scaled by the same Fp2 factor as below) */
+    l.c0.c0 = l4; l.c1.c0 = l1; l.c1.c1 = l0;
+#else
     l.c0.c0 = l0; l.c0.c1 = l1; l.c1.c1 = l4;
+#endif
     return l;
 }
 static void dbl_step(fp12* f, g2p* T, g1a Pt) {
@@ -420,6 +463,26 @@ static void add_step(fp12* f, g2p* T, g2a Q, g1a Pt) {
     r.z = f2_mul(vvv, T->z);
     *T = r;
 }
+#ifdef ORC_BN254
+static fp2 G2FROB_X, G2FROB_Y;                 /* xi^((p-1)/3), xi^((p-1)/2): p-power Frobenius on the D-twist */
+static g2a g2_frob(g2a q) { g2a r = q; r.x = f2_mul(f2_conj(q.x), G2FROB_X); r.y = f2_mul(f2_conj(q.y), G2FROB_Y); return r; }
+static fp12 miller_loop(g1a Pt, g2a Q) {
+    fp12 f = f12_one();
+    if (Pt.inf || Q.inf) return f;            /* ark-ec skips identity pairs */
+    g2p T = {Q.x, Q.y, f2_one()};
+    /* optimal ate: loop over 6x + 2 = 0x1 9d797039be763ba8 (65 bits), then the lines through pi(Q) and -pi^2(Q) */
+    const u64 lo = 0x9d797039be763ba8ULL;
+    for (int i = 63; i >= 0; i--) {
+        f = f12_sqr(f);
+        dbl_step(&f, &T, Pt);
+        if ((lo >> i) & 1) add_step(&f, &T, Q, Pt);
+    }
+    g2a Q1 = g2_frob(Q), Q2 = g2_neg(g2_frob(Q1));
+    add_step(&f, &T, Q1, Pt);
+    add_step(&f, &T, Q2, Pt);
+    return f;
+}
+#else
 static fp12 miller_loop(g1a Pt, g2a Q) {
     fp12 f = f12_one();
     if (Pt.inf || Q.inf) return f;            /* ark-ec skips identity pairs */
@@ -431,6 +494,7 @@ static fp12 miller_loop(g1a Pt, g2a Q) {
     }
     return f12_conj(f);                        /* x < 0 */
 }
+#endif
 static fp12 f12_pow_big(fp12 a, const u64* e, int n) {
     fp12 r = f12_one();
     int started = 0;
@@ -441,6 +505,36 @@ static fp12 f12_pow_big(fp12 a, const u64* e, int n) {
     return r;
 }
 static void init_hard_exp(void) {}
+#ifdef ORC_BN254
+static fp12 f12_pow_x(fp12 a) {                /* a^x, x > 0 */
+    fp12 r = a;
+    for (int i = 61; i >= 0; i--) { r = f12_sqr(r); if ((X_ABS >> i) & 1) r = f12_mul(r, a); }
+    return r;
+}
+/* f^((p^12-1)/r): easy part, then the hard part (p^4-p^2+1)/r by the Devegili-Scott-Dahab chain
+ * y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36 (f unitary after the easy part: inverse = conjugate) */
+static fp12 final_exp(fp12 f) {
+    fp12 t = f12_mul(f12_conj(f), f12_inv(f));                    /* ^(p^6 - 1) */
+    t = f12_mul(f12_frob(f12_frob(t)), t);                        /* ^(p^2 + 1) */
+    fp12 fu = f12_pow_x(t), fu2 = f12_pow_x(fu), fu3 = f12_pow_x(fu2);
+    fp12 tp = f12_frob(t), tp2 = f12_frob(tp), tp3 = f12_frob(tp2);
+    fp12 y0 = f12_mul(f12_mul(tp, tp2), tp3);
+    fp12 y1 = f12_conj(t);
+    fp12 y2 = f12_frob(f12_frob(fu2));
+    fp12 y3 = f12_conj(f12_frob(fu));
+    fp12 y4 = f12_conj(f12_mul(fu, f12_frob(fu2)));
+    fp12 y5 = f12_conj(fu2);
+    fp12 y6 = f12_conj(f12_mul(fu3, f12_frob(fu3)));
+    fp12 t0 = f12_sqr(y6);
+    t0 = f12_mul(t0, y4); t0 = f12_mul(t0, y5);
+    fp12 t1 = f12_mul(y3, y5);
+    t1 = f12_mul(t1, t0); t0 = f12_mul(t0, y2);
+    t1 = f12_sqr(t1); t1 = f12_mul(t1, t0); t1 = f12_sqr(t1);
+    t0 = f12_mul(t1, y1); t1 = f12_mul(t1, y0);
+    t0 = f12_sqr(t0);
+    return f12_mul(t0, t1);
+}
+#else
 static fp12 f12_pow_x(fp12 a) {                /* a^x, x = -X_ABS, a unitary */
     fp12 r = a;
     for (int i = 62; i >= 0; i--) { r = f12_sqr(r); if ((X_ABS >> i) & 1) r = f12_mul(r, a); }
@@ -458,6 +552,7 @@ static fp12 final_exp(fp12 f) {
     c = f12_mul(c, f12_conj(b));
     return f12_mul(c, f12_mul(f12_sqr(t), t));
 }
+#endif
 static fp12 pairing(g1a Pt, g2a Q) { return final_exp(miller_loop(Pt, Q)); }
 
 /* ------------------------------------------------------------------------------- SHA-256 */
@@ -534,9 +629,34 @@ static void bput(buf* b, const void* s, size_t n) {
 }
 static void bput_u64be(buf* b, u64 v) { uint8_t t[8]; for (int i = 0; i < 8; i++) t[i] = (uint8_t)(v >> (56 - 8 * i)); bput(b, t, 8); }
 static void bput_fr(buf* b, fr x) { uint8_t t[32]; fr_to_be(x, t); bput(b, t, 32); }
-static void bput_g1(buf* b, g1j p) { uint8_t t[48]; g1_compress(g1j_to_aff(p), t); bput(b, t, 48); }
+static void bput_g1(buf* b, g1j p) { uint8_t t[FPB]; g1_compress(g1j_to_aff(p), t); bput(b, t, FPB); }
 
 static g1j P1_PT;
+#ifdef ORC_BN254
+static void div_small(u64* e, u64 d) { u128 rem = 0; for (int i = NP - 1; i >= 0; i--) { u128 cur = (rem << 64) | e[i]; e[i] = (u64)(cur / d); rem = cur % d; } }
+static void init_all(void) {
+    static int done = 0;
+    if (done) return;
+    init_consts(); init_frob(); init_hard_exp();
+    u64 three[NP] = {3}; FP_B = fp_from_raw(three);
+    static const u64 g2x0[NP] = {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL};
+    static const u64 g2x1[NP] = {0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL};
+    static const u64 g2y0[NP] = {0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL};
+    static const u64 g2y1[NP] = {0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL};
+    G2_GEN.inf = 0; G2_GEN.x.c0 = fp_from_raw(g2x0); G2_GEN.x.c1 = fp_from_raw(g2x1); G2_GEN.y.c0 = fp_from_raw(g2y0); G2_GEN.y.c1 = fp_from_raw(g2y1);
+    /* P1 (src/constants.rs:39-51), the affine coordinates the reference hard-codes */
+    static const u64 p1x[NP] = {0x098204f045e61adeULL, 0x0db2146c9bde3376ULL, 0x7ce8f44e877c5f6cULL, 0x111c0a273f09aa94ULL};
+    static const u64 p1y[NP] = {0xb420b35cc0ef2fa7ULL, 0x6fb06e2ad7890eaaULL, 0xdec23067d05d165dULL, 0x124050fe34102928ULL};
+    g1a p1; p1.inf = 0; p1.x = fp_from_raw(p1x); p1.y = fp_from_raw(p1y);
+    P1_PT = g1j_from_aff(p1);
+    fp2 xi = f2_mul_xi(f2_one());
+    u64 e[NP]; memcpy(e, P, sizeof e); e[0] -= 1; div_small(e, 3);
+    G2FROB_X = f2_pow_u64s(xi, e, NP);
+    memcpy(e, P, sizeof e); e[0] -= 1; div_small(e, 2);
+    G2FROB_Y = f2_pow_u64s(xi, e, NP);
+    done = 1;
+}
+#else
 static void init_all(void) {
     static int done = 0;
     if (done) return;
@@ -560,14 +680,15 @@ static void init_all(void) {
     P1_PT = g1j_from_aff(p1);
     done = 1;
 }
+#endif
 
 typedef struct { int L; g1j* gens; const uint8_t* api_id; size_t alen; } gen_ctx;
 
 /* calculate_domain, core_utilities.rs:24-63 */
 static int calc_domain(g2a pk, const gen_ctx* g, const uint8_t* hdr, size_t hlen, fr* out) {
     buf b = {0};
-    uint8_t t[96];
-    g2_compress(pk, t); bput(&b, t, 96);
+    uint8_t t[2 * FPB];
+    g2_compress(pk, t); bput(&b, t, 2 * FPB);
     bput_u64be(&b, (u64)g->L);
     for (int i = 0; i <= g->L; i++) bput_g1(&b, g->gens[i]);
     bput(&b, g->api_id, g->alen);
@@ -599,15 +720,16 @@ static g1j compute_b(const gen_ctx* g, fr domain, const fr* msgs) {   /* sign.rs
 static gen_ctx make_ctx(int L, const uint8_t* gens_le, const uint8_t* api_id, size_t alen) {
     gen_ctx g; g.L = L; g.api_id = api_id; g.alen = alen;
     g.gens = (g1j*)malloc(sizeof(g1j) * (size_t)(L + 1));
-    for (int i = 0; i <= L; i++) g.gens[i] = g1j_from_aff(g1a_from_le(gens_le + 96 * (size_t)i));
+    for (int i = 0; i <= L; i++) g.gens[i] = g1j_from_aff(g1a_from_le(gens_le + 2 * FPB * (size_t)i));
     return g;
 }
 
 /* ---- exported entry points (ctypes) ---------------------------------------------------------- */
+int orc_fp_bytes(void) { return FPB; }
 void orc_sk_to_pk(const uint8_t* sk32, uint8_t* pk192) {
     init_all();
     g2a pk = g2_mul(G2_GEN, fr_from_le(sk32));
-    fp_to_le(pk.x.c0, pk192); fp_to_le(pk.x.c1, pk192 + 48); fp_to_le(pk.y.c0, pk192 + 96); fp_to_le(pk.y.c1, pk192 + 144);
+    fp_to_le(pk.x.c0, pk192); fp_to_le(pk.x.c1, pk192 + FPB); fp_to_le(pk.y.c0, pk192 + 2 * FPB); fp_to_le(pk.y.c1, pk192 + 3 * FPB);
 }
 
 /* core_sign, sign.rs:63-133.  out: A (96 LE) || e (32 LE).  returns 1, or -20 for the unwrap panic */
@@ -629,7 +751,7 @@ int orc_core_sign(const uint8_t* sk32, int L, const uint8_t* gens_le, const uint
     fr spe = fr_add(sk, e);
     int rc = 1;
     if (fr_is_zero(spe)) rc = -20;
-    else { g1a_to_le(g1j_to_aff(g1_mul(B, fr_inv(spe))), out128); fr_to_le(e, out128 + 96); }
+    else { g1a_to_le(g1j_to_aff(g1_mul(B, fr_inv(spe))), out128); fr_to_le(e, out128 + 2 * FPB); }
     free(m); free(g.gens);
     return rc;
 }
@@ -645,7 +767,7 @@ int orc_core_verify(const uint8_t* pk192, int pk_inf, int L, const uint8_t* gens
     fr domain; calc_domain(pk, &g, hdr, hlen, &domain);
     g1j B = compute_b(&g, domain, m);
     g1a A = g1a_from_le(sig128);
-    fr e = fr_from_le(sig128 + 96);
+    fr e = fr_from_le(sig128 + 2 * FPB);
     g2a q = g2_add(pk, g2_mul(G2_GEN, e));
     fp12 gt = f12_mul(pairing(A, q), pairing(g1j_to_aff(B), g2_neg(G2_GEN)));
     free(m); free(g.gens);
@@ -672,7 +794,7 @@ int orc_core_proof_gen(const uint8_t* pk192, int pk_inf, int L, const uint8_t* g
     for (int j = 0; j < L; j++) if (!isd[j]) und[nu++] = (size_t)j;
     fr domain; calc_domain(pk, &g, hdr, hlen, &domain);
     g1j A = g1j_from_aff(g1a_from_le(sig128));
-    fr e = fr_from_le(sig128 + 96);
+    fr e = fr_from_le(sig128 + 2 * FPB);
     g1j B = compute_b(&g, domain, m);                                  /* proof_init :249-263 */
     g1j D = g1_mul(B, rs[1]);
     g1j Abar = g1_mul(A, fr_mul(rs[0], rs[1]));
@@ -688,11 +810,11 @@ int orc_core_proof_gen(const uint8_t* pk192, int pk_inf, int L, const uint8_t* g
     if (fr_is_zero(rs[1])) rc = -21;
     else {
         fr r3 = fr_inv(rs[1]);                                         /* proof_finalize :346-353 */
-        g1a_to_le(g1j_to_aff(Abar), proof_fixed); g1a_to_le(g1j_to_aff(Bbar), proof_fixed + 96); g1a_to_le(g1j_to_aff(D), proof_fixed + 192);
-        fr_to_le(fr_add(rs[2], fr_mul(e, c)), proof_fixed + 288);
-        fr_to_le(fr_sub(rs[3], fr_mul(rs[0], c)), proof_fixed + 320);
-        fr_to_le(fr_sub(rs[4], fr_mul(r3, c)), proof_fixed + 352);
-        fr_to_le(c, proof_fixed + 384);
+        g1a_to_le(g1j_to_aff(Abar), proof_fixed); g1a_to_le(g1j_to_aff(Bbar), proof_fixed + 2 * FPB); g1a_to_le(g1j_to_aff(D), proof_fixed + 4 * FPB);
+        fr_to_le(fr_add(rs[2], fr_mul(e, c)), proof_fixed + 6 * FPB);
+        fr_to_le(fr_sub(rs[3], fr_mul(rs[0], c)), proof_fixed + 6 * FPB + 32);
+        fr_to_le(fr_sub(rs[4], fr_mul(r3, c)), proof_fixed + 6 * FPB + 64);
+        fr_to_le(c, proof_fixed + 6 * FPB + 96);
         for (size_t i = 0; i < U; i++) fr_to_le(fr_add(rs[5 + i], fr_mul(m[und[i]], c)), commitments_le + 32 * i);
     }
     free(m); free(rs); free(isd); free(und); free(dm); free(g.gens);
@@ -707,8 +829,8 @@ int orc_core_proof_verify(const uint8_t* pk192, int pk_inf, int L, const uint8_t
     gen_ctx g = make_ctx(L, gens_le, api_id, alen);
     g2a pk = g2a_from_le(pk192, pk_inf);
     size_t U = (size_t)L - R;
-    g1j Abar = g1j_from_aff(g1a_from_le(proof_fixed)), Bbar = g1j_from_aff(g1a_from_le(proof_fixed + 96)), D = g1j_from_aff(g1a_from_le(proof_fixed + 192));
-    fr e_cap = fr_from_le(proof_fixed + 288), r1_cap = fr_from_le(proof_fixed + 320), r3_cap = fr_from_le(proof_fixed + 352), c = fr_from_le(proof_fixed + 384);
+    g1j Abar = g1j_from_aff(g1a_from_le(proof_fixed)), Bbar = g1j_from_aff(g1a_from_le(proof_fixed + 2 * FPB)), D = g1j_from_aff(g1a_from_le(proof_fixed + 4 * FPB));
+    fr e_cap = fr_from_le(proof_fixed + 6 * FPB), r1_cap = fr_from_le(proof_fixed + 6 * FPB + 32), r3_cap = fr_from_le(proof_fixed + 6 * FPB + 64), c = fr_from_le(proof_fixed + 6 * FPB + 96);
     fr* dm = (fr*)malloc(sizeof(fr) * (R + 1));
     for (size_t k = 0; k < R; k++) dm[k] = fr_from_le(dmsgs_le + 32 * k);
     uint8_t* isd = (uint8_t*)calloc((size_t)L + 1, 1);

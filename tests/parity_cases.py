@@ -703,15 +703,16 @@ def check_mixed_curves_in_flight(lib_path=None, n=1024, per_curve=3, rounds=4):
         j.free()
 
 
-def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None):
+def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, curve="bls12_381"):
     """EVERY item of a BASELINE-shaped batch against the plain-C oracle (oracle/c), bit for bit:
     signatures, proofs and proof_verify booleans incl. corrupted items."""
     import concurrent.futures as cf
     import os
     from oracle import c_port
-    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload("bls12_381", n, L, R, lib_path, window_bits)
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, L, R, lib_path, window_bits)
     c = suite.curve
     api_id = suite.api_id
+    c_port = c_port.port(curve)
     pk = c_port.sk_to_pk(sk)
     sigs, st = eng.core_sign_batch(msgs)
     assert (st == 1).all()

@@ -58,3 +58,51 @@ def test_c_matches_python_oracle_random():
         forged = bbs.Proof(None, proof.b_bar, proof.d, proof.e_cap, proof.r1_cap, proof.r3_cap, proof.commitments, proof.challenge)
         want = bbs.core_proof_verify(S, pk, forged, gens, hdr, ph, dm, disclosed, S.api_id)
         assert c_port.core_proof_verify(pk, forged, gens, hdr, ph, dm, disclosed, S.api_id) == want
+
+
+def test_bn254_c_matches_python_oracle():
+    """The BN254 build of the C restatement (-DORC_BN254: D-type twist, 6x+2 loop with the two Frobenius lines,
+    Devegili-Scott-Dahab hard part, little-endian encodings) against the Python oracle: key, signature, proof bytes,
+    booleans incl. a forged A = identity and a tampered scalar; the reference's one BN254 constant P1
+    (src/constants.rs:39-51) is embedded in the C build and exercised through core_sign."""
+    from oracle.bbs import BN_SUITE as SB
+    from oracle.curves import BN254 as CB
+    P = c_port.port("bn254")
+    rng = random.Random(9)
+    L = 5
+    gens = bbs.synthetic_generators(SB, L + 1)
+    sk = rng.randrange(1, CB.r)
+    pk = P.sk_to_pk(sk)
+    assert pk == bbs.sk_to_pk(SB, sk)
+    for it in range(3):
+        msgs = [rng.randrange(CB.r) for _ in range(L)]
+        hdr = bytes(rng.randrange(256) for _ in range(rng.choice([0, 7, 70])))
+        ph = bytes(rng.randrange(256) for _ in range(rng.choice([0, 33])))
+        disclosed = sorted(rng.sample(range(L), rng.randrange(0, L + 1)))
+        rnd = [rng.randrange(1, CB.r) for _ in range(5 + L - len(disclosed))]
+        sig = P.core_sign(sk, gens, hdr, msgs, SB.api_id)
+        psig = bbs.core_sign(SB, sk, gens, hdr, msgs, SB.api_id)
+        assert (sig.a, sig.e) == (psig.a, psig.e)
+        assert P.core_verify(pk, sig, gens, hdr, msgs, SB.api_id) is True
+        assert P.core_verify(pk, sig, gens, hdr + b"x", msgs, SB.api_id) is False
+        assert P.core_verify(pk, bbs.Signature(None, sig.e), gens, hdr, msgs, SB.api_id) is False
+        proof = P.core_proof_gen(pk, sig, hdr, gens, ph, msgs, disclosed, SB.api_id, rnd)
+        assert proof == bbs.core_proof_gen(SB, pk, psig, hdr, gens, ph, msgs, disclosed, SB.api_id, rnd)
+        dm = [msgs[i] for i in disclosed]
+        assert P.core_proof_verify(pk, proof, gens, hdr, ph, dm, disclosed, SB.api_id) is True
+        bad = bbs.Proof(proof.a_bar, proof.b_bar, proof.d, (proof.e_cap + 1) % CB.r, proof.r1_cap, proof.r3_cap, proof.commitments, proof.challenge)
+        assert P.core_proof_verify(pk, bad, gens, hdr, ph, dm, disclosed, SB.api_id) is False
+        forged = bbs.Proof(None, proof.b_bar, proof.d, proof.e_cap, proof.r1_cap, proof.r3_cap, proof.commitments, proof.challenge)
+        want = bbs.core_proof_verify(SB, pk, forged, gens, hdr, ph, dm, disclosed, SB.api_id)
+        assert P.core_proof_verify(pk, forged, gens, hdr, ph, dm, disclosed, SB.api_id) == want
+    # a proof of a forged signature: the challenge matches, only the pairing product decides (-> false)
+    fsig = bbs.Signature(CB.g1_add(sig.a, CB.g1), sig.e)
+    fp = P.core_proof_gen(pk, fsig, hdr, gens, ph, msgs, disclosed, SB.api_id, rnd)
+    assert P.core_proof_verify(pk, fp, gens, hdr, ph, dm, disclosed, SB.api_id) is False
+
+
+def test_config1_readme_example_bn254():
+    """BASELINE configs[0] (README.md:64-81): BN254, 4 messages, IKM [5u8;32]: sign + verify through the C restatement."""
+    from oracle import c_baseline
+    r = c_baseline.config1(c_port.port("bn254"))
+    assert r["verified"] and r["matches_python_oracle"]

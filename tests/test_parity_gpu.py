@@ -58,9 +58,9 @@ def test_full_batch_4096(curve, window_bits):
     pc.check_big_batch(curve, None, n=4096, L=32, R=8, window_bits=window_bits)
 
 
-@pytest.mark.parametrize("window_bits", [8, 16, 20])
-def test_every_item_against_c_oracle(window_bits):
-    pc.check_batch_vs_c_oracle(None, n=1024, window_bits=window_bits)
+@pytest.mark.parametrize("curve,window_bits", [("bls12_381", 8), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 16)])
+def test_every_item_against_c_oracle(curve, window_bits):
+    pc.check_batch_vs_c_oracle(None, n=1024, window_bits=window_bits, curve=curve)
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
