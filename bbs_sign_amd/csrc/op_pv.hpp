@@ -79,6 +79,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     PvArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
+    a.nvar = ctx->latency_mode ? PV_NVAR_SPLIT : PV_NVAR;
     uint32_t* pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * nn, rc);
     uint32_t* sc = job->template scratch<uint32_t>((size_t)4 * 8 * nn, rc);
     uint32_t* slots = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
@@ -92,7 +93,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     a.hdr_bytes = dimg + hb.at_data; a.ph_bytes = dimg + pb.at_data;
     a.dom = job->template scratch<uint32_t>(8 * n, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
-    a.partials = job->template scratch<uint32_t>((size_t)PV_NPARTS * 3 * N * n, rc);
+    a.partials = job->template scratch<uint32_t>((size_t)PV_NPARTS_MAX * 3 * N * n, rc);
     a.aff = job->template scratch<uint32_t>((size_t)5 * 2 * N * n, rc);
     a.fmiller = job->template scratch<uint32_t>((size_t)2 * 12 * N * n, rc);
     a.vtab = job->template scratch<uint32_t>((size_t)4 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);   // T1's three tables + the one of D * r3^
@@ -124,14 +125,14 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         // stages: it needs only the proof's own points (canonical, converted in the kernel) and the
         // host-validated flag
         add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
-        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
+        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
         // batch verification (pippenger.hpp): one combined pairing check over the items whose challenge matched;
         // if it fails, the per-item kernel decides (its lanes return at once when the combined check passed)
         pa.gate_arr = a.status; pa.gate = ST_PAIRING;                            // fallback: items still pending
-        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * PV_NPARTS); }});
+        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         // a_bar, b_bar in Montgomery form, stored by PvMsmPart
         if ((rc = add_batch_verification<C>(j, &j->bv, ctx, n, a.cc, a.status, a.aff, a.aff + (size_t)2 * N * n, 1, &j->pa))) return rc;

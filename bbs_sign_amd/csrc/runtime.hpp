@@ -395,6 +395,8 @@ struct Ctx : bbs_ctx {
     // caller vouches that every G1 input is in the prime-order subgroup: variable-base multiplications of the
     // verification paths use the GLV split where the curve has it (g1.hpp); off by default
     bool points_in_subgroup = false;
+    // proof_verify: the three terms of T1 on three lanes instead of one joint chain (shorter critical lane, more work)
+    bool latency_mode = false;
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
     std::mutex mu;                   // uploads may come from several host threads: counter and constant sync

@@ -255,7 +255,9 @@ __host__ __device__ inline void g1j_to_aff2(const G1Jac<C>& a, const G1Jac<C>& b
 // proof_verify
 // =============================================================================================
 constexpr int PV_NVAR = 2;                    // (c*Bbar + e^*Abar + r1^*D) jointly, r3^*D
+constexpr int PV_NVAR_SPLIT = 4;              // latency mode: c*Bbar, e^*Abar, r1^*D, r3^*D each on its own lane
 constexpr int PV_NPARTS = PV_NVAR + NFIX;
+constexpr int PV_NPARTS_MAX = PV_NVAR_SPLIT + NFIX;
 
 template <class C>
 struct PvArgs {
@@ -263,6 +265,7 @@ struct PvArgs {
     int L, Rmax;
     const CtxConsts<C>* cc;
     int glv;                  // inputs vouched to be in G1: GLV split for the variable-base terms (BLS12-381)
+    int nvar;                 // PV_NVAR (throughput: T1 as one joint chain) or PV_NVAR_SPLIT (latency: bbs_ctx_set_latency_mode)
     // inputs (canonical limbs, SoA)
     const uint32_t* pts;      // [3][2NC][n] a_bar, b_bar, d (canonical words)
     const uint32_t* sc;       // [4][8][n]   e_cap, r1_cap, r3_cap, challenge
@@ -276,7 +279,7 @@ struct PvArgs {
     // intermediates
     uint32_t* dom;            // [8][n] domain, Montgomery
     uint32_t* fscal;          // [L+2][8][n] canonical fixed-base scalars
-    uint32_t* partials;       // [PV_NPARTS][3N][n] Jacobian
+    uint32_t* partials;       // [nvar + NFIX][3N][n] Jacobian
     uint32_t* aff;            // [5][2N][n] Montgomery affine: a_bar, b_bar, d, T1, T2
     uint32_t* fmiller;        // [2][12N][n]
     uint32_t* vtab;           // [4][G1_TAB][2N][n] window tables: three of the joint multiplication, one of D * r3^ (g1.hpp)
@@ -412,9 +415,9 @@ struct PvMsmPart {
         const size_t i = t - (size_t)part * n;
         if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
+        constexpr int NC = C::FpP::NC;
         if (part == 0) {
-            // T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain
-            constexpr int NC = C::FpP::NC;
+            // on-curve checks of the proof's three points and their Montgomery copies, once per item
             G1Aff<C> pa = g1a_load_canon_to_mont<C>(a.pts, n, i);
             G1Aff<C> pb = g1a_load_canon_to_mont<C>(a.pts + (size_t)2 * NC * n, n, i);
             G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * NC * n, n, i);
@@ -422,21 +425,32 @@ struct PvMsmPart {
             g1a_store_mont<C>(a.aff, n, i, pa);
             g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, pb);
             g1a_store_mont<C>(a.aff + (size_t)4 * N * n, n, i, pd);
-            uint32_t kc[8], ke[8], k1[8];
+            uint32_t kc[8];
             soa_ld<8>(a.sc + (size_t)3 * 8 * n, n, i, kc);
-            soa_ld<8>(a.sc, n, i, ke);
-            soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
-            g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n, a.glv != 0));
-        } else if (part == 1) {
-            // r3^*D, the variable-base term of T2 (proof_verify.rs:175-182)
-            G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * C::FpP::NC * n, n, i);
+            if (a.nvar == PV_NVAR) {
+                // T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain
+                uint32_t ke[8], k1[8];
+                soa_ld<8>(a.sc, n, i, ke);
+                soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
+                g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n, a.glv != 0));
+            } else {
+                // latency mode: c*Bbar alone; e^*Abar and r1^*D are parts 1 and 2 (summed by PvChallenge)
+                g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(pb, kc, a.glv != 0, a.vtab + i, n));
+            }
+        } else if (part < a.nvar) {
+            // single variable-base multiplications: r3^*D, the variable-base term of T2 (proof_verify.rs:175-182), always;
+            // in latency mode also e^*Abar (part 1) and r1^*D (part 2).  Window tables in HBM (a private table is 0.9 KB of
+            // scratch per lane of the whole kernel, and scratch x hardware queues limits the number of queues: DESIGN.md 5 rule 6)
+            const bool last = part == a.nvar - 1;
+            const int pt = last ? 2 : (part == 1 ? 0 : 2);                     // point: D, Abar, D
+            const int sc = last ? 2 : (part == 1 ? 0 : 1);                     // scalar: r3^, e^, r1^
+            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * NC * n, n, i);
             uint32_t k[8];
-            soa_ld<8>(a.sc + (size_t)2 * 8 * n, n, i, k);
-            // its window table in HBM next to the three of part 0 (a private table is 0.9 KB of scratch per lane of
-            // the whole kernel, and scratch x hardware queues is what limits the number of queues: DESIGN.md 5 rule 6)
-            g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(pd, k, a.glv != 0, a.vtab + (size_t)3 * G1_TAB * 2 * N * n + i, n));
+            soa_ld<8>(a.sc + (size_t)sc * 8 * n, n, i, k);
+            const int slot = last ? 3 : part;                                   // vtab slot 3 is D * r3^ in both modes
+            g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(p, k, a.glv != 0, a.vtab + (size_t)slot * G1_TAB * 2 * N * n + i, n));
         } else {
-            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - PV_NVAR));
+            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - a.nvar));
         }
     }
 };
@@ -450,8 +464,9 @@ struct PvChallenge {
         if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> t1 = part(0);
-        G1Jac<C> t2 = part(1);
-        for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(PV_NVAR + f));
+        for (int p = 1; p < a.nvar - 1; p++) t1 = g1j_add<C>(t1, part(p));       // latency mode: the three terms of T1
+        G1Jac<C> t2 = part(a.nvar - 1);
+        for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(a.nvar + f));
         G1Aff<C> T1, T2;
         g1j_to_aff2<C>(t1, t2, T1, T2);
         // challenge (proof_gen.rs:272-328)

@@ -194,6 +194,10 @@ class Engine:
         """bbs_ctx_set_points_in_subgroup: the caller vouches that every G1 input is in the prime-order subgroup."""
         self._chk(self.lib.bbs_ctx_set_points_in_subgroup(self.h, 1 if vouched else 0), "bbs_ctx_set_points_in_subgroup")
 
+    def set_latency_mode(self, enabled: bool):
+        """bbs_ctx_set_latency_mode: proof_verify's T1 as three multiplications on three lanes (one batch at a time)."""
+        self._chk(self.lib.bbs_ctx_set_latency_mode(self.h, 1 if enabled else 0), "bbs_ctx_set_latency_mode")
+
     def set_batch_verification(self, enabled: bool, seed: Optional[bytes] = None):
         """Opt-in random-linear-combination batch verification for core_proof_verify (include/bbs_sign_amd.h);
         seed=None draws the secret seed from the operating system."""

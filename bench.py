@@ -290,15 +290,20 @@ def main():
                 # the cycles 1024 SIMDs have in ms_per_step at the clock measured under load (SQ_BUSY_CYCLES)
                 tot_cyc = sum(k["valu_insts"] * k["cycles_per_inst"] for k in kc.values()) * (n / 4096.0)
                 tot_inst = sum(k["valu_insts"] for k in kc.values()) * (n / 4096.0)
+                tot_cyc8 = sum(k["valu_insts"] * k["cycles_per_inst_if_waves_per_simd"]["8"] for k in kc.values()) * (n / 4096.0)
                 clk = counters["clock_ghz_under_load"]
                 avail = 1024 * clk * 1e9 * (dt / args.steps) / world
                 out["valu_issue"] = {
                     "frac": tot_cyc / avail, "issue_cycles_per_step": tot_cyc, "simd_cycles_available_per_step": avail,
+                    "frac_if_8_waves_per_simd_issue_costs": tot_cyc8 / avail,
                     "valu_wave_insts_per_step": tot_inst, "achieved_ginstr_s": tot_inst * args.steps * world / dt / 1e9 / world,
                     "clock_ghz_under_load": clk, "source": counters_file,
                     "note": "issue cycles = sum over kernels of SQ_INSTS_VALU x (opcode histogram of the kernel's ISA . "
-                            "micro-benchmarked issue cost at this kernel's waves per SIMD); reproducible by hand from "
-                            "profiles/ (tools/valu_model.py)"}
+                            "micro-benchmarked issue cost at this kernel's waves per SIMD = 1); reproducible by hand from "
+                            "profiles/ (tools/valu_model.py).  frac = share of the SIMD cycles the step needs just to ISSUE "
+                            "its vector instructions one wavefront per SIMD; frac_if_8_waves_per_simd_issue_costs prices the "
+                            "same instructions at the cheaper issue costs eight co-resident wavefronts would see (the "
+                            "kernels need 400 of 512 registers, so they run one per SIMD)"}
                 out["kernels"] = [{"kernel": k, "ms_per_launch": per_step.get(k), "valu_wave_insts": v["valu_insts"] * (n / 4096.0),
                                    "cycles_per_inst": v["cycles_per_inst"],
                                    "hbm_bytes": (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0)}

@@ -101,6 +101,13 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
  * Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched);
 
+/* Latency mode for core_proof_verify (off by default).  T1 = Bbar*c + Abar*e^ + D*r1^ (src/proof_verify.rs:163-164) is by
+ * default ONE joint windowed chain on one lane per item -- the least work, and the longest lane of a batch.  With
+ * enabled = 1 the three multiplications run on three lanes and are summed afterwards: the same group element, a
+ * critical lane about one third shorter, about 10 % more instructions per batch.  For callers that verify one batch
+ * at a time; with several batches in flight the default is faster.  Takes effect for jobs uploaded afterwards. */
+int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled);
+
 /* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
  * products of a batch (src/proof_verify.rs:112-115, src/verify.rs:88-92) are replaced by 16 products over random
  * linear combinations of the items' G1 arguments (sum rho_i * Abar_i, sum rho_i * Bbar_i; for verify

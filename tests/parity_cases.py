@@ -868,3 +868,57 @@ def check_submit(curve, lib_path=None, n=7, L=4, seed=23):
                 assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], idx[i], api_id)) == got[i]
         job.free()
     eng.close()
+
+
+def check_latency_mode(curve, lib_path=None, n=12, L=4, seed=41):
+    """bbs_ctx_set_latency_mode (T1's three terms on three lanes, summed afterwards): the same statuses as the default
+    joint chain and as the oracle -- valid proofs, every tampered field that enters T1 or T2, identity and small-order
+    points -- alone and together with batch verification and subgroup vouching."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    exact = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    fast = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    fast.set_latency_mode(True)
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = exact.core_sign_batch(msgs, headers)
+    proofs, st = exact.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    assert list(fast.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
+    bad = [to_engine_proof(p_) for p_ in proofs]
+    bad[1].e_cap = (bad[1].e_cap + 1) % c.r
+    bad[2].r1_cap = 0
+    bad[3].r3_cap = c.r - 1
+    bad[4].d = c.g1_mul(bad[4].d, 2)
+    bad[5].a_bar, bad[5].b_bar = bad[5].b_bar, bad[5].a_bar
+    bad[6].a_bar = None
+    bad[7].challenge = (bad[7].challenge + 1) % c.r
+    bad[8].b_bar = None
+    if curve == "bls12_381":
+        bad[9].d = (0, 2)                                            # on the curve, order 3
+    bad[10].d = None
+    want = list(exact.core_proof_verify_batch(bad, dm, disclosed, headers, phs))
+    assert want[0] == 1 and want[11] == 1 and 0 in want, want
+    assert list(fast.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == want
+    for i in (1, 4, 6):
+        p = bad[i]
+        op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+        assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], disclosed[i], api_id)) == want[i]
+    fast.set_batch_verification(True, bytes(rng.randrange(256) for _ in range(32)))
+    assert list(fast.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == want
+    fast.set_batch_verification(False)
+    fast.set_points_in_subgroup(True)
+    ok = [i for i in range(n) if i != 9]                            # vouching excludes the small-order point
+    pick = lambda xs: [xs[i] for i in ok]
+    assert list(fast.core_proof_verify_batch(pick(bad), pick(dm), pick(disclosed), pick(headers), pick(phs))) == pick(want)
+    exact.close()
+    fast.close()

@@ -86,3 +86,9 @@ def test_mixed_curves_in_flight():
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_empty_batches(curve):
     pc.check_empty_batches(curve, None)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_latency_mode(curve):
+    pc.check_latency_mode(curve, None)
+    pc.check_latency_mode(curve, None, n=80, L=6, seed=42)

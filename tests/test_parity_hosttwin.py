@@ -77,3 +77,8 @@ def test_fail_closed(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_submit(twin, curve):
     pc.check_submit(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_latency_mode(twin, curve):
+    pc.check_latency_mode(curve, twin)

@@ -6,7 +6,9 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_int.hip -o tools/ubench/valu_int && tools/ubench/valu_int > profiles/rNN_ubench_valu_int.csv
 //
 // Output: CSV  op,chains,waves_per_simd,ns_per_wave_instr_per_simd,cycles_per_wave_instr_per_simd,clock_ghz
-// (cycles = ns x the shader clock measured in the same kernel: s_memtime ticks / wall time).
+// (cycles = ns x clock_ghz, the shader clock as s_memtime ticks of one wavefront / kernel wall time: only the
+// 1-wave-per-SIMD rows give a usable clock -- with more waves than SIMDs the waves of one launch do not all live for
+// the whole kernel; tools/valu_model.py works from the ns column).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +32,7 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, unsigned long long* cyc, 
     uint64_t c[NCH];
     for (int i = 0; i < NCH; i++) { a[i] = in[threadIdx.x + 64 * i]; b[i] = in[threadIdx.x + 64 * (i + NCH)] | 1u; c[i] = ((uint64_t)b[i] << 32) | a[i]; }
     const uint32_t sh = in[0] & 7u;                   // run-time shift amount
+    const uint64_t mask = __ballot((in[threadIdx.x] >> 3) & 1u);   // run-time lane mask in an SGPR pair
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, unsigned long long* cyc, 
                 if (OP == OR_B32) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
                 if (OP == LSHRREV) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(sh));
                 if (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(sh));
-                if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : );
+                if (OP == CNDMASK) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "s"(mask));
                 if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b[i]));
                 if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b[i]));
                 if (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b[i]));
@@ -106,6 +109,16 @@ int main() {
     for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345u) >> 4;
     CHECK(hipMalloc(&g_in, h.size() * 4));
     CHECK(hipMemcpy(g_in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    // warm up: the first kernels of a process run before the clock has ramped (round 2's first row read 4.2 ns for an
+    // instruction that measures 2.5 ns once warm)
+    {
+        const int wb = 256 * 4 * 4;
+        uint32_t* wout; unsigned long long* wcyc;
+        CHECK(hipMalloc(&wout, wb * 64 * 4)); CHECK(hipMalloc(&wcyc, wb * 8));
+        for (int r = 0; r < 40; r++) hipLaunchKernelGGL((k<MAD_MIX, 8>), dim3(wb), dim3(64), 0, 0, wout, wcyc, g_in);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipFree(wout)); CHECK(hipFree(wcyc));
+    }
     printf("op,chains,waves_per_simd,ns_per_wave_instr_per_simd,cycles_per_wave_instr_per_simd,clock_ghz\n");
     sweep<MAD_U64_U32>(); sweep<MUL_LO_U32>(); sweep<MUL_HI_U32>(); sweep<MAD_U32_U24>(); sweep<ADD_U32>(); sweep<SUB_U32>();
     sweep<AND_B32>(); sweep<OR_B32>(); sweep<LSHRREV>(); sweep<LSHLREV>(); sweep<CNDMASK>(); sweep<MOV>(); sweep<ADD3>();

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Integer-issue model of the proof_verify kernels: the `valu_issue` ceiling of bench.py, reproducible by hand.
+
+    tools/valu_model.py profiles/r02_c          # reads  <prefix>_pmc.csv  <prefix>_ubench_valu_int.csv  <prefix>_isa_histogram.csv
+                                                # writes <prefix>_counters.json  (what bench.py loads)  and prints the table
+
+Per kernel:   issue cycles per launch = SQ_INSTS_VALU x cycles_per_inst,
+              cycles_per_inst        = sum over opcode classes of  (share of the class in the kernel's hot-loop ISA)
+                                       x (micro-benchmarked issue cost of the class at the kernel's waves per SIMD).
+Issue costs come from tools/ubench/valu_int.hip (ns per wave-instruction per SIMD at 1 / 2 / 4 / 8 waves per SIMD, turned
+into cycles with the clock the same micro-benchmark measured at one wave per SIMD).  The opcode shares come from
+tools/isa_histogram.py: loop bodies of the kernel symbol + the whole text of the device functions it calls.
+bench.py then reports  frac = sum_k issue_cycles_k / (1024 SIMDs x clock under load x seconds per step).
+"""
+import collections
+import csv
+import json
+import sys
+
+STAGE_OF = {"PairDist<BlsCurve>": "pairing_6lane", "PvMsmPart<BlsCurve>": "pv_msm_parts", "PvChallenge<BlsCurve>": "pv_challenge",
+            "PvScalars<BlsCurve>": "pv_scalars", "PvFinish": "pv_finish"}
+SIMPLE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32",
+          "v_mov_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32", "v_not_b32", "v_max_i32", "v_min_i32", "v_max_u32",
+          "v_min_u32", "v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32", "v_mul_i32_i24", "v_mul_u32_u24", "v_bfrev_b32"}
+
+
+def load_ubench(path):
+    t = collections.defaultdict(dict)
+    for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):
+        t[r["op"]][(int(r["chains"]), int(r["waves_per_simd"]))] = (float(r["ns_per_wave_instr_per_simd"]), float(r["clock_ghz"]))
+    return t
+
+
+def class_costs(ub, waves):
+    """cycles per wave-instruction per SIMD for the three classes at `waves` waves per SIMD (8 independent chains)"""
+    w = min((1, 2, 4, 8), key=lambda x: abs(x - waves))
+    ghz = lambda op: ub[op][(8, 1)][1]                     # clock of that op's one-wave run
+    ns = lambda op: ub[op][(8, w)][0]
+    simple_ops = ["v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_lshrrev_b32", "v_mov_b32"]
+    vop3_ops = ["v_mul_lo_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_and_or_b32", "v_bfe_u32", "v_alignbit_b32", "v_lshl_add_u64"]
+    simple = sum(ns(o) * ghz(o) for o in simple_ops) / len(simple_ops)
+    vop3 = sum(ns(o) * ghz(o) for o in vop3_ops) / len(vop3_ops)
+    mix = "mix:3xv_mad_u64_u32+1xv_and_b32"
+    mad = (4 * ns(mix) * ghz(mix) - ns("v_and_b32") * ghz("v_and_b32")) / 3.0    # the mad's share of the 3 + 1 mix
+    carry = ns("v_add_co_u32+v_addc_co_u32") * ghz("v_add_co_u32+v_addc_co_u32")     # per instruction of the pair
+    return {"mad": mad, "vop3": vop3, "simple": simple, "carry": carry}
+
+
+def classify(op):
+    base = op.replace("_e32", "").replace("_e64", "").replace("_sdwa", "").replace("_dpp", "")
+    if base == "v_mad_u64_u32" or base == "v_mad_i64_i32":
+        return "mad"
+    if base in ("v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_subbrev_co_u32"):
+        return "carry"
+    if base in SIMPLE and not op.endswith("_e64"):
+        return "simple"
+    if base.startswith("v_cmp") and not op.endswith("_e64"):
+        return "simple"
+    return "vop3"
+
+
+def main():
+    pre = sys.argv[1]
+    ub = load_ubench(pre + "_ubench_valu_int.csv")
+    pmc = collections.defaultdict(dict)
+    for r in csv.DictReader(l for l in open(pre + "_pmc.csv") if not l.startswith("#")):
+        pmc[r["kernel"]][r["counter"]] = float(r["mean_per_launch"])
+    hist = collections.defaultdict(collections.Counter)
+    for r in csv.DictReader(l for l in open(pre + "_isa_histogram.csv") if not l.startswith("#")):
+        is_kernel = "k_stage" in r["symbol"]
+        if (is_kernel and r["scope"] == "loops") or (not is_kernel and r["scope"] == "text"):
+            if r["opcode"].startswith("v_"):
+                hist[r["kernel"]][r["opcode"]] += int(r["count"])
+    kernels = {}
+    print("%-24s %12s %7s %7s %7s %7s %9s" % ("kernel", "SQ_INSTS_VALU", "mad", "vop3", "simple", "carry", "cyc/inst"))
+    for k, stage in STAGE_OF.items():
+        if k not in pmc or "SQ_INSTS_VALU" not in pmc[k]:
+            continue
+        c = pmc[k]
+        waves_per_simd = 1            # every proof_verify kernel runs one wavefront per SIMD (registers): DESIGN.md 5
+        cost = class_costs(ub, waves_per_simd)
+        h = hist.get(k) or hist.get("PvMsmPart<BlsCurve>")      # small kernels: the MSM kernel's mix (same field arithmetic)
+        tot = sum(h.values())
+        share = collections.Counter()
+        for op, n in h.items():
+            share[classify(op)] += n / tot
+        def cpi_at(w):
+            cw = class_costs(ub, w)
+            return sum(share[cl] * cw[cl] for cl in share)
+        cpi = cpi_at(waves_per_simd)
+        clk = c.get("GRBM_GUI_ACTIVE", 0) / 8.0 / (c.get("duration_ns", 0) or 1) if c.get("duration_ns") else None
+        kernels[stage] = {"kernel": k, "valu_insts": c["SQ_INSTS_VALU"], "FETCH_SIZE_KiB": c.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": c.get("WRITE_SIZE", 0.0),
+                          "waves": c.get("SQ_WAVES"), "waves_per_simd": waves_per_simd, "cycles_per_inst": cpi,
+                          "cycles_per_inst_if_waves_per_simd": {str(w): round(cpi_at(w), 3) for w in (1, 2, 4, 8)},
+                          "opcode_class_share": {cl: round(share[cl], 4) for cl in ("mad", "vop3", "simple", "carry")},
+                          "class_cost_cycles": {cl: round(cost[cl], 3) for cl in cost},
+                          "wait_any_over_wave_cycles": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                          "duration_ns_exclusive": c.get("duration_ns"), "clock_ghz_grbm": clk}
+        print("%-24s %12.4g %7.3f %7.3f %7.3f %7.3f %9.3f" % (k, c["SQ_INSTS_VALU"], share["mad"], share["vop3"], share["simple"], share["carry"], cpi))
+    big = [v for v in kernels.values() if v["clock_ghz_grbm"] and v["valu_insts"] > 1e8]
+    clock = sum(v["clock_ghz_grbm"] * v["duration_ns_exclusive"] for v in big) / sum(v["duration_ns_exclusive"] for v in big)
+    out = {"kernels": kernels, "clock_ghz_under_load": clock,
+           "source": "%s_{pmc,ubench_valu_int,isa_histogram}.csv via tools/valu_model.py" % pre,
+           "note": "SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE: rocprofv3 --pmc, mean of the last launches, one 4096-item BLS12-381 batch; rocprofv3 "
+                   "serialises dispatches while collecting counters, so cycle counters are exclusive-run values; clock = GRBM_GUI_ACTIVE / 8 / kernel duration"}
+    with open(pre + "_counters.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print("clock under load (GRBM_GUI_ACTIVE / 8 / duration, big kernels): %.3f GHz" % clock)
+    print("wrote", pre + "_counters.json")
+
+
+if __name__ == "__main__":
+    main()
