@@ -66,6 +66,24 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the "
                                                 "headline's own width (%d) is `value`" % (args.inflight, args.window_bits))
 
+    # ---- one batch at a time in latency mode (bbs_ctx_set_latency_mode: T1's three terms on three lanes), and the
+    # price of that mode with eight batches in flight
+    eng.set_latency_mode(True)
+    lj = eng.core_proof_verify_upload(proofs, dm, disclosed)
+    lj.run(); lj.wait()
+    assert (lj.status() == 1).all()
+    lms, lst = lj.run_timed(3, per_stage=True)
+    lj.free()
+    bls["latency_mode"] = {"single_batch_ms": lms / 3, "single_batch_proof_verify_per_s": n / (lms / 3 * 1e-3),
+                           "stage_ms": {k: v / 3 for k, v in lst.items()},
+                           "proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed))}
+    eng.set_latency_mode(False)
+    # ---- larger batches need fewer batches in flight to fill the chip (one 16384-item batch is 2560 + 1640 wavefronts
+    # of the two long kernels on 1024 SIMDs): resident, two and four in flight
+    big = (proofs * 4, dm * 4, disclosed * 4)
+    bls["batch_16384"] = {"proof_verify_2_in_flight": rate_k(lambda: eng.core_proof_verify_upload(*big), 2, 8),
+                          "proof_verify_4_in_flight": rate_k(lambda: eng.core_proof_verify_upload(*big), 4, 12)}
+
     # ---- opt-in modes (not the headline): batch verification, subgroup vouching
     eng.set_batch_verification(True)
     bls["proof_verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32, 96)
