@@ -72,6 +72,7 @@ SIGNATURES = {
     "bbs_selftest_inv": (ci, [ci, ci, c_u8p, c_u8p, c_u8p]),
     "bbs_selftest_fp4sqr": (ci, [ci, ci, c_u8p, c_u8p, c_u8p]),
     "bbs_selftest_f2dot": (ci, [ci, sz, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "bbs_selftest_f2dot2": (ci, [ci, sz, c_u8p, c_u8p, c_u8p, c_u8p]),
     "bbs_create_generators": (ci, [ci, sz, c_u8p, sz, c_u8p]),
     "bbs_hash_to_g1": (ci, [ci, c_u8p, sz, c_u8p, sz, c_u8p]),
     "bbs_scalar_from_okm": (ci, [ci, c_u8p, c_u8p]),

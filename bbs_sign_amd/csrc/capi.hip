@@ -64,6 +64,37 @@ static int selftest_f2dot(size_t n_terms, const uint8_t* a, const uint8_t* b, co
     return BBS_OK;
 }
 
+// the same dot product by the two-pass accumulators (low columns, quotients, high columns: tower.hpp F2AccLo / F2AccHi)
+template <class C>
+static int selftest_f2dot2(size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* w, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr size_t FPB = 4 * P::NC;
+    std::vector<Fp2<C>> X(n_terms), Y(n_terms);
+    int weight = 0;
+    for (size_t k = 0; k < n_terms; k++) {
+        if (!fe_from_le_bytes<P>(a + k * 2 * FPB, X[k].c0) || !fe_from_le_bytes<P>(a + k * 2 * FPB + FPB, X[k].c1) ||
+            !fe_from_le_bytes<P>(b + k * 2 * FPB, Y[k].c0) || !fe_from_le_bytes<P>(b + k * 2 * FPB + FPB, Y[k].c1)) return BBS_E_ARG;
+        weight += w[k] ? w[k] : 1;
+        if (w[k] > 2 || weight > 6) return BBS_E_ARG;
+    }
+    F2AccLo<C> lo;
+    f2acc_lo_zero<C>(lo);
+    for (size_t k = 0; k < n_terms; k++) {
+        if (w[k] == 0) f2acc2_mac_fp<C, false>(lo, X[k], Y[k].c0); else f2acc2_mac_sh<C, false>(lo, X[k], Y[k], w[k] - 1u);
+    }
+    F2AccMid<C> mid;
+    f2acc_finish_lo<C>(lo, mid);
+    F2AccHi<C> hi;
+    f2acc_hi_zero<C>(hi);
+    for (size_t k = 0; k < n_terms; k++) {
+        if (w[k] == 0) f2acc2_mac_fp<C, true>(hi, X[k], Y[k].c0); else f2acc2_mac_sh<C, true>(hi, X[k], Y[k], w[k] - 1u);
+    }
+    const Fp2<C> r = f2acc_finish_hi<C>(hi, mid);
+    fe_to_le_bytes<P>(r.c0, out);
+    fe_to_le_bytes<P>(r.c1, out + FPB);
+    return BBS_OK;
+}
+
 // host arithmetic self-test: x^-1 by the safegcd inversion and by the Fermat power (independent code paths)
 template <class P>
 static int selftest_inv(const uint8_t* x, uint8_t* out_safegcd, uint8_t* out_fermat) {
@@ -91,7 +122,9 @@ static int selftest_fp4sqr(int hi, const uint8_t* a, const uint8_t* b, uint8_t* 
     Fp2<C> A, B;
     if (!fe_from_le_bytes<P>(a, A.c0) || !fe_from_le_bytes<P>(a + FPB, A.c1) || !fe_from_le_bytes<P>(b, B.c0) ||
         !fe_from_le_bytes<P>(b + FPB, B.c1)) return BBS_E_ARG;
-    const Fp2<C> r = fp4_sqr_part<C>(hi != 0, A, B);
+    Fp2<C> r;
+    if constexpr (C::K::XI_C0 == 1) r = (hi & 2) ? fp4_sqr_part2<C>((hi & 1) != 0, A, B) : fp4_sqr_part<C>((hi & 1) != 0, A, B);
+    else r = fp4_sqr_part<C>((hi & 1) != 0, A, B);
     fe_to_le_bytes<P>(r.c0, out);
     fe_to_le_bytes<P>(r.c1, out + FPB);
     return BBS_OK;
@@ -675,6 +708,12 @@ int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_
     if (!a || !b || !weights || !out) return BBS_E_ARG;
     if (curve == BBS_CURVE_BLS12_381) return selftest_f2dot<BlsCurve>(n_terms, a, b, weights, out);
     if (curve == BBS_CURVE_BN254) return selftest_f2dot<BnCurve>(n_terms, a, b, weights, out);
+    return BBS_E_ARG;
+}
+int bbs_selftest_f2dot2(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights, uint8_t* out) {
+    if (!a || !b || !weights || !out) return BBS_E_ARG;
+    if (curve == BBS_CURVE_BLS12_381) return selftest_f2dot2<BlsCurve>(n_terms, a, b, weights, out);
+    if (curve == BBS_CURVE_BN254) return selftest_f2dot2<BnCurve>(n_terms, a, b, weights, out);
     return BBS_E_ARG;
 }
 

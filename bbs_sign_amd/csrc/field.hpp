@@ -598,6 +598,69 @@ BBS_HD void cols_reduce(uint32_t* r, uint64_t* t) {
     BBS_BOUND_ASSERT(carry <= P::MOD2[N - 1], "cols_reduce result < 2p");
 }
 
+
+// ---- the same sum of limb products accumulated in TWO passes: columns 0 .. N-1 first, then N .. 2N-2 ---------------
+// Half the accumulator registers (N or N-1 columns instead of 2N-1): what lets the lane-sliced Fp12 kernels keep two
+// wavefronts per SIMD.  The multiply-accumulates are the same ones, each in the pass that owns its column; the
+// Montgomery quotients m[] and the carry out of column N-1 are computed after the low pass and consumed by the high one.
+template <class P>
+BBS_HD void cols_lo_zero(uint64_t* t) {
+#pragma unroll
+    for (int c = 0; c < P::N; c++) t[c] = 0;
+}
+template <class P>
+BBS_HD void cols_hi_zero(uint64_t* t) {
+#pragma unroll
+    for (int c = 0; c < P::N - 1; c++) t[c] = 0;
+}
+template <class P>
+BBS_HD void cols_mac_lo(uint64_t* t, const uint32_t* a, const uint32_t* b) {      // columns i + j < N
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+#pragma unroll
+        for (int j = 0; j < P::N - i; j++) t[i + j] += (uint64_t)a[i] * b[j];
+    }
+}
+template <class P>
+BBS_HD void cols_mac_hi(uint64_t* t, const uint32_t* a, const uint32_t* b) {      // columns i + j >= N, stored at i + j - N
+#pragma unroll
+    for (int i = 1; i < P::N; i++) {
+#pragma unroll
+        for (int j = P::N - i; j < P::N; j++) t[i + j - P::N] += (uint64_t)a[i] * b[j];
+    }
+}
+// low half of cols_reduce: the N quotients and the carry into column N; t (N columns) is consumed
+template <class P>
+BBS_HD void cols_reduce_lo(uint64_t* t, uint32_t* m, uint64_t& carry) {
+    constexpr int N = P::N;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        m[c] = ((uint32_t)t[c] * P::INV) & MASK28;
+#pragma unroll
+        for (int j = 0; j < N - c; j++) t[c + j] += (uint64_t)m[c] * P::MOD[j];
+        if (c + 1 < N) t[c + 1] += t[c] >> 28;
+    }
+    carry = t[N - 1] >> 28;
+}
+// high half: the quotient products that land in columns N .. 2N-2, the carry, the result limbs; t (N-1 columns) is consumed
+template <class P>
+BBS_HD void cols_reduce_hi(uint32_t* r, uint64_t* t, const uint32_t* m, uint64_t carry) {
+    constexpr int N = P::N;
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) {
+#pragma unroll
+        for (int c = k + 1; c < N; c++) t[k] += (uint64_t)m[c] * P::MOD[N + k - c];
+    }
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) {
+        const uint64_t v = t[k] + carry;
+        r[k] = (uint32_t)v & MASK28;
+        carry = v >> 28;
+    }
+    r[N - 1] = (uint32_t)carry;
+    BBS_BOUND_ASSERT(carry <= P::MOD2[N - 1], "cols_reduce_hi result < 2p");
+}
+
 }  // namespace r28
 
 // =============================================================================================

@@ -70,6 +70,11 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 #ifndef BBS_DIST_LAZY
 #define BBS_DIST_LAZY 1
 #endif
+// 1: the dot products accumulate their limb-product columns in two passes (tower.hpp F2AccLo / F2AccHi: half the
+// accumulator registers, operands fetched twice) -- what lets the kernel keep two wavefronts per SIMD (BBS_PAIR_WAVES=2)
+#ifndef BBS_DIST_TWOPASS
+#define BBS_DIST_TWOPASS 0
+#endif
 #ifndef BBS_DIST_UNROLL
 #define BBS_DIST_UNROLL 1        // iterations of the dot-product loops kept rolled (1) or unrolled (6 / 4): A/B knob
 #endif
@@ -79,9 +84,36 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 // 6 * 3 N^2 + 2 N^2 multiply-accumulates instead of 6 * 5 N^2.  Operands come in by ds_bpermute.
 template <class C>
 __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
+    const int k = L.m;
+#if BBS_DIST_TWOPASS
+    F2AccLo<C> lo;
+    f2acc_lo_zero<C>(lo);
+#pragma unroll 1
+    for (int j = 0; j < GRP; j++) {
+        const Fp2<C> a = d_coef<C>(L, g, j);
+        int src = k - j;
+        if (src < 0) src += GRP;
+        Fp2<C> b = d_coef<C>(L, h, src);
+        b = f2_sel<C>(j > k, f2_mul_xi<C>(b), b);
+        f2acc2_mac_sh<C, false>(lo, a, b, 0u);
+    }
+    F2AccMid<C> mid;
+    f2acc_finish_lo<C>(lo, mid);
+    F2AccHi<C> hi;
+    f2acc_hi_zero<C>(hi);
+#pragma unroll 1
+    for (int j = 0; j < GRP; j++) {
+        const Fp2<C> a = d_coef<C>(L, g, j);
+        int src = k - j;
+        if (src < 0) src += GRP;
+        Fp2<C> b = d_coef<C>(L, h, src);
+        b = f2_sel<C>(j > k, f2_mul_xi<C>(b), b);
+        f2acc2_mac_sh<C, true>(hi, a, b, 0u);
+    }
+    return f2acc_finish_hi<C>(hi, mid);
+#else
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
-    const int k = L.m;
 #pragma unroll BBS_DIST_UNROLL
     for (int j = 0; j < GRP; j++) {
         const Fp2<C> a = d_coef<C>(L, g, j);
@@ -92,6 +124,7 @@ __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& 
         f2acc_mac<C, 1>(acc, a, b);
     }
     return f2acc_finish<C>(acc);
+#endif
 }
 
 // f^2: c_k = sum over unordered pairs {i, j}, i + j = k mod 6, of w g_i g_j xi^[i + j >= 6] (w = 1 for squares,
@@ -112,6 +145,40 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
     uint32_t pk = PK[0];
 #pragma unroll
     for (int q = 1; q < 6; q++) pk = (k == q) ? PK[q] : pk;
+#if BBS_DIST_TWOPASS
+    // slot s: operands and weight (fetched in both passes)
+    auto slot = [&](int s, Fp2<C>& a, Fp2<C>& b, uint32_t& sh) {
+        const uint32_t i = (pk >> (6 * s)) & 7u, j = (pk >> (6 * s + 3)) & 7u;
+        const bool used = i != 7u;
+        const uint32_t ii = used ? i : 0u, jj = used ? j : 0u;
+        a = d_coef<C>(L, g, (int)ii);
+        b = d_coef<C>(L, g, (int)jj);
+        a = f2_sel<C>(used, a, f2_zero<C>());
+        b = f2_sel<C>(ii + jj >= (uint32_t)GRP, f2_mul_xi<C>(b), b);
+        sh = (used && ii != jj) ? 1u : 0u;
+    };
+    F2AccLo<C> lo;
+    f2acc_lo_zero<C>(lo);
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+        Fp2<C> a, b;
+        uint32_t sh;
+        slot(s, a, b, sh);
+        f2acc2_mac_sh<C, false>(lo, a, b, sh);
+    }
+    F2AccMid<C> mid;
+    f2acc_finish_lo<C>(lo, mid);
+    F2AccHi<C> hi;
+    f2acc_hi_zero<C>(hi);
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+        Fp2<C> a, b;
+        uint32_t sh;
+        slot(s, a, b, sh);
+        f2acc2_mac_sh<C, true>(hi, a, b, sh);
+    }
+    return f2acc_finish_hi<C>(hi, mid);
+#else
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
 #pragma unroll BBS_DIST_UNROLL
@@ -126,6 +193,7 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
         f2acc_mac_sh<C>(acc, a, b, (used && ii != jj) ? 1u : 0u);
     }
     return f2acc_finish<C>(acc);
+#endif
 }
 #else
 // f * h.  Lane m multiplies g_m by every h_j; product j belongs to w^(m+j): it is rotated to lane
@@ -243,29 +311,46 @@ BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEnt
     const Fp<C> mine = fe_mul_i<typename C::FpP>(fe_select<typename C::FpP>(odd, le.nl.c1, le.nl.c0), P.x);
     const Fp<C> other = fe_shfl<typename C::FpP>(mine, L.base + (L.m ^ 1));
     const Fp2<C> lx = {fe_select<typename C::FpP>(odd, other, mine), fe_select<typename C::FpP>(odd, mine, other)};
+    const int k = L.m;
+    // l = c + lx w^2 + yP w^3 (M twist) :  c_k = g_k c + xi^[k<2] g_{k-2} lx + xi^[k<3] g_{k-3} yP
+    // l = yP + lx w + c w^3   (D twist) :  c_k = g_k yP + xi^[k<1] g_{k-1} lx + xi^[k<3] g_{k-3} c
+    constexpr int SA = C::K::TWIST_M ? 2 : 1;
+    Fp2<C> a = d_coef<C>(L, g, k < SA ? k + GRP - SA : k - SA);
+    Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
+    a = f2_sel<C>(k < SA, f2_mul_xi<C>(a), a);
+    b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
+#if BBS_DIST_TWOPASS
+    F2AccLo<C> lo;
+    f2acc_lo_zero<C>(lo);
+    if constexpr (C::K::TWIST_M) {
+        f2acc2_mac_sh<C, false>(lo, g, le.c, 0u); f2acc2_mac_sh<C, false>(lo, a, lx, 0u); f2acc2_mac_fp<C, false>(lo, b, P.y);
+    } else {
+        f2acc2_mac_fp<C, false>(lo, g, P.y); f2acc2_mac_sh<C, false>(lo, a, lx, 0u); f2acc2_mac_sh<C, false>(lo, b, le.c, 0u);
+    }
+    F2AccMid<C> mid;
+    f2acc_finish_lo<C>(lo, mid);
+    F2AccHi<C> hi;
+    f2acc_hi_zero<C>(hi);
+    if constexpr (C::K::TWIST_M) {
+        f2acc2_mac_sh<C, true>(hi, g, le.c, 0u); f2acc2_mac_sh<C, true>(hi, a, lx, 0u); f2acc2_mac_fp<C, true>(hi, b, P.y);
+    } else {
+        f2acc2_mac_fp<C, true>(hi, g, P.y); f2acc2_mac_sh<C, true>(hi, a, lx, 0u); f2acc2_mac_sh<C, true>(hi, b, le.c, 0u);
+    }
+    return f2acc_finish_hi<C>(hi, mid);
+#else
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
-    const int k = L.m;
     if constexpr (C::K::TWIST_M) {
-        // l = c + lx w^2 + yP w^3 :  c_k = g_k c + xi^[k<2] g_{k-2} lx + xi^[k<3] g_{k-3} yP
-        Fp2<C> a = d_coef<C>(L, g, k < 2 ? k + 4 : k - 2);
-        Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
-        a = f2_sel<C>(k < 2, f2_mul_xi<C>(a), a);
-        b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
         f2acc_mac<C, 1>(acc, g, le.c);
         f2acc_mac<C, 1>(acc, a, lx);
         f2acc_mac_fp<C>(acc, b, P.y);
     } else {
-        // l = yP + lx w + c w^3    :  c_k = g_k yP + xi^[k<1] g_{k-1} lx + xi^[k<3] g_{k-3} c
-        Fp2<C> a = d_coef<C>(L, g, k < 1 ? k + 5 : k - 1);
-        Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
-        a = f2_sel<C>(k < 1, f2_mul_xi<C>(a), a);
-        b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
         f2acc_mac_fp<C>(acc, g, P.y);
         f2acc_mac<C, 1>(acc, a, lx);
         f2acc_mac<C, 1>(acc, b, le.c);
     }
     return f2acc_finish<C>(acc);
+#endif
 }
 #else
 template <class C>
@@ -312,7 +397,11 @@ BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     Fp2<C> sq;                                              // lane m<3: X2[0] of pair m ; m>=3: X2[1] of pair m-3
 #if BBS_DIST_LAZY
     if constexpr (C::K::XI_C0 == 1) {                       // BN254 (xi = 9 + u, 10 limbs): measured no faster, old form kept
+#if BBS_DIST_TWOPASS
+        sq = fp4_sqr_part2<C>(hi, g, px);                   // the same in two passes over the columns
+#else
         sq = fp4_sqr_part<C>(hi, g, px);                    // tower.hpp: four column products, one reduction pair
+#endif
     } else
 #endif
     {

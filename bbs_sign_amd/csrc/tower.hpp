@@ -146,6 +146,69 @@ BBS_HD Fp2<C> f2acc_finish(F2Acc<C>& acc) {
     return r;
 }
 
+// ---- the same dot products in two passes over the terms (r28::cols_*_lo / _hi): 3 x N (then 3 x (N-1)) accumulator
+// columns live instead of 3 x (2N-1).  Usage: zero lo; mac_lo every term; st = finish_lo; zero hi; mac_hi every term
+// AGAIN (the caller fetches the operands twice); finish_hi.  Same value as f2acc_finish, limb for limb.
+template <class C>
+struct F2AccLo { uint64_t t0[C::FpP::N], t1[C::FpP::N], ts[C::FpP::N]; };
+template <class C>
+struct F2AccHi { uint64_t t0[C::FpP::N - 1], t1[C::FpP::N - 1], ts[C::FpP::N - 1]; };
+template <class C>
+struct F2AccMid { uint32_t m_re[C::FpP::N], m_im[C::FpP::N]; uint64_t carry_re, carry_im; };   // between the passes
+
+template <class C> BBS_HD void f2acc_lo_zero(F2AccLo<C>& a) { r28::cols_lo_zero<FP>(a.t0); r28::cols_lo_zero<FP>(a.t1); r28::cols_lo_zero<FP>(a.ts); }
+template <class C> BBS_HD void f2acc_hi_zero(F2AccHi<C>& a) { r28::cols_hi_zero<FP>(a.t0); r28::cols_hi_zero<FP>(a.t1); r28::cols_hi_zero<FP>(a.ts); }
+
+// HI = false: low pass, true: high pass.  sh: run-time weight 2^sh (0 or 1) on the a side.
+template <class C, bool HI, class ACC>
+BBS_HD void f2acc2_mac_sh(ACC& acc, const Fp2<C>& a, const Fp2<C>& b, uint32_t sh) {
+    constexpr int N = C::FpP::N;
+    uint32_t a0[N], a1[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { a0[i] = a.c0.v[i] << sh; a1[i] = a.c1.v[i] << sh; }
+    if constexpr (HI) { r28::cols_mac_hi<FP>(acc.t0, a0, b.c0.v); r28::cols_mac_hi<FP>(acc.t1, a1, b.c1.v); }
+    else { r28::cols_mac_lo<FP>(acc.t0, a0, b.c0.v); r28::cols_mac_lo<FP>(acc.t1, a1, b.c1.v); }
+    uint32_t sb[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { a0[i] += a1[i]; sb[i] = b.c0.v[i] + b.c1.v[i]; }     // exact limb-wise sums (Karatsuba on the integers)
+    if constexpr (HI) r28::cols_mac_hi<FP>(acc.ts, a0, sb); else r28::cols_mac_lo<FP>(acc.ts, a0, sb);
+}
+template <class C, bool HI, class ACC>
+BBS_HD void f2acc2_mac_fp(ACC& acc, const Fp2<C>& a, const Fp<C>& y) {              // b = y in Fp: t1 += 0
+    constexpr int N = C::FpP::N;
+    uint32_t sa[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) sa[i] = a.c0.v[i] + a.c1.v[i];
+    if constexpr (HI) { r28::cols_mac_hi<FP>(acc.t0, a.c0.v, y.v); r28::cols_mac_hi<FP>(acc.ts, sa, y.v); }
+    else { r28::cols_mac_lo<FP>(acc.t0, a.c0.v, y.v); r28::cols_mac_lo<FP>(acc.ts, sa, y.v); }
+}
+template <class C>
+BBS_HD void f2acc_finish_lo(F2AccLo<C>& acc, F2AccMid<C>& st) {
+    constexpr int N = C::FpP::N;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        const uint64_t x = acc.t0[c], y = acc.t1[c];
+        acc.ts[c] = acc.ts[c] - x - y;
+        acc.t0[c] = x + C::FpP::WP2X[c] - y;
+    }
+    r28::cols_reduce_lo<FP>(acc.t0, st.m_re, st.carry_re);
+    r28::cols_reduce_lo<FP>(acc.ts, st.m_im, st.carry_im);
+}
+template <class C>
+BBS_HD Fp2<C> f2acc_finish_hi(F2AccHi<C>& acc, const F2AccMid<C>& st) {
+    constexpr int N = C::FpP::N;
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) {
+        const uint64_t x = acc.t0[k], y = acc.t1[k];
+        acc.ts[k] = acc.ts[k] - x - y;
+        acc.t0[k] = x + C::FpP::WP2X[N + k] - y;
+    }
+    Fp2<C> r;
+    r28::cols_reduce_hi<FP>(r.c0.v, acc.t0, st.m_re, st.carry_re);
+    r28::cols_reduce_hi<FP>(r.c1.v, acc.ts, st.m_im, st.carry_im);
+    return r;
+}
+
 // One half of an Fp4 square (Granger-Scott cyclotomic squaring; Fp4 = Fp2[s]/(s^2 - xi), xi = c + u) as FOUR
 // limb-column products and one reduction pair, the same instruction stream for both halves (operands selected by
 // `hi`; the two lanes of a pair in pairing_dist.hpp run it side by side):
@@ -195,6 +258,64 @@ BBS_HD Fp2<C> fp4_sqr_part(bool hi, const Fp2<C>& A, const Fp2<C>& B) {
     r28::cols_reduce<P>(r.c0.v, x1);
     r28::cols_reduce<P>(r.c1.v, x2);
     return r;
+}
+
+// fp4_sqr_part with the four limb-column products accumulated in two passes (columns 0 .. N-1, then N .. 2N-2): 4 x N
+// accumulator columns live instead of 4 x (2N-1), the operand pair of each product formed when it is needed.  Same
+// value, limb for limb (host-testable: bbs_selftest_fp4sqr with hi | 2).
+template <class C>
+BBS_HD Fp2<C> fp4_sqr_part2(bool hi, const Fp2<C>& A, const Fp2<C>& B) {
+    using P = typename C::FpP;
+    constexpr int N = P::N;
+    constexpr uint32_t XC = C::K::XI_C0;
+    const Fp<C> dA = fe_sub<P>(A.c0, A.c1), dB = fe_sub<P>(B.c0, B.c1);
+    // operands of product k (see the table above fp4_sqr_part); sums formed here, lazily for xi = 1 + u
+    auto operands = [&](int k, uint32_t* l, uint32_t* r) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t a0 = A.c0.v[i], a1 = A.c1.v[i], b0 = B.c0.v[i], b1 = B.c1.v[i];
+            if (k == 1) { l[i] = hi ? (a0 << 1) : (a0 + a1); r[i] = hi ? b0 : dA.v[i]; }
+            if (k == 2) { l[i] = hi ? (a1 << 1) : (a0 << 1); r[i] = hi ? b1 : a1; }
+            if (k == 3) { l[i] = hi ? (a0 << 1) : (b0 + b1); r[i] = hi ? b1 : dB.v[i]; }
+            if (k == 4) { l[i] = hi ? (a1 << 1) : (b0 << 1); r[i] = hi ? b0 : b1; }
+        }
+    };
+    static_assert(XC == 1, "two-pass Fp4 square: xi = 1 + u only (lazy sums; BN254 keeps the two-squarings form)");
+    uint32_t l[N], r[N];
+    uint64_t x1[N], x2[N], x3[N], x4[N];
+    r28::cols_lo_zero<P>(x1); r28::cols_lo_zero<P>(x2); r28::cols_lo_zero<P>(x3); r28::cols_lo_zero<P>(x4);
+    operands(1, l, r); r28::cols_mac_lo<P>(x1, l, r);
+    operands(2, l, r); r28::cols_mac_lo<P>(x2, l, r);
+    operands(3, l, r); r28::cols_mac_lo<P>(x3, l, r);
+    operands(4, l, r); r28::cols_mac_lo<P>(x4, l, r);
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        const uint64_t re = x1[c] + P::WP2X[c] + (hi ? (0 - x2[c]) : (x3[c] - x4[c]));
+        const uint64_t im = x3[c] + (hi ? x4[c] : (x4[c] + x2[c]));
+        x1[c] = re;
+        x2[c] = im;
+    }
+    uint32_t m_re[N], m_im[N];
+    uint64_t c_re, c_im;
+    r28::cols_reduce_lo<P>(x1, m_re, c_re);
+    r28::cols_reduce_lo<P>(x2, m_im, c_im);
+    uint64_t y1[N - 1], y2[N - 1], y3[N - 1], y4[N - 1];
+    r28::cols_hi_zero<P>(y1); r28::cols_hi_zero<P>(y2); r28::cols_hi_zero<P>(y3); r28::cols_hi_zero<P>(y4);
+    operands(1, l, r); r28::cols_mac_hi<P>(y1, l, r);
+    operands(2, l, r); r28::cols_mac_hi<P>(y2, l, r);
+    operands(3, l, r); r28::cols_mac_hi<P>(y3, l, r);
+    operands(4, l, r); r28::cols_mac_hi<P>(y4, l, r);
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) {
+        const uint64_t re = y1[k] + P::WP2X[N + k] + (hi ? (0 - y2[k]) : (y3[k] - y4[k]));
+        const uint64_t im = y3[k] + (hi ? y4[k] : (y4[k] + y2[k]));
+        y1[k] = re;
+        y2[k] = im;
+    }
+    Fp2<C> out;
+    r28::cols_reduce_hi<P>(out.c0.v, y1, m_re, c_re);
+    r28::cols_reduce_hi<P>(out.c1.v, y2, m_im, c_im);
+    return out;
 }
 
 template <class C>

@@ -336,10 +336,15 @@ int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_
  * (src/proof_verify.rs:163-164), plain (glv = 0) or with the GLV split (glv = 1; BLS12-381 points must be in the subgroup).  points: 3 affine records, scalars: 3 x 32 bytes LE canonical. */
 int bbs_selftest_mul3(int curve, int glv, const uint8_t* points, const uint8_t* scalars, uint8_t* out_affine);
 /* Host arithmetic self-test (no GPU): one half of an Fp4 square as the pairing kernel computes it (four limb-column
- * products, one reduction pair): hi = 0: a^2 + xi b^2, hi = 1: 2 a b, for a, b in Fp2 (c0 || c1, canonical LE). */
+ * products, one reduction pair): hi = 0: a^2 + xi b^2, hi = 1: 2 a b, for a, b in Fp2 (c0 || c1, canonical LE);
+ * hi | 2 (BLS12-381): the same through the two-pass column accumulators. */
 int bbs_selftest_fp4sqr(int curve, int hi, const uint8_t* a, const uint8_t* b, uint8_t* out);
 int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
                        uint8_t* out);
+/* The same dot product by the two-pass column accumulators (low columns -> Montgomery quotients -> high columns; half the
+ * accumulator registers): must equal bbs_selftest_f2dot limb for limb. */
+int bbs_selftest_f2dot2(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
+                        uint8_t* out);
 
 #ifdef __cplusplus
 }

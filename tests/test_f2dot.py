@@ -54,6 +54,10 @@ def test_f2dot(libs, cid, curve):
                 assert lib.bbs_selftest_f2dot(cid, len(pat), _u8(ab), _u8(bb), _u8(wb), _u8(out)) == 0
                 o = out.tobytes()
                 assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == (re % p, im % p), (cid, pat, trial)
+                # the two-pass accumulators (low columns, quotients, high columns) give the same limbs
+                out2 = np.zeros(2 * fpb, dtype=np.uint8)
+                assert lib.bbs_selftest_f2dot2(cid, len(pat), _u8(ab), _u8(bb), _u8(wb), _u8(out2)) == 0
+                assert out2.tobytes() == o, (cid, pat, trial, "two-pass")
 
 
 @pytest.mark.parametrize("cid,curve", [(0, BLS12_381), (1, BN254)])
@@ -114,6 +118,10 @@ def test_fp4_half_square(libs, cid, curve, xi0, nl):
                 assert lib.bbs_selftest_fp4sqr(cid, hi, _u8(ab), _u8(bbuf), _u8(out)) == 0
                 o = out.tobytes()
                 assert (int.from_bytes(o[:fpb], "little"), int.from_bytes(o[fpb:], "little")) == want, (cid, hi, trial)
+                if cid == 0:                     # BLS12-381: the two-pass form (hi | 2) gives the same limbs
+                    out2 = np.zeros(2 * fpb, dtype=np.uint8)
+                    assert lib.bbs_selftest_fp4sqr(cid, hi | 2, _u8(ab), _u8(bbuf), _u8(out2)) == 0
+                    assert out2.tobytes() == o, (cid, hi, trial, "two-pass")
 
 
 def _glv_edge_scalars(r, lam, rng, count):
