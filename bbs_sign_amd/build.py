@@ -5,6 +5,7 @@
 """
 import concurrent.futures as cf
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -16,9 +17,34 @@ PRODUCT = os.path.join(HERE, "libbbs_sign_amd.so")
 TWIN = os.path.join(ROOT, "tests", "hosttwin", "libbbs_hosttwin_TESTONLY.so")
 
 
-def _newest_src():
-    files = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(ROOT, "include", "bbs_sign_amd.h")]
-    return max(os.path.getmtime(f) for f in files)
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(ROOT, "include", "bbs_sign_amd.h")]
+
+
+def source_hash():
+    """SHA-256 over the names and contents of every file the library is built from (csrc/* and the C header).  It is
+    compiled into the library (bbs_source_hash()) so that a prebuilt .so that travelled with the tree -- the GPU box
+    receives the built library, and file times do not survive the copy reliably -- is recognised as current or stale
+    by content, not by modification time."""
+    h = hashlib.sha256()
+    for f in _sources():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:32]
+
+
+def built_hash(path):
+    """The source hash embedded in an existing library (marker string in its read-only data), or None.  Read from the
+    file, not through dlopen: a library that is about to be rebuilt must not be mapped into this process."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        data = f.read()
+    i = data.find(b"BBS_SRC_HASH=")
+    if i < 0:
+        return None
+    return data[i + 13:i + 45].decode("ascii", "replace")
 
 
 def _run(cmd):
@@ -30,7 +56,10 @@ def _run(cmd):
 
 def build(twin=False, force=False, jobs=None, verbose=True):
     out = TWIN if twin else PRODUCT
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_src():
+    want = source_hash()
+    if not force and built_hash(out) == want:
+        if verbose:
+            print("up to date (source hash %s): %s" % (want, out))
         return out
     objdir = os.path.join(HERE, "build", "twin" if twin else "gfx950")
     os.makedirs(objdir, exist_ok=True)
@@ -41,22 +70,27 @@ def build(twin=False, force=False, jobs=None, verbose=True):
     else:
         flags = ["-O3", "--offload-arch=gfx950", "-fPIC"]
     # only the C ABI of include/bbs_sign_amd.h is exported (capi.hip raises the visibility of its extern "C" blocks)
-    flags += ["-fvisibility=hidden", "-fvisibility-inlines-hidden"]
+    flags += ["-fvisibility=hidden", "-fvisibility-inlines-hidden", '-DBBS_SRC_HASH="%s"' % want]
+    stamp = os.path.join(objdir, "source_hash.txt")
+    fresh_objs = os.path.exists(stamp) and open(stamp).read() == want
     jobs = jobs or min(8, os.cpu_count() or 1)
 
     def one(tu):
         obj = os.path.join(objdir, os.path.basename(tu)[:-4] + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= _newest_src():
+        if not force and fresh_objs and os.path.exists(obj):
             return obj
         _run(["hipcc"] + flags + ["-c", tu, "-o", obj])
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(one, tus))
+    with open(stamp, "w") as f:
+        f.write(want)
     link = ["hipcc", "-shared", "-fPIC"] + (["--offload-host-only"] if twin else ["--offload-arch=gfx950"]) + objs + ["-o", out]
     _run(link)
+    assert built_hash(out) == want, "the library just built does not report the source hash it was built from"
     if verbose:
-        print("built", out)
+        print("built (source hash %s): %s" % (want, out))
     return out
 
 

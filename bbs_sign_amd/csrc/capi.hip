@@ -213,6 +213,11 @@ const char* bbs_version(void) {
     return "bbs_sign_amd 0.1 (gfx950)";
 #endif
 }
+#ifndef BBS_SRC_HASH
+#define BBS_SRC_HASH "unknown"
+#endif
+static const char BBS_SRC_HASH_MARK[] = "BBS_SRC_HASH=" BBS_SRC_HASH;      // found by bbs_sign_amd/build.py in the file
+const char* bbs_source_hash(void) { return BBS_SRC_HASH_MARK + 13; }
 int bbs_device_count(void) { return rt::device_count(); }
 
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out) {

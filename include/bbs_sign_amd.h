@@ -81,6 +81,9 @@ typedef struct bbs_job bbs_job;
  * ------------------------------------------------------------------------------------------ */
 size_t bbs_fp_bytes(int curve);
 const char* bbs_version(void);
+/* Hash of the sources (bbs_sign_amd/csrc/* and this header) the library was built from; bbs_sign_amd/build.py rebuilds
+ * when it differs from the tree's (a prebuilt library travels with the tree: staleness is judged by content). */
+const char* bbs_source_hash(void);
 int bbs_device_count(void);
 
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);

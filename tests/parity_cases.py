@@ -922,3 +922,42 @@ def check_latency_mode(curve, lib_path=None, n=12, L=4, seed=41):
     assert list(fast.core_proof_verify_batch(pick(bad), pick(dm), pick(disclosed), pick(headers), pick(phs))) == pick(want)
     exact.close()
     fast.close()
+
+
+def check_large_shapes(curve, lib_path=None, L=100, n=3, seed=51):
+    """Shapes well beyond the BASELINE one: many messages (the reference's benches go to 128, benches/sign.rs:40), long
+    ragged headers / presentation headers (several SHA-256 blocks more than the cached prefix), everything or nothing
+    disclosed.  Signature, proof and booleans against the oracle."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = bbs.synthetic_generators(suite, L + 1)           # hash-to-curve of 100+ generators is not what is tested here
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(k)) for k in (1000, 0, 63, 129)[:n]]
+    phs = [bytes(rng.randrange(256) for _ in range(k)) for k in (0, 300, 64, 1)[:n]]
+    disclosed = [list(range(L)), [], sorted(rng.sample(range(L), L // 3)), [L - 1]][:n]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    want = bbs.core_sign(suite, sk, gens, headers[0], msgs[0], api_id)
+    assert (sigs[0].a, sigs[0].e) == (want.a, want.e)
+    assert list(eng.core_verify_batch(sigs, msgs, headers)) == [1] * n
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    for i in range(min(n, 2)):
+        ws = bbs.core_sign(suite, sk, gens, headers[i], msgs[i], api_id)
+        wp = bbs.core_proof_gen(suite, pk, ws, headers[i], gens, phs[i], msgs[i], disclosed[i], api_id, rnds[i])
+        assert proof_eq(proofs[i], wp), (curve, i)
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    assert list(eng.core_proof_verify_batch(proofs, dm, disclosed, headers, phs)) == [1] * n
+    phs2 = list(phs)
+    phs2[0] = phs2[0] + b"x"
+    hd2 = list(headers)
+    hd2[-1] = hd2[-1][:-1] if hd2[-1] else b"y"
+    assert list(eng.core_proof_verify_batch(proofs, dm, disclosed, hd2, phs2))[0] == 0
+    assert list(eng.core_proof_verify_batch(proofs, dm, disclosed, hd2, phs))[-1] == 0
+    eng.close()

@@ -92,3 +92,8 @@ def test_empty_batches(curve):
 def test_latency_mode(curve):
     pc.check_latency_mode(curve, None)
     pc.check_latency_mode(curve, None, n=80, L=6, seed=42)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_large_shapes(curve):
+    pc.check_large_shapes(curve, None, L=100, n=4)

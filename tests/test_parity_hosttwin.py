@@ -82,3 +82,8 @@ def test_submit(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_latency_mode(twin, curve):
     pc.check_latency_mode(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_large_shapes(twin, curve):
+    pc.check_large_shapes(curve, twin, L=40, n=2)

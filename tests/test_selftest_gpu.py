@@ -48,7 +48,32 @@ def test_six_lane_fp12_matches_one_lane(curve):
                 b[0], b[1] = P
             s, d = _run(eng, op, a, b)
             assert s == d, (curve, name, rep)
+            # ... and against the ORACLE's Fp12 (oracle/curves.py, w-basis), operation by operation: the one-lane and
+            # the six-lane code share tower.hpp, so their agreement alone would not localise a break in it
+            x = _tower_to_w(c, a)
+            if op >= 10:                                  # the host makes the input cyclotomic: x^((p^6-1)(p^2+1))
+                x = c.f12_mul(c.f12_conj(x), c.f12_inv(x))
+                x = c.f12_mul(c.f12_frob(c.f12_frob(x)), x)
+            frobk = lambda v, k: v if k == 0 else frobk(c.f12_frob(v), k - 1)
+            want = None
             if op == 0:
-                want = c.f12_mul(_tower_to_w(c, a), _tower_to_w(c, b))
-                assert _tower_to_w(c, s) == want, (curve, "mul vs oracle")
+                want = c.f12_mul(x, _tower_to_w(c, b))
+            elif op in (1, 2, 3):
+                want = frobk(x, op)
+            elif op == 4:
+                want = c.f12_inv(x)
+            elif op == 5:
+                want = c.f12_conj(x)
+            elif op == 7:                                 # BLS12-381 raises to 3 (p^12-1)/r, BN254 to (p^12-1)/r
+                want = c.final_exp(x)
+                if curve == "bls12_381":
+                    want = c.f12_pow(want, 3)
+            elif op in (8, 10):
+                want = c.f12_sqr(x)
+            elif op == 11:                                # x^(curve parameter), the sign by conjugation (x unitary)
+                want = c.f12_pow(x, abs(c.x_param))
+                if c.x_param < 0:
+                    want = c.f12_conj(want)
+            if want is not None:
+                assert _tower_to_w(c, d) == [tuple(v) for v in want], (curve, name, rep, "six-lane vs oracle")
     eng.close()
