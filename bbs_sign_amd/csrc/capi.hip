@@ -449,12 +449,25 @@ int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* pf, const
     delete job;
     return rc;
 }
-int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
-                          const uint8_t* h, const uint64_t* ho, int8_t* status) {
+int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                           const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
+    if (!status || !job_out) return BBS_E_ARG;
     bbs_job* job = nullptr;
     int rc = bbs_core_verify_upload(ctx, n, sigs, m, mo, h, ho, &job);
     if (rc) return rc;
-    rc = run_fetch_free(job, status);
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                          const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_core_verify_submit(ctx, n, sigs, m, mo, h, ho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
     delete job;
     return rc;
 }

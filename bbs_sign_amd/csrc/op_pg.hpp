@@ -8,6 +8,7 @@ template <class C>
 struct PgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     PgArgs<C> a{};
+    PgIngestArgs<C> ingest{};
     std::vector<std::vector<uint32_t>> undisclosed;     // per item, sorted
     int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
         constexpr int N = C::FpP::NC;       // canonical words
@@ -46,7 +47,6 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     constexpr int N = C::FpP::N;
     constexpr int NC = C::FpP::NC;
     constexpr int FPB = 4 * NC;
-    using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!sigs || !msg_off || !didx_off || !rnd_off || !rnd))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
@@ -54,64 +54,60 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t rec = 2 * FPB + 32;
     auto job = std::unique_ptr<PgJob<C>>(new PgJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, ST_PENDING);
+    RaggedIn ms{msg_off, msgs, 32}, di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8}, rs{rnd_off, rnd, 32},
+             hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
+    if (!ms.measure(n) || !di.measure(n) || !rs.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
+    if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
+    // Host side, index bookkeeping only (no field data is touched): the contract of this ABI on the number of random
+    // scalars (proof_gen.rs:145-149; checked where the reference would have got that far) and, for fetch_proofs, the sorted
+    // undisclosed indexes of every item that passes the reference's checks.  Everything else -- the checks themselves,
+    // range checks, deduplication, unpacking, SoA transposition -- is stage PgIngest on the device.
     job->undisclosed.resize(n);
-    size_t rmax = 1;
-    for (size_t i = 0; i < n; i++) rmax = std::max<size_t>(rmax, (size_t)(didx_off[i + 1] - didx_off[i]));
-    Soa sa, se, sm, dmask, didx_s, rcount, rnd5, mt;
-    sa.init(2 * NC, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
-    dmask.init((size_t)(std::max(L, 1) + 31) / 32, n); didx_s.init(rmax, n); rcount.init(1, n);
-    rnd5.init(5 * 8, n); mt.init((size_t)std::max(L, 1) * 8, n);
     std::vector<uint8_t> seen;
     for (size_t i = 0; i < n; i++) {
-        int8_t& st = job->status0[i];
         const size_t l = (size_t)(msg_off[i + 1] - msg_off[i]);
         const size_t r = (size_t)(didx_off[i + 1] - didx_off[i]);
         const size_t nr = (size_t)(rnd_off[i + 1] - rnd_off[i]);
         const uint64_t* idx = didx + didx_off[i];
-        // proof_gen.rs:133-143
-        if (r > l) { st = BBS_ST_INVALID_DISCLOSED_INDICES_LENGTH; continue; }
+        if (r > l) continue;                                          // -> InvalidDisclosedIndicesLength on the device
         bool bad = false;
         for (size_t k = 0; k < r; k++) if (idx[k] >= l) bad = true;
-        if (bad) { st = BBS_ST_INVALID_DISCLOSED_INDEX; continue; }
-        if (nr != 5 + l - r) return BBS_E_ARG;                       // contract of this ABI (:145-149)
-        // proof_init, proof_gen.rs:229-239
-        if (l != (size_t)L) { st = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }
+        if (bad) continue;                                            // -> InvalidDisclosedIndex
+        if (nr != 5 + l - r) return BBS_E_ARG;
+        if (l != (size_t)L) continue;
         seen.assign(l, 0);
-        size_t distinct = 0;
-        for (size_t k = 0; k < r; k++) if (!seen[idx[k]]) { seen[idx[k]] = 1; distinct++; }
-        if (distinct != r) { st = BBS_ST_INVALID_RANDOM_SCALARS_AND_UNDISCLOSED_INDICES_LENGTH; continue; }
-        if (ctx->dst_too_long) { st = BBS_ST_PANIC_DST_TOO_LONG; continue; }
-        bool ok = pack_g1<C>(sa, 0, i, sigs + i * rec);
-        ok &= pack_fe<R>(se, 0, i, sigs + i * rec + 2 * FPB);
-        for (size_t j = 0; j < l; j++) ok &= pack_fe<R>(sm, j * 8, i, msgs + (msg_off[i] + j) * 32);
-        const uint8_t* rs = rnd + rnd_off[i] * 32;
-        for (int k = 0; k < 5; k++) ok &= pack_fe<R>(rnd5, (size_t)k * 8, i, rs + 32 * k);
-        size_t ku = 0, kd = 0;
-        for (size_t j = 0; j < l; j++) {
-            if (seen[j]) {
-                dmask.at(j >> 5, i) |= 1u << (j & 31);
-                didx_s.at(kd++, i) = (uint32_t)j;
-            } else {
-                ok &= pack_fe<R>(mt, j * 8, i, rs + 32 * (5 + ku));
-                ku++;
-                job->undisclosed[i].push_back((uint32_t)j);
-            }
-        }
-        rcount.at(0, i) = (uint32_t)kd;
-        if (!ok) st = BBS_ST_NONCANONICAL;
+        for (size_t k = 0; k < r; k++) seen[idx[k]] = 1;
+        for (size_t j = 0; j < l; j++) if (!seen[j]) job->undisclosed[i].push_back((uint32_t)j);
     }
-    BytePool hp, pp;
-    if (!hp.build(n, headers, hdr_off) || !pp.build(n, ph, ph_off)) return BBS_E_ARG;
+    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &di, &rs, &hb, &pb})) return rc0;
+    const uint8_t* dimg = job->d_raw.template as<uint8_t>();
+    auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
+    auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };
     int rc = BBS_OK;
+    const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     PgArgs<C>& a = job->a;
-    a.n = n; a.L = L; a.Rmax = (int)rmax; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
+    a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
-    a.sig_a = job->up(sa.soa(), rc); a.sig_e = job->up(se.soa(), rc); a.msgs = job->up(sm.soa(), rc);
-    a.dmask = job->up(dmask.soa(), rc); a.didx = job->up(didx_s.soa(), rc); a.rcount = job->up(rcount.soa(), rc);
-    a.rnd5 = job->up(rnd5.soa(), rc); a.mtilde = job->up(mt.soa(), rc);
-    a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
-    a.ph_off = job->up(pp.off, rc); a.ph_len = job->up(pp.len, rc); a.ph_bytes = job->up(pp.bytes, rc);
+    PgIngestArgs<C>& ia = job->ingest;
+    ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0;
+    ia.rec = d32(0);
+    ia.m_off = d64(ms.at_off); ia.di_off = d64(di.at_off); ia.rnd_off = d64(rs.at_off); ia.hdr_off64 = d64(hb.at_off); ia.ph_off64 = d64(pb.at_off);
+    ia.m = d32(ms.at_data); ia.di = d64(di.at_data); ia.rnd = d32(rs.at_data);
+    ia.sig_a = job->template scratch<uint32_t>((size_t)2 * NC * nn, rc);
+    ia.sig_e = job->template scratch<uint32_t>((size_t)8 * nn, rc);
+    ia.msgs = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
+    ia.dmask = job->template scratch<uint32_t>(((Lw + 31) / 32) * nn, rc);
+    ia.didx = job->template scratch<uint32_t>(Lw * nn, rc);
+    ia.rcount = job->template scratch<uint32_t>(nn, rc);
+    ia.rnd5 = job->template scratch<uint32_t>((size_t)5 * 8 * nn, rc);
+    ia.mtilde = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
+    uint32_t* offs = job->template scratch<uint32_t>(4 * nn, rc);
+    if (rc) return rc;
+    ia.hdr_off = offs; ia.hdr_len = offs + nn; ia.ph_off = offs + 2 * nn; ia.ph_len = offs + 3 * nn;
+    a.sig_a = ia.sig_a; a.sig_e = ia.sig_e; a.msgs = ia.msgs; a.dmask = ia.dmask; a.didx = ia.didx; a.rcount = ia.rcount;
+    a.rnd5 = ia.rnd5; a.mtilde = ia.mtilde;
+    a.hdr_off = ia.hdr_off; a.hdr_len = ia.hdr_len; a.hdr_bytes = dimg + hb.at_data;
+    a.ph_off = ia.ph_off; a.ph_len = ia.ph_len; a.ph_bytes = dimg + pb.at_data;
     a.dom = job->template scratch<uint32_t>(8 * n, rc);
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.fscal2 = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
@@ -123,8 +119,10 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.out_sc = job->template scratch<uint32_t>((size_t)4 * 8 * n, rc);
     a.out_mhat = job->template scratch<uint32_t>((size_t)std::max(L, 1) * 8 * n, rc);
     if (rc) return rc;
-    if ((rc = job->finish_setup())) return rc;
+    if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
+    ia.status0 = job->d_status0.template as<int8_t>();
+    if (rt::launch<PgIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
     PgJob<C>* j = job.get();
     j->stages.push_back({"pg_scalars", [j]() { return rt::launch<PgScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->stream(), j->a, j->n * NFIX); }});

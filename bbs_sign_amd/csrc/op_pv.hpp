@@ -14,34 +14,6 @@ struct PvJob : JobBase<C> {
     BvState<C> bv{};                  // batch verification only
 };
 
-// Ragged input arrays of one batch inside the staging image: offsets rebased to 0, sections 16-byte aligned.
-struct RaggedIn {
-    const uint64_t* off;      // n + 1 caller offsets, or nullptr (every item empty)
-    const uint8_t* data;
-    size_t elem;              // bytes per element
-    uint64_t total = 0;       // elements
-    size_t at_off = 0, at_data = 0;
-    // false: offsets decrease, or data missing
-    bool measure(size_t n) {
-        total = 0;
-        if (!off) return true;
-        for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
-        total = off[n] - off[0];
-        return total == 0 || data != nullptr;
-    }
-    void place(size_t& cur, size_t n) {
-        at_off = cur; cur += ((n + 1) * 8 + 15) & ~(size_t)15;
-        at_data = cur; cur += ((size_t)total * elem + 4 + 15) & ~(size_t)15;
-    }
-    void fill(uint8_t* img, size_t n) const {
-        uint64_t* o = reinterpret_cast<uint64_t*>(img + at_off);
-        if (!off) { std::memset(o, 0, (n + 1) * 8); return; }
-        const uint64_t b = off[0];
-        for (size_t i = 0; i <= n; i++) o[i] = off[i] - b;
-        if (total) std::memcpy(img + at_data, data + b * elem, (size_t)total * elem);
-    }
-};
-
 template <class C>
 int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t* commitments,
                      const uint64_t* commit_off, const uint8_t* dmsgs, const uint64_t* dmsg_off,
@@ -63,14 +35,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
              hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
     if (!cm.measure(n) || !dm.measure(n) || !di.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
-    size_t cur = (n * rec + 15) & ~(size_t)15;
-    cm.place(cur, n); dm.place(cur, n); di.place(cur, n); hb.place(cur, n); pb.place(cur, n);
-    const size_t img_bytes = cur;
-    if (job->h_raw.alloc(img_bytes) || job->d_raw.alloc(img_bytes)) return BBS_E_NOMEM;
-    uint8_t* img = job->h_raw.template as<uint8_t>();
-    if (n) std::memcpy(img, proofs_fixed, n * rec);
-    cm.fill(img, n); dm.fill(img, n); di.fill(img, n); hb.fill(img, n); pb.fill(img, n);
-    if (rt::h2d_async(job->d_raw.p, img, img_bytes, job->stream())) return BBS_E_HIP;
+    if (int rc0 = stage_image(job.get(), n, proofs_fixed, rec, {&cm, &dm, &di, &hb, &pb})) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
     auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };

@@ -8,6 +8,7 @@ template <class C>
 struct SgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     SgArgs<C> a{};
+    VfIngestArgs<C> ingest{};
     int fetch_signatures(uint8_t* out) override {
         constexpr int N = C::FpP::NC;       // canonical words
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
@@ -30,40 +31,43 @@ template <class C>
 int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* headers,
                      const uint64_t* hdr_off, bbs_job** out) {
     constexpr int N = C::FpP::N;
-    using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->sk_set) return BBS_E_STATE;
     if (!out || (n && !msg_off)) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
     const int L = ctx->L;
     auto job = std::unique_ptr<SgJob<C>>(new SgJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, ST_PENDING);
-    Soa sm;
-    sm.init((size_t)std::max(L, 1) * 8, n);
-    for (size_t i = 0; i < n; i++) {
-        int8_t& st = job->status0[i];
-        const size_t l = (size_t)(msg_off[i + 1] - msg_off[i]);
-        if (l != (size_t)L) { st = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }   // sign.rs:77-79
-        if (ctx->dst_too_long) { st = BBS_ST_PANIC_DST_TOO_LONG; continue; }
-        bool ok = true;
-        for (size_t j = 0; j < l; j++) ok &= pack_fe<R>(sm, j * 8, i, msgs + (msg_off[i] + j) * 32);
-        if (!ok) st = BBS_ST_NONCANONICAL;
-    }
-    BytePool hp;
-    if (!hp.build(n, headers, hdr_off)) return BBS_E_ARG;
+    // staging image + device-side checks (stage VfIngest without a signature record: sign.rs:77-79's length check,
+    // range checks of the messages, SoA transposition)
+    RaggedIn ms{msg_off, msgs, 32}, hb{hdr_off, headers, 1};
+    if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
+    if (int rc0 = stage_image(job.get(), n, nullptr, 0, {&ms, &hb})) return rc0;
+    const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     int rc = BBS_OK;
+    const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     SgArgs<C>& a = job->a;
     a.n = n; a.L = L; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     std::memcpy(a.sk, ctx->sk, sizeof(a.sk));
-    a.msgs = job->up(sm.soa(), rc);
-    a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
+    uint32_t* smsgs = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
+    uint32_t* offs = job->template scratch<uint32_t>(2 * nn, rc);
+    if (rc) return rc;
+    a.msgs = smsgs;
+    a.hdr_off = offs; a.hdr_len = offs + nn; a.hdr_bytes = dimg + hb.at_data;
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)NFIX * 3 * N * n, rc);
     a.out_a = job->template scratch<uint32_t>((size_t)2 * C::FpP::NC * n, rc);
     a.out_e = job->template scratch<uint32_t>((size_t)8 * n, rc);
     if (rc) return rc;
-    if ((rc = job->finish_setup())) return rc;
+    if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
+    VfIngestArgs<C>& ia = job->ingest;
+    ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 0;
+    ia.rec = nullptr;
+    ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
+    ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
+    ia.sig_a = nullptr; ia.sig_e = nullptr; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;
+    ia.status0 = job->d_status0.template as<int8_t>();
+    if (rt::launch<VfIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
     SgJob<C>* j = job.get();
     j->stages.push_back({"sg_scalars", [j]() { return rt::launch<SgScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"sg_msm_parts", [j]() { return rt::launch<SgMsmPart<C>>(j->stream(), j->a, j->n * NFIX); }});

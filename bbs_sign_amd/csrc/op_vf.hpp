@@ -9,6 +9,7 @@ struct VfJob : JobBase<C> {
     using JobBase<C>::JobBase;
     VfArgs<C> a{};
     PairArgs<C> pa{};
+    VfIngestArgs<C> ingest{};
     BvState<C> bv{};                  // batch verification only
 };
 
@@ -18,7 +19,6 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     constexpr int N = C::FpP::N;
     constexpr int NC = C::FpP::NC;
     constexpr int FPB = 4 * NC;
-    using R = typename C::FrP;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
     if (!out || (n && (!sigs || !msg_off))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
@@ -26,34 +26,39 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t rec = 2 * FPB + 32;
     auto job = std::unique_ptr<VfJob<C>>(new VfJob<C>(ctx));
     job->n = n;
-    job->status0.assign(n, ST_PENDING);
-    Soa sa, se, sm;
-    sa.init(2 * NC, n); se.init(8, n); sm.init((size_t)std::max(L, 1) * 8, n);
-    for (size_t i = 0; i < n; i++) {
-        int8_t& st = job->status0[i];
-        const size_t l = (size_t)(msg_off[i + 1] - msg_off[i]);
-        if (l != (size_t)L) { st = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }   // verify.rs:69-71
-        if (ctx->dst_too_long) { st = BBS_ST_PANIC_DST_TOO_LONG; continue; }
-        bool ok = pack_g1<C>(sa, 0, i, sigs + i * rec);
-        ok &= pack_fe<R>(se, 0, i, sigs + i * rec + 2 * FPB);
-        for (size_t j = 0; j < l; j++) ok &= pack_fe<R>(sm, j * 8, i, msgs + (msg_off[i] + j) * 32);
-        if (!ok) st = BBS_ST_NONCANONICAL;
-    }
-    BytePool hp;
-    if (!hp.build(n, headers, hdr_off)) return BBS_E_ARG;
+    // the batch as one staging image, one asynchronous copy; checks, range checks and the SoA transposition on the
+    // device (stage VfIngest), as for proof_verify
+    RaggedIn ms{msg_off, msgs, 32}, hb{hdr_off, headers, 1};
+    if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
+    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &hb})) return rc0;
+    const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     int rc = BBS_OK;
+    const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     VfArgs<C>& a = job->a;
     a.n = n; a.L = L; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
-    a.sig_a = job->up(sa.soa(), rc); a.sig_e = job->up(se.soa(), rc); a.msgs = job->up(sm.soa(), rc);
-    a.hdr_off = job->up(hp.off, rc); a.hdr_len = job->up(hp.len, rc); a.hdr_bytes = job->up(hp.bytes, rc);
+    uint32_t* sig_a = job->template scratch<uint32_t>((size_t)2 * NC * nn, rc);
+    uint32_t* sig_e = job->template scratch<uint32_t>((size_t)8 * nn, rc);
+    uint32_t* smsgs = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
+    uint32_t* offs = job->template scratch<uint32_t>(2 * nn, rc);
+    if (rc) return rc;
+    a.sig_a = sig_a; a.sig_e = sig_e; a.msgs = smsgs;
+    a.hdr_off = offs; a.hdr_len = offs + nn; a.hdr_bytes = dimg + hb.at_data;
     a.fscal = job->template scratch<uint32_t>((size_t)(L + 2) * 8 * n, rc);
     a.partials = job->template scratch<uint32_t>((size_t)VF_NPARTS * 3 * N * n, rc);
     a.aff = job->template scratch<uint32_t>((size_t)2 * 2 * N * n, rc);
     a.fmiller = job->template scratch<uint32_t>((size_t)2 * 12 * N * n, rc);
     if (rc) return rc;
-    if ((rc = job->finish_setup())) return rc;
+    if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
+    VfIngestArgs<C>& ia = job->ingest;
+    ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 1;
+    ia.rec = reinterpret_cast<const uint32_t*>(dimg);
+    ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
+    ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
+    ia.sig_a = sig_a; ia.sig_e = sig_e; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;
+    ia.status0 = job->d_status0.template as<int8_t>();
+    if (rt::launch<VfIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
     PairArgs<C>& pa = job->pa;
     pa.n = n; pa.cc = a.cc; pa.pa = a.aff; pa.pb = a.aff + (size_t)2 * N * n; pa.negate_b = 0;
     pa.canonical = 0; pa.gate_arr = a.status; pa.gate = ST_PAIRING; pa.out = a.status; pa.fmiller = a.fmiller;

@@ -602,8 +602,7 @@ struct bbs_job {
 template <class C>
 struct JobBase : bbs_job {
     Ctx<C>* ctx;
-    std::vector<int8_t> status0;     // host-validated initial status (ST_PENDING = to compute)
-    DevBuf d_status, d_status0;
+    DevBuf d_status, d_status0;      // per-item statuses; d_status0 = what the ingest stage decided (restored before every run)
     HostBuf h_status;                // page-locked landing area of the submit form
     // the batch as the caller handed it over: page-locked image (source of the ONE asynchronous H2D copy) and the same
     // image on the device, which the ingest stage reads and where headers / presentation headers stay.  Members of
@@ -675,12 +674,6 @@ struct JobBase : bbs_job {
         if (b.alloc(count * sizeof(T))) { rc = BBS_E_NOMEM; return nullptr; }
         return b.as<T>();
     }
-    int finish_setup() {
-        if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
-        if (rt::dmemset(d_status.p, (uint8_t)ST_PENDING, n, stream())) return BBS_E_HIP;     // a job never run has decided nothing
-        if (rt::h2d(d_status0.p, status0.data(), n, stream())) return BBS_E_HIP;
-        return ctx->sync_consts();
-    }
     // the initial statuses come from the device's ingest stage (no host validation pass, no synchronous copy)
     int finish_setup_device() {
         if (d_status.alloc(n ? n : 1) || d_status0.alloc(n ? n : 1)) return BBS_E_NOMEM;
@@ -693,6 +686,50 @@ struct JobBase : bbs_job {
     }
 };
 
+
+// =============================================================================================
+// staging image: the batch as the caller handed it over, one page-locked buffer, one asynchronous copy
+// =============================================================================================
+// Ragged input arrays of one batch inside the staging image: offsets rebased to 0, sections 16-byte aligned.
+struct RaggedIn {
+    const uint64_t* off;      // n + 1 caller offsets, or nullptr (every item empty)
+    const uint8_t* data;
+    size_t elem;              // bytes per element
+    uint64_t total = 0;       // elements
+    size_t at_off = 0, at_data = 0;
+    // false: offsets decrease, or data missing
+    bool measure(size_t n) {
+        total = 0;
+        if (!off) return true;
+        for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+        total = off[n] - off[0];
+        return total == 0 || data != nullptr;
+    }
+    void place(size_t& cur, size_t n) {
+        at_off = cur; cur += ((n + 1) * 8 + 15) & ~(size_t)15;
+        at_data = cur; cur += ((size_t)total * elem + 4 + 15) & ~(size_t)15;
+    }
+    void fill(uint8_t* img, size_t n) const {
+        uint64_t* o = reinterpret_cast<uint64_t*>(img + at_off);
+        if (!off) { std::memset(o, 0, (n + 1) * 8); return; }
+        const uint64_t b = off[0];
+        for (size_t i = 0; i <= n; i++) o[i] = off[i] - b;
+        if (total) std::memcpy(img + at_data, data + b * elem, (size_t)total * elem);
+    }
+};
+
+// Fixed-size records at the start of the image + the ragged sections behind them; allocates the job's page-locked and
+// device buffers, fills the host image and enqueues the ONE host-to-device copy on the job's stream.
+template <class J>
+inline int stage_image(J* job, size_t n, const uint8_t* records, size_t rec_bytes, std::initializer_list<RaggedIn*> sections) {
+    size_t cur = (n * rec_bytes + 15) & ~(size_t)15;
+    for (RaggedIn* s : sections) s->place(cur, n);
+    if (job->h_raw.alloc(cur) || job->d_raw.alloc(cur)) return BBS_E_NOMEM;
+    uint8_t* img = job->h_raw.template as<uint8_t>();
+    if (n && rec_bytes) std::memcpy(img, records, n * rec_bytes);
+    for (RaggedIn* s : sections) s->fill(img, n);
+    return rt::h2d_async(job->d_raw.p, img, cur, job->stream()) ? BBS_E_HIP : BBS_OK;
+}
 
 // =============================================================================================
 // batch verification plumbing shared by proof_verify and verify (pippenger.hpp)

@@ -689,6 +689,55 @@ struct VfArgs {
     uint32_t* fmiller;
 };
 
+// stage 0 of verify (lane per item, once per upload): verify.rs:69-71's length check, range checks of the signature
+// and the messages, transposition of the item-major staging image into the SoA arrays (see PvIngest)
+template <class C>
+struct VfIngestArgs {
+    size_t n;
+    int L, dst_too_long, has_sig;         // has_sig = 0: core_sign (no signature record, only messages)
+    const uint32_t* rec;                  // n records A || e, little-endian words (has_sig)
+    const uint64_t *m_off, *hdr_off64;    // n + 1 entries each, rebased to 0
+    const uint32_t* m;                    // messages, 8 words each
+    uint32_t *sig_a, *sig_e, *msgs, *hdr_off, *hdr_len;
+    int8_t* status0;
+};
+template <class C>
+struct VfIngest {
+    static __host__ __device__ void run(const VfIngestArgs<C>& a, size_t i) {
+        using P = typename C::FpP;
+        using R = typename C::FrP;
+        constexpr int NC = P::NC;
+        const size_t n = a.n;
+        a.hdr_off[i] = (uint32_t)a.hdr_off64[i];
+        a.hdr_len[i] = (uint32_t)(a.hdr_off64[i + 1] - a.hdr_off64[i]);
+        const uint64_t l = a.m_off[i + 1] - a.m_off[i];
+        if (l != (uint64_t)a.L) { a.status0[i] = -1; return; }            // InvalidMessageAndGeneratorsLength
+        if (a.dst_too_long) { a.status0[i] = -23; return; }
+        bool ok = true;
+        if (a.has_sig) {
+            const uint32_t* sg = a.rec + i * (size_t)(2 * NC + 8);
+            for (int c = 0; c < 2; c++) {
+                uint32_t w[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) w[k] = sg[c * NC + k];
+                ok &= limbs_lt_mod<P>(w);
+                soa_st<NC>(a.sig_a + (size_t)c * NC * n, n, i, w);
+            }
+            uint32_t e[8];
+            soa_ld<8>(sg + 2 * NC, 1, 0, e);
+            ok &= limbs_lt_mod<R>(e);
+            soa_st<8>(a.sig_e, n, i, e);
+        }
+        for (uint64_t j = 0; j < l; j++) {
+            uint32_t w[8];
+            soa_ld<8>(a.m + (a.m_off[i] + j) * 8, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.msgs + (size_t)j * 8 * n, n, i, w);
+        }
+        a.status0[i] = ok ? ST_PENDING : (int8_t)-40;
+    }
+};
+
 template <class C>
 struct VfScalars {
     static __host__ __device__ void run(const VfArgs<C>& a, size_t i) {
@@ -864,6 +913,95 @@ struct PgArgs {
     uint32_t* out_pts;        // [3][2NC][n] a_bar, b_bar, d (canonical)
     uint32_t* out_sc;         // [4][8][n]   e^, r1^, r3^, c
     uint32_t* out_mhat;       // [L][8][n]   m^_j at undisclosed slots
+};
+
+// stage 0 of proof_gen (lane per item, once per upload): the checks of proof_gen.rs:133-143 and :229-239 in the
+// reference's order (the count of random scalars is a contract of this ABI and checked on the host), deduplication and
+// sorting of the disclosed indexes (:151-161) through the bit mask, range checks, transposition (see PvIngest)
+template <class C>
+struct PgIngestArgs {
+    size_t n;
+    int L, dst_too_long;
+    const uint32_t* rec;                  // n signature records A || e
+    const uint64_t *m_off, *di_off, *rnd_off, *hdr_off64, *ph_off64;
+    const uint32_t* m;                    // messages
+    const uint64_t* di;                   // disclosed indexes, caller order, duplicates possible
+    const uint32_t* rnd;                  // random scalars: r1, r2, e~, r1~, r3~, then m~_j for the undisclosed j ascending
+    uint32_t *sig_a, *sig_e, *msgs, *dmask, *didx, *rcount, *rnd5, *mtilde, *hdr_off, *hdr_len, *ph_off, *ph_len;
+    int8_t* status0;
+};
+template <class C>
+struct PgIngest {
+    static __host__ __device__ void run(const PgIngestArgs<C>& a, size_t i) {
+        using P = typename C::FpP;
+        using R = typename C::FrP;
+        constexpr int NC = P::NC;
+        const size_t n = a.n;
+        a.hdr_off[i] = (uint32_t)a.hdr_off64[i];
+        a.hdr_len[i] = (uint32_t)(a.hdr_off64[i + 1] - a.hdr_off64[i]);
+        a.ph_off[i] = (uint32_t)a.ph_off64[i];
+        a.ph_len[i] = (uint32_t)(a.ph_off64[i + 1] - a.ph_off64[i]);
+        const uint64_t l = a.m_off[i + 1] - a.m_off[i], r = a.di_off[i + 1] - a.di_off[i];
+        const uint64_t* idx = a.di + a.di_off[i];
+        const int MW = ((a.L > 1 ? a.L : 1) + 31) / 32;
+        for (int w = 0; w < MW; w++) a.dmask[(size_t)w * n + i] = 0;
+        a.rcount[i] = 0;
+        if (r > l) { a.status0[i] = -2; return; }                          // InvalidDisclosedIndicesLength
+        bool bad = false;
+        for (uint64_t k = 0; k < r; k++) bad |= idx[k] >= l;
+        if (bad) { a.status0[i] = -3; return; }                            // InvalidDisclosedIndex
+        if (l != (uint64_t)a.L) { a.status0[i] = -1; return; }             // proof_init: InvalidMessageAndGeneratorsLength
+        uint64_t distinct = 0;
+        for (uint64_t k = 0; k < r; k++) {
+            const size_t j = (size_t)idx[k];
+            uint32_t* wp = a.dmask + (j >> 5) * n + i;
+            const uint32_t w = *wp, bit = 1u << (j & 31);
+            if (!(w & bit)) { *wp = w | bit; distinct++; }
+        }
+        // the random scalars were sized from the un-deduplicated length: a duplicate leaves fewer than 5 + undisclosed
+        if (distinct != r) { a.status0[i] = -4; return; }
+        if (a.dst_too_long) { a.status0[i] = -23; return; }
+        bool ok = true;
+        const uint32_t* sg = a.rec + i * (size_t)(2 * NC + 8);
+        for (int c = 0; c < 2; c++) {
+            uint32_t w[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) w[k] = sg[c * NC + k];
+            ok &= limbs_lt_mod<P>(w);
+            soa_st<NC>(a.sig_a + (size_t)c * NC * n, n, i, w);
+        }
+        uint32_t e[8];
+        soa_ld<8>(sg + 2 * NC, 1, 0, e);
+        ok &= limbs_lt_mod<R>(e);
+        soa_st<8>(a.sig_e, n, i, e);
+        const uint32_t* rs = a.rnd + a.rnd_off[i] * 8;
+        for (int k = 0; k < 5; k++) {
+            uint32_t w[8];
+            soa_ld<8>(rs + 8 * k, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.rnd5 + (size_t)k * 8 * n, n, i, w);
+        }
+        uint32_t ku = 0, kd = 0;
+        const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t j = 0; j < (size_t)l; j++) {
+            uint32_t w[8];
+            soa_ld<8>(a.m + (a.m_off[i] + j) * 8, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.msgs + j * 8 * n, n, i, w);
+            if ((a.dmask[(j >> 5) * n + i] >> (j & 31)) & 1u) {
+                a.didx[(size_t)kd * n + i] = (uint32_t)j;
+                kd++;
+                soa_st<8>(a.mtilde + j * 8 * n, n, i, zero);
+            } else {
+                soa_ld<8>(rs + 8 * (5 + ku), 1, 0, w);
+                ok &= limbs_lt_mod<R>(w);
+                soa_st<8>(a.mtilde + j * 8 * n, n, i, w);
+                ku++;
+            }
+        }
+        a.rcount[i] = kd;
+        a.status0[i] = ok ? ST_PENDING : (int8_t)-40;
+    }
 };
 
 template <class C>

@@ -285,6 +285,20 @@ class Engine:
                                                  st.ctypes.data_as(_lib.c_i8p)), "bbs_core_verify_batch")
         return st[:n]
 
+    def core_verify_submit(self, signatures, messages, headers=None) -> "Job":
+        """bbs_core_verify_submit: everything enqueued, nothing waited for; ``job.wait()`` then ``job.result``."""
+        n = len(signatures)
+        sg = self._sigs(signatures)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_verify_submit(self.h, n, _u8(sg), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
+                                                  st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_core_verify_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        return job
+
     def core_verify_upload(self, signatures, messages, headers=None) -> "Job":
         n = len(signatures)
         sg = self._sigs(signatures)

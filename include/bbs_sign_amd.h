@@ -81,7 +81,7 @@ typedef struct bbs_job bbs_job;
  * ------------------------------------------------------------------------------------------ */
 size_t bbs_fp_bytes(int curve);
 const char* bbs_version(void);
-/* Hash of the sources (bbs_sign_amd/csrc/* and this header) the library was built from; bbs_sign_amd/build.py rebuilds
+/* Hash of the sources (every file under bbs_sign_amd/csrc and this header) the library was built from; bbs_sign_amd/build.py rebuilds
  * when it differs from the tree's (a prebuilt library travels with the tree: staleness is judged by content). */
 const char* bbs_source_hash(void);
 int bbs_device_count(void);
@@ -137,10 +137,11 @@ int bbs_ctx_get_public_key(bbs_ctx* ctx, uint8_t* pk_affine_out, int* is_identit
 int bbs_ctx_get_public_key_compressed(bbs_ctx* ctx, uint8_t* out, size_t cap, size_t* len_out);
 
 /* ------------------------------------------------------------------------------------------
- * Batched core operations.  `*_upload` validates (reference order of checks), packs and copies
- * the batch to HBM and returns a device-resident job; `bbs_job_run` enqueues the kernels on the
- * context's stream (asynchronous); `bbs_job_wait` blocks; `bbs_job_fetch_*` copies results back.
- * The one-shot `*_batch` functions do all of it.
+ * Batched core operations.  `*_upload` stages the batch in page-locked memory, copies it to HBM with one
+ * asynchronous copy and enqueues the ingest kernel -- the reference's checks in the reference's order, range
+ * checks and unpacking run on the device -- and returns a device-resident job; `bbs_job_run` enqueues the
+ * kernels on the job's streams (asynchronous); `bbs_job_wait` blocks; `bbs_job_fetch_*` copies results back.
+ * The one-shot `*_batch` functions do all of it; `*_submit` is the asynchronous one-shot form.
  * ------------------------------------------------------------------------------------------ */
 
 /* core_proof_verify (src/proof_verify.rs:64-116 with proof_verify_init :119-188).
@@ -182,6 +183,10 @@ int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
 int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                           const uint8_t* messages, const uint64_t* msg_off,
                           const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
+/* asynchronous form, as bbs_core_proof_verify_submit: bbs_job_wait(job) delivers `status`, then bbs_job_free(job) */
+int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                           const uint8_t* messages, const uint64_t* msg_off,
+                           const uint8_t* headers, const uint64_t* hdr_off, int8_t* status, bbs_job** job_out);
 
 /* core_sign (src/sign.rs:63-133); needs bbs_ctx_set_secret_key.
  * signatures_out: n records A || e (status 1 where written). */

@@ -854,6 +854,23 @@ def check_submit(curve, lib_path=None, n=7, L=4, seed=23):
             idx[(k + 3) % n] = idx[(k + 3) % n] + [idx[(k + 3) % n][0]]   # duplicate: the reference panics, -22 (or -1)
             dm[(k + 3) % n] = dm[(k + 3) % n] + [7]
         batches.append((proofs, dm, idx, headers, phs))
+    # core_verify through its submit form: two batches in flight, a forged message, a non-canonical e, a wrong length
+    vjobs, vwant = [], []
+    for b in range(2):
+        msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+        headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+        sigs, st = eng.core_sign_batch(msgs, headers)
+        vm = [list(m) for m in msgs]
+        vm[b][0] = (vm[b][0] + 1) % c.r
+        vs = [Signature(s_.a, s_.e) for s_ in sigs]
+        vs[b + 2] = Signature(sigs[b + 2].a, c.r + 5)
+        vm[b + 4] = vm[b + 4][:-1]
+        vjobs.append(eng.core_verify_submit(vs, vm, headers))
+        vwant.append([int(x) for x in eng.core_verify_batch(vs, vm, headers)])
+    for job, want in zip(vjobs, vwant):
+        job.wait()
+        assert [int(x) for x in job.result] == want and 0 in want and -40 in want and -1 in want, want
+        job.free()
     jobs = [eng.core_proof_verify_submit(*b) for b in batches]            # all in flight
     for job, b in zip(jobs, batches):
         job.wait()
