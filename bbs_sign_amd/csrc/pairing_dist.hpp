@@ -75,6 +75,14 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 #ifndef BBS_DIST_TWOPASS
 #define BBS_DIST_TWOPASS 0
 #endif
+// per phase: the Miller-loop operations (d_sqr, d_mul_line) and the final-exponentiation operations (d_mul, the
+// cyclotomic square) can be switched separately -- with BBS_PAIR_SPLIT they live in different kernels
+#ifndef BBS_DIST_TWOPASS_MILLER
+#define BBS_DIST_TWOPASS_MILLER BBS_DIST_TWOPASS
+#endif
+#ifndef BBS_DIST_TWOPASS_FINAL
+#define BBS_DIST_TWOPASS_FINAL BBS_DIST_TWOPASS
+#endif
 #ifndef BBS_DIST_UNROLL
 #define BBS_DIST_UNROLL 1        // iterations of the dot-product loops kept rolled (1) or unrolled (6 / 4): A/B knob
 #endif
@@ -85,7 +93,7 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 template <class C>
 __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
     const int k = L.m;
-#if BBS_DIST_TWOPASS
+#if BBS_DIST_TWOPASS_FINAL
     F2AccLo<C> lo;
     f2acc_lo_zero<C>(lo);
 #pragma unroll 1
@@ -145,7 +153,7 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
     uint32_t pk = PK[0];
 #pragma unroll
     for (int q = 1; q < 6; q++) pk = (k == q) ? PK[q] : pk;
-#if BBS_DIST_TWOPASS
+#if BBS_DIST_TWOPASS_MILLER
     // slot s: operands and weight (fetched in both passes)
     auto slot = [&](int s, Fp2<C>& a, Fp2<C>& b, uint32_t& sh) {
         const uint32_t i = (pk >> (6 * s)) & 7u, j = (pk >> (6 * s + 3)) & 7u;
@@ -319,7 +327,7 @@ BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEnt
     Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
     a = f2_sel<C>(k < SA, f2_mul_xi<C>(a), a);
     b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
-#if BBS_DIST_TWOPASS
+#if BBS_DIST_TWOPASS_MILLER
     F2AccLo<C> lo;
     f2acc_lo_zero<C>(lo);
     if constexpr (C::K::TWIST_M) {
@@ -397,7 +405,7 @@ BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     Fp2<C> sq;                                              // lane m<3: X2[0] of pair m ; m>=3: X2[1] of pair m-3
 #if BBS_DIST_LAZY
     if constexpr (C::K::XI_C0 == 1) {                       // BN254 (xi = 9 + u, 10 limbs): measured no faster, old form kept
-#if BBS_DIST_TWOPASS
+#if BBS_DIST_TWOPASS_FINAL
         sq = fp4_sqr_part2<C>(hi, g, px);                   // the same in two passes over the columns
 #else
         sq = fp4_sqr_part<C>(hi, g, px);                    // tower.hpp: four column products, one reduction pair
