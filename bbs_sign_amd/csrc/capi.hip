@@ -318,8 +318,8 @@ int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
                                  const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                  const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job),
-                    pv_upload<BnCurve>(AS_BN(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job));
+    return DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr),
+                    pv_upload<BnCurve>(AS_BN(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr));
 }
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                            const uint8_t* h, const uint64_t* ho, bbs_job** job) {
@@ -444,6 +444,33 @@ int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* pf, const
                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
     bbs_job* job = nullptr;
     int rc = bbs_core_proof_verify_submit(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
+// proof_verify from proof OCTET strings: decoding (square roots, subgroup checks) on the device, then the same pipeline
+int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
+                                   const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
+                                   const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
+                                   bbs_job** job_out) {
+    if (!ctx || !status || !job_out || (n && !oct_off)) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off),
+                      pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off));
+    if (rc) return rc;
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
+                                  const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
+                                  const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_proof_verify_octets_submit(ctx, n, oct, oct_off, dm, dmo, di, dio, h, ho, ph, pho, status, &job);
     if (rc) return rc;
     rc = job->wait();
     delete job;

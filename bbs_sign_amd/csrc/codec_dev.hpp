@@ -73,67 +73,196 @@ BBS_HD_NOINLINE Fe<P> fe_sqrt_candidate(const Fe<P>& a) {
     return r;
 }
 
+// one compressed point (fp_bytes octets at `in`, any alignment) -> canonical affine words o[2 NC] (zeros unless the
+// code is 0).  Code: 0 ok, 1 ok and the identity, -40 malformed / non-canonical, -41 not on the curve / not in the subgroup.
+template <class C>
+__host__ __device__ inline int8_t g1_decode_octets(const uint8_t* in, uint32_t* o) {
+    using P = typename C::FpP;
+    constexpr int NC = P::NC, NB = 4 * NC;
+    uint32_t w[NC];
+#pragma unroll
+    for (int k = 0; k < 2 * NC; k++) o[k] = 0;
+    bool inf, ybig;
+    uint32_t rest = 0;                                              // OR of the value bytes (for the identity encoding)
+    if constexpr (C::ID == 0) {
+        const uint32_t b0 = in[0];
+        if (!(b0 & 0x80u)) return -40;
+        inf = (b0 & 0x40u) != 0; ybig = (b0 & 0x20u) != 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {                              // big-endian bytes -> little-endian words
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t byte = in[NB - 1 - (4 * k + j)];
+                if (4 * k + j == NB - 1) byte &= 0x1Fu;
+                v |= byte << (8 * j);
+            }
+            w[k] = v; rest |= v;
+        }
+    } else {
+        const uint32_t bl = in[NB - 1];
+        inf = (bl & 0x40u) != 0; ybig = (bl & 0x80u) != 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t byte = in[4 * k + j];
+                if (4 * k + j == NB - 1) byte &= 0x3Fu;
+                v |= byte << (8 * j);
+            }
+            w[k] = v; rest |= v;
+        }
+    }
+    if (inf) return (rest == 0 && !ybig) ? 1 : -40;
+    if (!limbs_lt_mod<P>(w)) return -40;
+    const Fe<P> x = fe_from_words<P>(w);
+    const Fe<P> rhs = fe_add<P>(fe_mul<P>(fe_sqr<P>(x), x), curve_b<C>());
+    Fe<P> y = fe_sqrt_candidate<P>(rhs);
+    if (!fe_eq<P>(fe_sqr<P>(y), rhs)) return -41;
+    uint32_t yw[NC];
+    fe_to_words<P>(y, yw);
+    if (words_gt_half<P>(yw) != ybig) { y = fe_neg<P>(y); fe_to_words<P>(y, yw); }
+    const G1Aff<C> pt = {x, y};
+    if (!g1_in_subgroup_endo<C>(pt)) return -41;
+#pragma unroll
+    for (int k = 0; k < NC; k++) { o[k] = w[k]; o[NC + k] = yw[k]; }
+    return 0;
+}
+
 template <class C>
 struct G1Decode {
     static __host__ __device__ void run(const G1DecodeArgs<C>& a, size_t t) {
-        using P = typename C::FpP;
-        constexpr int NC = P::NC, NB = 4 * NC;
-        const uint8_t* in = a.in + t * NB;
-        uint32_t w[NC], zero[2 * NC];
-#pragma unroll
-        for (int k = 0; k < 2 * NC; k++) zero[k] = 0;
-        bool inf, ybig;
-        uint32_t rest = 0;                                              // OR of the value bytes (for the identity encoding)
-        if constexpr (C::ID == 0) {
-            const uint32_t b0 = in[0];
-            if (!(b0 & 0x80u)) { a.code[t] = -40; soa_st<2 * NC>(a.out, a.n_points, t, zero); return; }
-            inf = (b0 & 0x40u) != 0; ybig = (b0 & 0x20u) != 0;
-#pragma unroll
-            for (int k = 0; k < NC; k++) {                              // big-endian bytes -> little-endian words
-                uint32_t v = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t byte = in[NB - 1 - (4 * k + j)];
-                    if (4 * k + j == NB - 1) byte &= 0x1Fu;
-                    v |= byte << (8 * j);
-                }
-                w[k] = v; rest |= v;
-            }
-        } else {
-            const uint32_t bl = in[NB - 1];
-            inf = (bl & 0x40u) != 0; ybig = (bl & 0x80u) != 0;
-#pragma unroll
-            for (int k = 0; k < NC; k++) {
-                uint32_t v = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t byte = in[4 * k + j];
-                    if (4 * k + j == NB - 1) byte &= 0x3Fu;
-                    v |= byte << (8 * j);
-                }
-                w[k] = v; rest |= v;
-            }
-        }
-        if (inf) {
-            a.code[t] = (rest == 0 && !ybig) ? 1 : -40;
-            soa_st<2 * NC>(a.out, a.n_points, t, zero);
-            return;
-        }
-        if (!limbs_lt_mod<P>(w)) { a.code[t] = -40; soa_st<2 * NC>(a.out, a.n_points, t, zero); return; }
-        const Fe<P> x = fe_from_words<P>(w);
-        const Fe<P> rhs = fe_add<P>(fe_mul<P>(fe_sqr<P>(x), x), curve_b<C>());
-        Fe<P> y = fe_sqrt_candidate<P>(rhs);
-        if (!fe_eq<P>(fe_sqr<P>(y), rhs)) { a.code[t] = -41; soa_st<2 * NC>(a.out, a.n_points, t, zero); return; }
-        uint32_t yw[NC];
-        fe_to_words<P>(y, yw);
-        if (words_gt_half<P>(yw) != ybig) { y = fe_neg<P>(y); fe_to_words<P>(y, yw); }
-        const G1Aff<C> pt = {x, y};
-        if (!g1_in_subgroup_endo<C>(pt)) { a.code[t] = -41; soa_st<2 * NC>(a.out, a.n_points, t, zero); return; }
+        constexpr int NC = C::FpP::NC, NB = 4 * NC;
         uint32_t o[2 * NC];
-#pragma unroll
-        for (int k = 0; k < NC; k++) { o[k] = w[k]; o[NC + k] = yw[k]; }
+        a.code[t] = g1_decode_octets<C>(a.in + t * NB, o);
         soa_st<2 * NC>(a.out, a.n_points, t, o);
-        a.code[t] = 0;
+    }
+};
+
+// ---- proof_verify from the wire: proof OCTET strings in, statuses out ---------------------------------------------
+// The octet form of the reference's vectors (src/tests/test_vector.rs:199-260): compress(Abar) || compress(Bbar) ||
+// compress(D) || e^ || r1^ || r3^ || m^_1 .. m^_U || c, scalars 32 bytes big-endian.  Two stages replace PvIngest:
+//   PvOctDecode (lane per (item, point)): decompression (square root), on-curve and prime-order-subgroup checks
+//   PvOctIngest (lane per item): shape of the octet string, the three point verdicts (identity rejected), scalars
+//       big-endian -> words with range checks, THEN the reference's proof_verify_init checks, slots / mask / indexes.
+// Verdict order = bbs_proof_from_octets followed by core_proof_verify: -42 shape, the first failing point's code, -40
+// scalars, then -3 / -6 / -1 / -23 / -22.  The points are known to be in G1 afterwards, so the variable-base terms
+// may use the GLV split without the caller vouching for anything.
+template <class C>
+struct PvOctArgs {
+    size_t n;
+    int L, dst_too_long;
+    const uint8_t* oct;                   // proof octets, ragged
+    const uint64_t *oct_off, *dm_off, *di_off, *hdr_off64, *ph_off64;   // n + 1 entries each, rebased to 0
+    const uint32_t* dm;                   // disclosed messages, 8 words each (scalars, as core_proof_verify takes them)
+    const uint64_t* di;
+    uint32_t *pts, *sc, *slots, *dmask, *didx, *rcount, *hdr_off, *hdr_len, *ph_off, *ph_len;
+    int8_t* pcode;                        // [3 n] per point: G1 decode code
+    int8_t* status0;
+};
+template <class C>
+BBS_HD bool pv_oct_shape(const PvOctArgs<C>& a, size_t i, size_t& u) {
+    constexpr size_t NB = 4 * C::FpP::NC, FIXED = 3 * NB + 4 * 32;
+    const uint64_t len = a.oct_off[i + 1] - a.oct_off[i];
+    if (len < FIXED || (len - FIXED) % 32) return false;
+    u = (size_t)((len - FIXED) / 32);
+    return true;
+}
+template <class C>
+struct PvOctDecode {
+    static __host__ __device__ void run(const PvOctArgs<C>& a, size_t t) {
+        constexpr int NC = C::FpP::NC;
+        constexpr size_t NB = 4 * NC;
+        const size_t i = t / 3;
+        const int p = (int)(t - 3 * i);
+        size_t u;
+        uint32_t o[2 * NC];
+        int8_t code = -42;
+        if (pv_oct_shape<C>(a, i, u)) code = g1_decode_octets<C>(a.oct + a.oct_off[i] + (size_t)p * NB, o);
+        else {
+#pragma unroll
+            for (int k = 0; k < 2 * NC; k++) o[k] = 0;
+        }
+        a.pcode[t] = code;
+        soa_st<2 * NC>(a.pts + (size_t)p * 2 * NC * a.n, a.n, i, o);
+    }
+};
+template <class C>
+struct PvOctIngest {
+    // 32 big-endian bytes (any alignment) -> 8 little-endian words
+    static __host__ __device__ void be32(const uint8_t* b, uint32_t* w) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint8_t* q = b + 28 - 4 * k;
+            w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+        }
+    }
+    static __host__ __device__ void run(const PvOctArgs<C>& a, size_t i) {
+        using R = typename C::FrP;
+        constexpr size_t NB = 4 * C::FpP::NC;
+        const size_t n = a.n;
+        a.hdr_off[i] = (uint32_t)a.hdr_off64[i];
+        a.hdr_len[i] = (uint32_t)(a.hdr_off64[i + 1] - a.hdr_off64[i]);
+        a.ph_off[i] = (uint32_t)a.ph_off64[i];
+        a.ph_len[i] = (uint32_t)(a.ph_off64[i + 1] - a.ph_off64[i]);
+        const int MW = ((a.L > 1 ? a.L : 1) + 31) / 32;
+        for (int w = 0; w < MW; w++) a.dmask[(size_t)w * n + i] = 0;
+        a.rcount[i] = 0;
+        size_t u;
+        if (!pv_oct_shape<C>(a, i, u)) { a.status0[i] = -42; return; }
+        int8_t verdict = ST_PENDING;
+        for (int p = 2; p >= 0; p--) {                   // the first failing point (lowest p) decides
+            const int8_t c = a.pcode[3 * i + p];
+            if (c == 1) verdict = -42;                    // octets_to_proof rejects identity points
+            else if (c < 0) verdict = c;
+        }
+        const uint8_t* s = a.oct + a.oct_off[i] + 3 * NB;
+        bool ok = true;
+        uint32_t w[8];
+        for (int k = 0; k < 3; k++) { be32(s + 32 * k, w); ok &= limbs_lt_mod<R>(w); soa_st<8>(a.sc + (size_t)k * 8 * n, n, i, w); }
+        be32(s + 96 + 32 * u, w); ok &= limbs_lt_mod<R>(w); soa_st<8>(a.sc + (size_t)3 * 8 * n, n, i, w);
+        for (size_t k = 0; k < u; k++) { be32(s + 96 + 32 * k, w); ok &= limbs_lt_mod<R>(w); }
+        if (verdict == ST_PENDING && !ok) verdict = -40;
+        if (verdict != ST_PENDING) { a.status0[i] = verdict; return; }
+        // from here: proof_verify_init's checks (src/proof_verify.rs:139-150) exactly as PvIngest
+        const uint64_t r = a.di_off[i + 1] - a.di_off[i], rm = a.dm_off[i + 1] - a.dm_off[i];
+        const uint64_t l = (uint64_t)u + r;
+        const uint64_t* idx = a.di + a.di_off[i];
+        bool bad = false;
+        for (uint64_t k = 0; k < r; k++) bad |= idx[k] >= l;
+        int8_t st = ST_PENDING;
+        if (bad) st = -3;
+        else if (rm != r) st = -6;
+        else if (l != (uint64_t)a.L) st = -1;
+        else if (a.dst_too_long) st = -23;
+        else {
+            uint64_t distinct = 0;
+            for (uint64_t k = 0; k < r; k++) {
+                const size_t j = (size_t)idx[k];
+                uint32_t* wp = a.dmask + (j >> 5) * n + i;
+                const uint32_t x = *wp, bit = 1u << (j & 31);
+                if (!(x & bit)) { *wp = x | bit; distinct++; }
+            }
+            if (distinct != r) st = -22;
+        }
+        if (st != ST_PENDING) { a.status0[i] = st; return; }
+        for (uint64_t k = 0; k < r; k++) {
+            const size_t j = (size_t)idx[k];
+            soa_ld<8>(a.dm + (a.dm_off[i] + k) * 8, 1, 0, w);
+            ok &= limbs_lt_mod<R>(w);
+            soa_st<8>(a.slots + j * 8 * n, n, i, w);
+            a.didx[(size_t)k * n + i] = (uint32_t)j;
+        }
+        size_t cu = 0;
+        for (size_t j = 0; j < (size_t)l; j++) {
+            if ((a.dmask[(j >> 5) * n + i] >> (j & 31)) & 1u) continue;
+            be32(s + 96 + 32 * cu, w);
+            soa_st<8>(a.slots + j * 8 * n, n, i, w);
+            cu++;
+        }
+        a.rcount[i] = (uint32_t)r;
+        a.status0[i] = ok ? ST_PENDING : (int8_t)-40;
     }
 };
 

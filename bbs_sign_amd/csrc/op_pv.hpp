@@ -11,19 +11,26 @@ struct PvJob : JobBase<C> {
     PairArgs<C> pa{};
     PvFinishArgs fin{};
     PvIngestArgs<C> ingest{};
+    PvOctArgs<C> oct{};               // wire form only
     BvState<C> bv{};                  // batch verification only
 };
 
+// octets / oct_off != nullptr: the wire form (bbs_proof_verify_octets_*): proofs_fixed / commitments / commit_off are
+// ignored, the proofs come as octet strings and are decoded on the device (codec_dev.hpp PvOctDecode / PvOctIngest)
 template <class C>
 int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t* commitments,
                      const uint64_t* commit_off, const uint8_t* dmsgs, const uint64_t* dmsg_off,
                      const uint64_t* didx, const uint64_t* didx_off, const uint8_t* headers,
-                     const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off, bbs_job** out) {
+                     const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off, bbs_job** out,
+                     const uint8_t* octets, const uint64_t* oct_off) {
+    const bool wire = oct_off != nullptr;
     constexpr int N = C::FpP::N;        // internal limbs
     constexpr int NC = C::FpP::NC;      // canonical 32-bit words
     constexpr int FPB = 4 * NC;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
-    if (!out || (n && (!proofs_fixed || !commit_off || !dmsg_off || !didx_off))) return BBS_E_ARG;
+    if (!out || (n && (!dmsg_off || !didx_off))) return BBS_E_ARG;
+    if (n && !wire && (!proofs_fixed || !commit_off)) return BBS_E_ARG;
+    if (n && wire && !octets) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
     const int L = ctx->L;
     const size_t rec = 6 * FPB + 128;
@@ -31,11 +38,12 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     job->n = n;
     // ---- the batch as one staging image in page-locked memory, one asynchronous copy; everything else (the
     // reference's checks, range checks, unpacking, the SoA transposition) happens on the device: stage PvIngest
-    RaggedIn cm{commit_off, commitments, 32}, dm{dmsg_off, dmsgs, 32}, di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8},
-             hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
+    // first ragged section: the commitments (core form) or the proof octet strings (wire form)
+    RaggedIn cm{wire ? oct_off : commit_off, wire ? octets : commitments, wire ? (size_t)1 : (size_t)32}, dm{dmsg_off, dmsgs, 32},
+             di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8}, hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
     if (!cm.measure(n) || !dm.measure(n) || !di.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
-    if (int rc0 = stage_image(job.get(), n, proofs_fixed, rec, {&cm, &dm, &di, &hb, &pb})) return rc0;
+    if (int rc0 = stage_image(job.get(), n, wire ? nullptr : proofs_fixed, wire ? 0 : rec, {&cm, &dm, &di, &hb, &pb})) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
     auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };
@@ -43,7 +51,8 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     PvArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
+    // wire form: every point has passed the subgroup check of the decoder, the GLV split needs no vouching
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup || wire)) ? 1 : 0;
     a.nvar = ctx->latency_mode ? PV_NVAR_SPLIT : PV_NVAR;
     uint32_t* pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * nn, rc);
     uint32_t* sc = job->template scratch<uint32_t>((size_t)4 * 8 * nn, rc);
@@ -68,16 +77,30 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     int8_t* pair_ok = job->template scratch<int8_t>(nn, rc);
     if (rc) return rc;
     job->zero_on_reset.push_back({pair_ok, nn});          // a pairing lane that never ran reads as "product != 1"
-    PvIngestArgs<C>& ia = job->ingest;
-    ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0;
-    ia.rec = d32(0);
-    ia.cm_off = d64(cm.at_off); ia.dm_off = d64(dm.at_off); ia.di_off = d64(di.at_off);
-    ia.hdr_off64 = d64(hb.at_off); ia.ph_off64 = d64(pb.at_off);
-    ia.cm = d32(cm.at_data); ia.dm = d32(dm.at_data); ia.di = d64(di.at_data);
-    ia.pts = pts; ia.sc = sc; ia.slots = slots; ia.dmask = dmask; ia.didx = didx_s; ia.rcount = rcount;
-    ia.hdr_off = offs; ia.hdr_len = offs + nn; ia.ph_off = offs + 2 * nn; ia.ph_len = offs + 3 * nn;
-    ia.status0 = job->d_status0.template as<int8_t>();
-    if (rt::launch<PvIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
+    if (!wire) {
+        PvIngestArgs<C>& ia = job->ingest;
+        ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0;
+        ia.rec = d32(0);
+        ia.cm_off = d64(cm.at_off); ia.dm_off = d64(dm.at_off); ia.di_off = d64(di.at_off);
+        ia.hdr_off64 = d64(hb.at_off); ia.ph_off64 = d64(pb.at_off);
+        ia.cm = d32(cm.at_data); ia.dm = d32(dm.at_data); ia.di = d64(di.at_data);
+        ia.pts = pts; ia.sc = sc; ia.slots = slots; ia.dmask = dmask; ia.didx = didx_s; ia.rcount = rcount;
+        ia.hdr_off = offs; ia.hdr_len = offs + nn; ia.ph_off = offs + 2 * nn; ia.ph_len = offs + 3 * nn;
+        ia.status0 = job->d_status0.template as<int8_t>();
+        if (rt::launch<PvIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
+    } else {
+        PvOctArgs<C>& oa = job->oct;
+        oa.n = n; oa.L = L; oa.dst_too_long = ctx->dst_too_long ? 1 : 0;
+        oa.oct = dimg + cm.at_data; oa.oct_off = d64(cm.at_off);
+        oa.dm_off = d64(dm.at_off); oa.di_off = d64(di.at_off); oa.hdr_off64 = d64(hb.at_off); oa.ph_off64 = d64(pb.at_off);
+        oa.dm = d32(dm.at_data); oa.di = d64(di.at_data);
+        oa.pts = pts; oa.sc = sc; oa.slots = slots; oa.dmask = dmask; oa.didx = didx_s; oa.rcount = rcount;
+        oa.hdr_off = offs; oa.hdr_len = offs + nn; oa.ph_off = offs + 2 * nn; oa.ph_len = offs + 3 * nn;
+        oa.pcode = job->template scratch<int8_t>(3 * nn, rc);
+        if (rc) return rc;
+        oa.status0 = job->d_status0.template as<int8_t>();
+        if (rt::launch<PvOctDecode<C>>(job->stream(), oa, 3 * n) || rt::launch<PvOctIngest<C>>(job->stream(), oa, n)) return BBS_E_HIP;
+    }
     PairArgs<C>& pa = job->pa;
     pa.n = n; pa.cc = a.cc; pa.pa = a.pts; pa.pb = a.pts + (size_t)2 * NC * n; pa.negate_b = 1;
     pa.canonical = 1; pa.gate_arr = job->d_status0.template as<int8_t>(); pa.gate = ST_PENDING; pa.out = pair_ok;

@@ -285,6 +285,33 @@ class Engine:
                                                  st.ctypes.data_as(_lib.c_i8p)), "bbs_core_verify_batch")
         return st[:n]
 
+    def _oct_inputs(self, octets, disclosed_msgs, disclosed_idx, headers, phs):
+        n = len(octets)
+        ob, oo = _ragged_bytes(octets)
+        dm, dmo = self._scalars(disclosed_msgs)
+        di, dio = self._indexes(disclosed_idx)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        keep = (ob, oo, dm, dmo, di, dio, hb, ho, pb, po)
+        args = (_u8(ob), _u64(oo), _u8(dm), _u64(dmo), _u64(di), _u64(dio), _u8(hb), _u64(ho), _u8(pb), _u64(po))
+        return n, keep, args
+
+    def proof_verify_octets_batch(self, octets, disclosed_msgs, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+        """bbs_proof_verify_octets_batch: proof octet strings in (decoded and subgroup-checked on the device), statuses out."""
+        n, keep, args = self._oct_inputs(octets, disclosed_msgs, disclosed_idx, headers, phs)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        self._chk(self.lib.bbs_proof_verify_octets_batch(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)), "bbs_proof_verify_octets_batch")
+        return st[:n]
+
+    def proof_verify_octets_submit_packed(self, n, args) -> "Job":
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_proof_verify_octets_submit(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)),
+                  "bbs_proof_verify_octets_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        return job
+
     def core_verify_submit(self, signatures, messages, headers=None) -> "Job":
         """bbs_core_verify_submit: everything enqueued, nothing waited for; ``job.wait()`` then ``job.result``."""
         n = len(signatures)

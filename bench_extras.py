@@ -118,6 +118,27 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     for _ in range(4):
         decode_call()
     bls["proofs_from_octets_per_s"] = 4 * n / (time.perf_counter() - t1)
+    # ... and the fused wire path: proof octets in host buffers -> statuses (decompression, subgroup checks, verification
+    # in one pipeline; GLV for the variable-base terms because the decoder has checked membership), 8 batches in flight
+    nn_o, keep_o, args_o = eng._oct_inputs(octs, dm, disclosed, None, None)
+    pend = []
+    def retire_o():
+        j = pend.pop(0)
+        j.wait()
+        assert (j.result == 1).all()
+        j.free()
+    for k in range(8):
+        pend.append(eng.proof_verify_octets_submit_packed(nn_o, args_o))
+    while pend:
+        retire_o()
+    t1 = time.perf_counter()
+    for k in range(64):
+        if len(pend) >= 8:
+            retire_o()
+        pend.append(eng.proof_verify_octets_submit_packed(nn_o, args_o))
+    while pend:
+        retire_o()
+    bls["proof_verify_from_octets_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
 
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
     sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)

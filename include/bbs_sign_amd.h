@@ -176,6 +176,25 @@ int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* proofs_f
                                  const uint8_t* headers, const uint64_t* hdr_off,
                                  const uint8_t* ph, const uint64_t* ph_off, int8_t* status, bbs_job** job_out);
 
+/* core_proof_verify from the WIRE: the n proofs as octet strings (compress(Abar) || compress(Bbar) || compress(D) || e^ ||
+ * r1^ || r3^ || m^_1 .. m^_U || c, scalars 32 bytes big-endian: the form of src/tests/test_vector.rs:199-260; ragged,
+ * oct_off: n + 1 byte offsets) instead of decoded records.  Decompression (square roots), on-curve and prime-order-subgroup
+ * checks and the scalar range checks run on the device in front of the same pipeline; the per-item status is what
+ * bbs_proof_from_octets followed by bbs_core_proof_verify_batch would give: BBS_ST_INVALID_ENCODING (shape, identity
+ * point), BBS_ST_NONCANONICAL, BBS_ST_NOT_ON_CURVE (also: outside the subgroup) before the reference's own checks.  The
+ * disclosed messages are scalars, as for bbs_core_proof_verify_batch.  Because every point has been subgroup-checked, the
+ * variable-base terms use the GLV split (BLS12-381) without bbs_ctx_set_points_in_subgroup. */
+int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                                   const uint8_t* disclosed_msgs, const uint64_t* dmsg_off,
+                                   const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                   const uint8_t* headers, const uint64_t* hdr_off,
+                                   const uint8_t* ph, const uint64_t* ph_off, int8_t* status, bbs_job** job_out);
+int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                                  const uint8_t* disclosed_msgs, const uint64_t* dmsg_off,
+                                  const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                  const uint8_t* headers, const uint64_t* hdr_off,
+                                  const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
+
 /* core_verify (src/verify.rs:53-93).  signatures: n records  A (G1 affine) || e (scalar). */
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                            const uint8_t* messages, const uint64_t* msg_off,

@@ -978,3 +978,100 @@ def check_large_shapes(curve, lib_path=None, L=100, n=3, seed=51):
     assert list(eng.core_proof_verify_batch(proofs, dm, disclosed, hd2, phs2))[0] == 0
     assert list(eng.core_proof_verify_batch(proofs, dm, disclosed, hd2, phs))[-1] == 0
     eng.close()
+
+
+def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61):
+    """bbs_proof_verify_octets_*: proof OCTET strings in, statuses out, decoding on the device.  Against (a) the
+    composition it replaces, bbs_proofs_from_octets_batch -> bbs_core_proof_verify_batch, item by item, and (b) the oracle:
+    valid proofs, tampered scalars, every kind of malformed encoding (truncated string, missing compression flag,
+    x with no square root, a point outside the subgroup, the identity, a scalar >= r) and the reference's own errors."""
+    from bbs_sign_amd import api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 70]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    octs = [bytearray(api.proof_to_octets(curve, p_, lib_path)) for p_ in proofs]
+    fpb = c.fp_bytes
+    idx = [list(d) for d in disclosed]
+    dmm = [list(d) for d in dm]
+    # 1: e^ tampered (valid encoding, Ok(false)); 2: truncated by one byte; 3: truncated by one scalar (l != L: Err -1)
+    octs[1][3 * fpb + 31] ^= 1
+    octs[2] = octs[2][:-1]
+    octs[3] = octs[3][:-32]
+    # 4: compression flag missing (BLS) / infinity flag with a non-zero value (BN254) -> malformed
+    if curve == "bls12_381":
+        octs[4][0] &= 0x7F
+    else:
+        octs[4][fpb - 1] |= 0x40
+    # 5: x of Bbar replaced by a value with no square root on the curve
+    x = 7
+    while pow((x ** 3 + c.b) % c.p, (c.p - 1) // 2, c.p) == 1:
+        x += 1
+    enc = bytearray(bbs.g1_compress(c, (x, 0)))          # flags + x; y is irrelevant: there is none
+    octs[5][fpb:2 * fpb] = enc
+    # 6: D = an on-curve point of order 3, outside the prime-order subgroup (BLS12-381 only)
+    if curve == "bls12_381":
+        octs[6][2 * fpb:3 * fpb] = bbs.g1_compress(c, (0, 2))
+    # 7: Abar = the identity (rejected by octets_to_proof); 8: r1^ >= r; 9: challenge >= r
+    octs[7][0:fpb] = bbs.g1_compress(c, None)
+    octs[8][3 * fpb + 32:3 * fpb + 64] = (c.r + 3).to_bytes(32, "big")
+    octs[9][-32:] = ((1 << 256) - 1).to_bytes(32, "big")
+    # 10: disclosed index >= l; 11: duplicate disclosed index (only when something is disclosed)
+    idx[10] = idx[10] + [L + 2]; dmm[10] = dmm[10] + [1]
+    if idx[11]:
+        idx[11] = idx[11] + [idx[11][0]]; dmm[11] = dmm[11] + [2]
+    octs = [bytes(o) for o in octs]
+    got = [int(x_) for x_ in eng.proof_verify_octets_batch(octs, dmm, idx, headers, phs)]
+    # (a) the composition
+    dec, dst = eng.proofs_from_octets_batch(octs)
+    want = []
+    for i in range(n):
+        if dst[i] != 1:
+            want.append(int(dst[i]))
+        else:
+            want.append(int(eng.core_proof_verify_batch([dec[i]], [dmm[i]], [idx[i]], [headers[i]], [phs[i]])[0]))
+    assert got == want, (curve, got, want)
+    assert got[0] == 1 and got[1] == 0 and got[2] == -42 and got[3] in (-1, -3) and got[4] == -40 and got[5] == -41, got
+    assert got[7] == -42 and got[8] == -40 and got[9] == -40 and got[10] == -3 and got[12] == 1 and got[13] == 1, got
+    if curve == "bls12_381":
+        assert got[6] == -41, got
+    # (b) the oracle on the well-formed ones
+    for i in (0, 1, 12):
+        p = dec[i]
+        op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+        assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dmm[i], idx[i], api_id)) == got[i]
+    # submit form, two batches in flight, and the reference's own proof vector through the wire path (BLS12-381)
+    nn, keep, args = eng._oct_inputs(octs, dmm, idx, headers, phs)
+    jobs = [eng.proof_verify_octets_submit_packed(nn, args) for _ in range(2)]
+    for j in jobs:
+        j.wait()
+        assert [int(x_) for x_ in j.result] == want
+        j.free()
+    eng.close()
+    if curve == "bls12_381":
+        S = bbs.BLS_SUITE
+        H = bytes.fromhex
+        kat = H("94916292a7a6bade28456c601d3af33fcf39278d6594b467e128a3f83686a104ef2b2fcf72df0215eeaf69262ffe8194a19fab31a82ddbe06908985abc4c9825788b8a1610942d12b7f5debbea8985296361206dbace7af0cc834c80f33e0aadaeea5597befbb651827b5eed5a66f1a959bb46cfd5ca1a817a14475960f69b32c54db7587b5ee3ab665fbd37b506830a49f21d592f5e634f47cee05a025a2f8f94e73a6c15f02301d1178a92873b6e8634bafe4983c3e15a663d64080678dbf29417519b78af042be2b3e1c4d08b8d520ffab008cbaaca5671a15b22c239b38e940cfeaa5e72104576a9ec4a6fad78c532381aeaa6fb56409cef56ee5c140d455feeb04426193c57086c9b6d397d9418")
+        ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+        key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+        key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+        sk2 = bbs.key_gen(S, ikm, key_info, key_dst)
+        e2 = make_engine("bls12_381", bbs.create_generators(S, 2, S.api_id), S.api_id, lib_path, sk=sk2)
+        m1 = bbs.msg_to_scalars(S, [H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")], S.api_id)
+        hdr, ph = H("11223344556677889900aabbccddeeff"), H("bed231d880675ed101ead304512e043ade9958dd0241ea70b4b3957fba941501")
+        assert list(e2.proof_verify_octets_batch([kat], [m1], [[0]], [hdr], [ph])) == [1]      # test_vector.rs:199-260
+        assert list(e2.proof_verify_octets_batch([kat], [m1], [[0]], [hdr], [ph + b"x"])) == [0]
+        e2.close()

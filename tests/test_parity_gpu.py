@@ -97,3 +97,9 @@ def test_latency_mode(curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_large_shapes(curve):
     pc.check_large_shapes(curve, None, L=100, n=4)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_verify_octets(curve):
+    pc.check_proof_verify_octets(curve, None)
+    pc.check_proof_verify_octets(curve, None, n=150, L=7, seed=62)

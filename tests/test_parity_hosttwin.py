@@ -87,3 +87,8 @@ def test_latency_mode(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_large_shapes(twin, curve):
     pc.check_large_shapes(curve, twin, L=40, n=2)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_verify_octets(twin, curve):
+    pc.check_proof_verify_octets(curve, twin)
