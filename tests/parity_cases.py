@@ -980,7 +980,7 @@ def check_large_shapes(curve, lib_path=None, L=100, n=3, seed=51):
     eng.close()
 
 
-def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61):
+def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61, disclose_all_3=False):
     """bbs_proof_verify_octets_*: proof OCTET strings in, statuses out, decoding on the device.  Against (a) the
     composition it replaces, bbs_proofs_from_octets_batch -> bbs_core_proof_verify_batch, item by item, and (b) the oracle:
     valid proofs, tampered scalars, every kind of malformed encoding (truncated string, missing compression flag,
@@ -998,6 +998,8 @@ def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61):
     headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 70]))) for _ in range(n)]
     phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
     disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    if disclose_all_3:                                   # item 3 without commitments: see the "one scalar short" case below
+        disclosed[3] = list(range(L))
     rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
     sigs, st = eng.core_sign_batch(msgs, headers)
     proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
@@ -1044,7 +1046,10 @@ def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61):
         else:
             want.append(int(eng.core_proof_verify_batch([dec[i]], [dmm[i]], [idx[i]], [headers[i]], [phs[i]])[0]))
     assert got == want, (curve, got, want)
-    assert got[0] == 1 and got[1] == 0 and got[2] == -42 and got[3] in (-1, -3) and got[4] == -40 and got[5] == -41, got
+    # 3: one scalar short.  With undisclosed messages that is a proof for l - 1 messages (Err: l != L); with every message
+    # disclosed there is no commitment to drop and the string falls below the floor of 3 points + 4 scalars: malformed
+    want3 = (-42,) if len(disclosed[3]) == L else (-1, -3)
+    assert got[0] == 1 and got[1] == 0 and got[2] == -42 and got[3] in want3 and got[4] == -40 and got[5] == -41, got
     assert got[7] == -42 and got[8] == -40 and got[9] == -40 and got[10] == -3 and got[12] == 1 and got[13] == 1, got
     if curve == "bls12_381":
         assert got[6] == -41, got

@@ -103,3 +103,4 @@ def test_large_shapes(curve):
 def test_proof_verify_octets(curve):
     pc.check_proof_verify_octets(curve, None)
     pc.check_proof_verify_octets(curve, None, n=150, L=7, seed=62)
+    pc.check_proof_verify_octets(curve, None, seed=63, disclose_all_3=True)
