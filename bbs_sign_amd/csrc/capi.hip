@@ -416,12 +416,6 @@ int bbs_job_stage_times(bbs_job* job, float* total_ms, float* kernel_ms, int cap
     return job ? job->stage_times(total_ms, kernel_ms, cap, n_stages) : BBS_E_ARG;
 }
 
-static int run_fetch_free(bbs_job* job, int8_t* status) {
-    int rc = job->run();
-    if (!rc && status) rc = job->fetch_status(status);
-    return rc;
-}
-
 // upload (one asynchronous H2D copy + the ingest kernel) -> kernels -> asynchronous copy of the statuses to page-locked
 // memory; nothing waits for the device.  bbs_job_wait delivers the statuses to `status`.
 int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
@@ -498,13 +492,48 @@ int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uin
     delete job;
     return rc;
 }
-int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
-                        uint8_t* sigs_out, int8_t* status) {
+// sign / proof_gen in the submit form: the records follow the statuses to page-locked memory behind the last stage and
+// bbs_job_wait unpacks them into the caller's buffers (which must stay valid until then)
+static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out) {
+    int rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc && (o1 || o2 || o3)) rc = job->enqueue_result_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    job->set_result_targets(o1, o2, o3);
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_core_sign_submit(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
+                         uint8_t* sigs_out, int8_t* status, bbs_job** job_out) {
+    if (!status || !job_out) return BBS_E_ARG;
     bbs_job* job = nullptr;
     int rc = bbs_core_sign_upload(ctx, n, m, mo, h, ho, &job);
     if (rc) return rc;
-    rc = run_fetch_free(job, status);
-    if (!rc && sigs_out) rc = job->fetch_signatures(sigs_out);
+    return submit_with_results(job, status, sigs_out, nullptr, nullptr, job_out);
+}
+int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                              const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                              const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                              uint8_t* pf_out, uint8_t* cm_out, uint64_t* cmo_out, int8_t* status, bbs_job** job_out) {
+    if (!status || !job_out) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = bbs_core_proof_gen_upload(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, &job);
+    if (rc) return rc;
+    return submit_with_results(job, status, pf_out, cm_out, cmo_out, job_out);
+}
+int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
+                        uint8_t* sigs_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc;
+    if (status) {
+        if ((rc = bbs_core_sign_submit(ctx, n, m, mo, h, ho, sigs_out, status, &job))) return rc;
+        rc = job->wait();
+    } else {                                       // records without statuses: failed items read as zero records
+        if ((rc = bbs_core_sign_upload(ctx, n, m, mo, h, ho, &job))) return rc;
+        rc = job->run();
+        if (!rc && sigs_out) rc = job->fetch_signatures(sigs_out);
+    }
     delete job;
     return rc;
 }
@@ -513,10 +542,15 @@ int bbs_core_proof_gen_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const 
                              const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
                              uint8_t* pf_out, uint8_t* cm_out, uint64_t* cmo_out, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_core_proof_gen_upload(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, &job);
-    if (rc) return rc;
-    rc = run_fetch_free(job, status);
-    if (!rc) rc = job->fetch_proofs(pf_out, cm_out, cmo_out);
+    int rc;
+    if (status) {
+        if ((rc = bbs_core_proof_gen_submit(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, pf_out, cm_out, cmo_out, status, &job))) return rc;
+        rc = job->wait();
+    } else {
+        if ((rc = bbs_core_proof_gen_upload(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, &job))) return rc;
+        rc = job->run();
+        if (!rc) rc = job->fetch_proofs(pf_out, cm_out, cmo_out);
+    }
     delete job;
     return rc;
 }

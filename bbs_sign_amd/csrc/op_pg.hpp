@@ -10,17 +10,12 @@ struct PgJob : JobBase<C> {
     PgArgs<C> a{};
     PgIngestArgs<C> ingest{};
     std::vector<std::vector<uint32_t>> undisclosed;     // per item, sorted
-    int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
+    // proof records + the m^ of the undisclosed messages (ascending index) of the items whose status is 1
+    void unpack(const uint32_t* P, const uint32_t* S, const uint32_t* M, const int8_t* st, uint8_t* pf_out, uint8_t* commit_out,
+                uint64_t* commit_off) const {
         constexpr int N = C::FpP::NC;       // canonical words
         constexpr int FPB = 4 * N;
-        if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
-        const size_t n = this->n;
-        const int L = a.L;
-        std::vector<uint32_t> P((size_t)3 * 2 * N * n), S((size_t)4 * 8 * n), M((size_t)std::max(L, 1) * 8 * n);
-        if (this->down(P, a.out_pts) || this->down(S, a.out_sc) || this->down(M, a.out_mhat)) return BBS_E_HIP;
-        std::vector<int8_t> st(n);
-        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
-        const size_t rec = 6 * FPB + 128;
+        const size_t n = this->n, rec = 6 * FPB + 128;
         uint64_t off = 0;
         for (size_t i = 0; i < n; i++) {
             if (commit_off) commit_off[i] = off;
@@ -35,6 +30,42 @@ struct PgJob : JobBase<C> {
             }
         }
         if (commit_off) commit_off[n] = off;
+    }
+    size_t words_p() const { return (size_t)3 * 2 * C::FpP::NC * this->n; }
+    size_t words_s() const { return (size_t)4 * 8 * this->n; }
+    size_t words_m() const { return (size_t)std::max(a.L, 1) * 8 * this->n; }
+    int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
+        if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
+        const size_t n = this->n;
+        std::vector<uint32_t> P(words_p()), S(words_s()), M(words_m());
+        if (this->down(P, a.out_pts) || this->down(S, a.out_sc) || this->down(M, a.out_mhat)) return BBS_E_HIP;
+        std::vector<int8_t> st(n);
+        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
+        unpack(P.data(), S.data(), M.data(), st.data(), pf_out, commit_out, commit_off);
+        return BBS_OK;
+    }
+    // submit form
+    uint8_t* pf_to = nullptr;
+    uint8_t* cm_to = nullptr;
+    uint64_t* cmo_to = nullptr;
+    HostBuf h_out;
+    void set_result_targets(uint8_t* pf, uint8_t* cm, uint64_t* cmo) override { pf_to = pf; cm_to = cm; cmo_to = cmo; }
+    int enqueue_result_fetch() override {
+        if (!this->n) return BBS_OK;
+        const size_t wp = words_p(), ws = words_s(), wm = words_m();
+        if (!h_out.p && h_out.alloc((wp + ws + wm) * 4)) return BBS_E_NOMEM;
+        uint32_t* h = h_out.template as<uint32_t>();
+        if (rt::d2h_async(h, a.out_pts, wp * 4, this->stream()) || rt::d2h_async(h + wp, a.out_sc, ws * 4, this->stream()) ||
+            rt::d2h_async(h + wp + ws, a.out_mhat, wm * 4, this->stream())) return BBS_E_HIP;
+        return BBS_OK;
+    }
+    int deliver() override {
+        if (int rc = JobBase<C>::deliver()) return rc;
+        if (!pf_to && !cm_to && !cmo_to) return BBS_OK;
+        if (!this->n) { if (cmo_to) cmo_to[0] = 0; return BBS_OK; }
+        if (!h_out.p) return BBS_E_STATE;
+        const uint32_t* h = h_out.template as<uint32_t>();
+        unpack(h, h + words_p(), h + words_p() + words_s(), this->h_status.template as<int8_t>(), pf_to, cm_to, cmo_to);
         return BBS_OK;
     }
 };

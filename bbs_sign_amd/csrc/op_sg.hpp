@@ -9,19 +9,47 @@ struct SgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     SgArgs<C> a{};
     VfIngestArgs<C> ingest{};
-    int fetch_signatures(uint8_t* out) override {
+    // signature records (Rust layout: A affine LE, e LE) of the items whose status is 1, zeros for the others
+    void unpack(const uint32_t* A, const uint32_t* E, const int8_t* st, uint8_t* out) const {
         constexpr int N = C::FpP::NC;       // canonical words
+        const size_t n = this->n, rec = 8 * N + 32;
+        for (size_t i = 0; i < n; i++) {
+            if (st[i] != 1) { std::memset(out + i * rec, 0, rec); continue; }
+            unpack_words_le(A, n, 0, i, 2 * N, out + i * rec);
+            unpack_words_le(E, n, 0, i, 8, out + i * rec + 8 * N);
+        }
+    }
+    int fetch_signatures(uint8_t* out) override {
+        constexpr int N = C::FpP::NC;
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
         std::vector<uint32_t> A((size_t)2 * N * n), E((size_t)8 * n);
         if (this->down(A, a.out_a) || this->down(E, a.out_e)) return BBS_E_HIP;
         std::vector<int8_t> st(n);
         if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
-        const size_t rec = 8 * N + 32;
-        for (size_t i = 0; i < n; i++) {
-            if (st[i] != 1) { std::memset(out + i * rec, 0, rec); continue; }
-            unpack_words_le(A, n, 0, i, 2 * N, out + i * rec);
-            unpack_words_le(E, n, 0, i, 8, out + i * rec + 8 * N);
+        unpack(A.data(), E.data(), st.data(), out);
+        return BBS_OK;
+    }
+    // submit form
+    uint8_t* sigs_to = nullptr;
+    HostBuf h_out;
+    void set_result_targets(uint8_t* sigs, uint8_t*, uint64_t*) override { sigs_to = sigs; }
+    int enqueue_result_fetch() override {
+        constexpr int N = C::FpP::NC;
+        const size_t n = this->n, wa = (size_t)2 * N * n, we = (size_t)8 * n;
+        if (!n) return BBS_OK;
+        if (!h_out.p && h_out.alloc((wa + we) * 4)) return BBS_E_NOMEM;
+        uint32_t* h = h_out.template as<uint32_t>();
+        if (rt::d2h_async(h, a.out_a, wa * 4, this->stream()) || rt::d2h_async(h + wa, a.out_e, we * 4, this->stream())) return BBS_E_HIP;
+        return BBS_OK;
+    }
+    int deliver() override {
+        constexpr int N = C::FpP::NC;
+        if (int rc = JobBase<C>::deliver()) return rc;
+        if (sigs_to && this->n) {
+            if (!h_out.p) return BBS_E_STATE;
+            const uint32_t* h = h_out.template as<uint32_t>();
+            unpack(h, h + (size_t)2 * N * this->n, this->h_status.template as<int8_t>(), sigs_to);
         }
         return BBS_OK;
     }

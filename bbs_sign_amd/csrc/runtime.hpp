@@ -337,8 +337,11 @@ inline bool pack_g1(Soa& s, size_t w0, size_t i, const uint8_t* xy) {
     bool b = pack_fe<typename C::FpP>(s, w0 + NC, i, xy + 4 * NC);
     return a && b;
 }
-inline void unpack_words_le(const std::vector<uint32_t>& v, size_t n, size_t w0, size_t i, int words, uint8_t* out) {
+inline void unpack_words_le(const uint32_t* v, size_t n, size_t w0, size_t i, int words, uint8_t* out) {
     for (int k = 0; k < words; k++) put_le32(out + 4 * k, v[(w0 + k) * n + i]);
+}
+inline void unpack_words_le(const std::vector<uint32_t>& v, size_t n, size_t w0, size_t i, int words, uint8_t* out) {
+    unpack_words_le(v.data(), n, w0, i, words, out);
 }
 
 // ragged bytes -> device pool + u32 offset / len
@@ -558,6 +561,10 @@ struct bbs_job {
     int8_t* deliver_to = nullptr;
     virtual int enqueue_status_fetch() = 0;
     virtual int deliver() = 0;
+    // sign / proof_gen: the produced records follow the statuses to page-locked memory; deliver() unpacks them into the
+    // caller's buffers
+    virtual int enqueue_result_fetch() { return BBS_OK; }
+    virtual void set_result_targets(uint8_t*, uint8_t*, uint64_t*) {}
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
     virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }
     // One pass over the stages.  ev != nullptr: one event before the first stage, then a (start, stop) pair around

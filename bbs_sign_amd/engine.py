@@ -359,6 +359,22 @@ class Engine:
                                                st.ctypes.data_as(_lib.c_i8p)), "bbs_core_sign_batch")
         return self._dec_sigs(out, st, n), st[:n]
 
+    def core_sign_submit(self, messages, headers=None) -> "Job":
+        """bbs_core_sign_submit: everything enqueued, nothing waited for; ``job.wait()`` then ``job.result`` (statuses)
+        and ``job.output()`` -> (signatures | None, statuses)."""
+        n = len(messages)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        out = np.zeros(max(n, 1) * (2 * self.fpb + 32), dtype=np.uint8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_sign_submit(self.h, n, _u8(ms), _u64(mo), _u8(hb), _u64(ho), _u8(out),
+                                                st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_core_sign_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        job._decode = lambda: (self._dec_sigs(out, st, n), st[:n])
+        return job
+
     def core_sign_upload(self, messages, headers=None) -> "Job":
         n = len(messages)
         ms, mo = self._scalars(messages)
@@ -408,6 +424,22 @@ class Engine:
         self._chk(self.lib.bbs_core_proof_gen_batch(self.h, n, *args, _u8(pf), _u8(cm), _u64(cmo),
                                                     st.ctypes.data_as(_lib.c_i8p)), "bbs_core_proof_gen_batch")
         return self._dec_proofs(pf, cm, cmo, st, n), st[:n]
+
+    def core_proof_gen_submit(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None) -> "Job":
+        """bbs_core_proof_gen_submit; ``job.wait()`` then ``job.result`` and ``job.output()`` -> (proofs | None, statuses)."""
+        n, keep, args = self._pg_inputs(signatures, messages, disclosed_idx, random_scalars, headers, phs)
+        total = sum(len(m) for m in messages)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        pf = np.zeros(max(n, 1) * (6 * self.fpb + 128), dtype=np.uint8)
+        cm = np.zeros(max(total, 1) * 32, dtype=np.uint8)
+        cmo = np.zeros(n + 1, dtype=np.uint64)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_core_proof_gen_submit(self.h, n, *args, _u8(pf), _u8(cm), _u64(cmo),
+                                                     st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_core_proof_gen_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        job._decode = lambda: (self._dec_proofs(pf, cm, cmo, st, n), st[:n])
+        return job
 
     def core_proof_gen_upload(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None) -> "Job":
         n, keep, args = self._pg_inputs(signatures, messages, disclosed_idx, random_scalars, headers, phs)
@@ -552,12 +584,21 @@ class Job:
         self.eng, self.h, self.n = eng, handle, n
         self.total_msgs = 0
         self.result = None          # submit form: the statuses, valid after wait()
+        self._decode = None         # submit form of sign / proof_gen: decodes the delivered records
+        self._waited = False
 
     def run(self):
         Engine._chk(self.eng.lib.bbs_job_run(self.h), "bbs_job_run")
 
     def wait(self):
         Engine._chk(self.eng.lib.bbs_job_wait(self.h), "bbs_job_wait")
+        self._waited = True
+
+    def output(self):
+        """Submit form of sign / proof_gen, after wait(): (signatures | proofs with None for failed items, statuses)."""
+        if self._decode is None or not self._waited:
+            raise RuntimeError("output(): a sign / proof_gen submit job that has been waited for")
+        return self._decode()
 
     def status(self) -> np.ndarray:
         st = np.zeros(max(self.n, 1), dtype=np.int8)

@@ -214,6 +214,11 @@ int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* messages, const 
 int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
                         const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signatures_out,
                         int8_t* status);
+/* asynchronous form: returns with everything enqueued; bbs_job_wait(job) delivers `status` and writes the records into
+ * signatures_out (may be NULL); both buffers must stay valid until then.  The inputs may be released on return. */
+int bbs_core_sign_submit(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
+                         const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signatures_out,
+                         int8_t* status, bbs_job** job_out);
 
 /* core_proof_gen (src/proof_gen.rs:116-208: proof_init :211-269, proof_challenge_calculate
  * :272-328, proof_finalize :331-365).  random_scalars replaces the draw at :145-149 and must hold
@@ -234,6 +239,15 @@ int bbs_core_proof_gen_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                              const uint8_t* ph, const uint64_t* ph_off,
                              uint8_t* proofs_fixed_out, uint8_t* commitments_out,
                              uint64_t* commit_off_out, int8_t* status);
+/* asynchronous form, as bbs_core_sign_submit: bbs_job_wait(job) delivers `status` and the three outputs */
+int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                              const uint8_t* messages, const uint64_t* msg_off,
+                              const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                              const uint8_t* random_scalars, const uint64_t* rnd_off,
+                              const uint8_t* headers, const uint64_t* hdr_off,
+                              const uint8_t* ph, const uint64_t* ph_off,
+                              uint8_t* proofs_fixed_out, uint8_t* commitments_out,
+                              uint64_t* commit_off_out, int8_t* status, bbs_job** job_out);
 
 int bbs_job_run(bbs_job* job);                       /* asynchronous */
 int bbs_job_wait(bbs_job* job);

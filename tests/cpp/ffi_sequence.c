@@ -79,6 +79,16 @@ static int run_curve(int curve) {
     memset(st, 99, sizeof st);
     CHECK(bbs_core_sign_batch(ctx, N, scal, mo, hdr_bytes, ho, sigs, st) == BBS_OK);                                     /* step 11 */
     CHECK(st[0] == 1 && st[1] == 1 && st[2] == 1 && st[3] == BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH);
+    {   /* the same batch through the asynchronous form: records and statuses arrive at bbs_job_wait */
+        uint8_t sigs2[N * (2 * 48 + 32)];
+        int8_t st2[N];
+        bbs_job* sj = NULL;
+        memset(sigs2, 0xEE, sizeof sigs2); memset(st2, 99, sizeof st2);
+        CHECK(bbs_core_sign_submit(ctx, N, scal, mo, hdr_bytes, ho, sigs2, st2, &sj) == BBS_OK && sj);
+        CHECK(bbs_job_wait(sj) == BBS_OK);
+        bbs_job_free(sj);
+        CHECK(memcmp(st, st2, sizeof st) == 0 && memcmp(sigs, sigs2, N * sig_rec) == 0);
+    }
 
     /* ---- PublicKey::verify: items 0..2; item 1's first message altered -> Ok(false) ------------------------------- */
     uint8_t scal_v[3 * L * 32];
@@ -122,6 +132,20 @@ static int run_curve(int curve) {
     CHECK(bbs_core_proof_gen_batch(vctx, N, sig4, scal4, mo4, di, dio, rnd, ro, hdr4, ho4, ph_bytes, po, pf, cm, cmo, st) == BBS_OK);   /* step 14 */
     CHECK(st[0] == 1 && st[1] == 1 && st[2] == 1 && st[3] == BBS_ST_INVALID_DISCLOSED_INDEX);
     CHECK(cmo[0] == 0 && cmo[1] == 1 && cmo[2] == 3 && cmo[3] == 6 && cmo[4] == 6);
+    {   /* asynchronous form: the same proofs, byte for byte (the random scalars are inputs) */
+        uint8_t* pf2 = calloc(N, pf_rec);
+        uint8_t cm2[N * L * 32];
+        uint64_t cmo2[N + 1];
+        int8_t st2[N];
+        bbs_job* pj = NULL;
+        memset(st2, 99, sizeof st2);
+        CHECK(bbs_core_proof_gen_submit(vctx, N, sig4, scal4, mo4, di, dio, rnd, ro, hdr4, ho4, ph_bytes, po, pf2, cm2, cmo2, st2, &pj) == BBS_OK && pj);
+        CHECK(bbs_job_wait(pj) == BBS_OK);
+        bbs_job_free(pj);
+        CHECK(memcmp(st, st2, sizeof st) == 0 && memcmp(cmo, cmo2, sizeof cmo) == 0);
+        CHECK(memcmp(pf, pf2, N * pf_rec) == 0 && memcmp(cm, cm2, (size_t)cmo[N] * 32) == 0);
+        free(pf2);
+    }
 
     /* ---- proof_verify: two batches submitted before either is waited for ------------------------------------------ */
     /* batch A: items 0..2 as generated.  batch B: item 0 with a commitment altered (Ok(false)), item 1 with an index

@@ -871,6 +871,52 @@ def check_submit(curve, lib_path=None, n=7, L=4, seed=23):
         job.wait()
         assert [int(x) for x in job.result] == want and 0 in want and -40 in want and -1 in want, want
         job.free()
+    # core_sign / core_proof_gen through their submit forms: two batches of each in flight, records delivered at wait;
+    # a wrong message count (Err), a scalar >= r (malformed), a signature with e >= r; against the oracle and the one-shot call
+    sjobs, pjobs, sin, pin = [], [], [], []
+    for b in range(2):
+        msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+        headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 11, 65]))) for _ in range(n)]
+        phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 4]))) for _ in range(n)]
+        disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+        rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+        good, st = eng.core_sign_batch(msgs, headers)
+        assert list(st) == [1] * n
+        sm = [list(m) for m in msgs]
+        sm[b] = sm[b][:-1]
+        sm[b + 2][L - 1] = c.r + 1
+        sin.append((sm, headers))
+        sjobs.append(eng.core_sign_submit(sm, headers))
+        ps = [Signature(s_.a, s_.e) for s_ in good]
+        ps[b + 1] = Signature(good[b + 1].a, c.r)
+        pin.append((ps, msgs, disclosed, rnds, headers, phs))
+        pjobs.append(eng.core_proof_gen_submit(ps, msgs, disclosed, rnds, headers, phs))
+    for b, job in enumerate(sjobs):
+        sm, headers = sin[b]
+        job.wait()
+        sigs, st = job.output()
+        one, st1 = eng.core_sign_batch(sm, headers)
+        assert list(st) == list(st1) == [int(x) for x in job.result] and list(st).count(1) == n - 2 and st[b] < 0 and st[b + 2] == -40, list(st)
+        for i in range(n):
+            if st[i] != 1:
+                assert sigs[i] is None and one[i] is None
+                continue
+            w = bbs.core_sign(suite, sk, gens, headers[i], sm[i], api_id)
+            assert sigs[i].a == w.a and sigs[i].e == w.e and one[i].a == w.a and one[i].e == w.e, (curve, b, i, "sign submit")
+        job.free()
+    for b, job in enumerate(pjobs):
+        ps, msgs, disclosed, rnds, headers, phs = pin[b]
+        job.wait()
+        proofs, st = job.output()
+        one, st1 = eng.core_proof_gen_batch(ps, msgs, disclosed, rnds, headers, phs)
+        assert list(st) == list(st1) == [int(x) for x in job.result] and list(st).count(1) == n - 1 and st[b + 1] == -40, list(st)
+        for i in range(n):
+            if st[i] != 1:
+                assert proofs[i] is None and one[i] is None
+                continue
+            w = bbs.core_proof_gen(suite, pk, bbs.Signature(ps[i].a, ps[i].e), headers[i], gens, phs[i], msgs[i], disclosed[i], api_id, rnds[i])
+            assert proof_eq(proofs[i], w) and proof_eq(one[i], w), (curve, b, i, "proof_gen submit")
+        job.free()
     jobs = [eng.core_proof_verify_submit(*b) for b in batches]            # all in flight
     for job, b in zip(jobs, batches):
         job.wait()
