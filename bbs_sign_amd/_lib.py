@@ -51,6 +51,8 @@ SIGNATURES = {
     "bbs_core_verify_upload": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
     "bbs_core_verify_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_core_verify_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_verify_octets_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_verify_octets_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_core_sign_upload": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
     "bbs_core_sign_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p]),
     "bbs_core_sign_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p, ctypes.POINTER(vp)]),

@@ -324,7 +324,7 @@ int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                            const uint8_t* h, const uint64_t* ho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, h, ho, job), vf_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, h, ho, job));
+    return DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, h, ho, job, nullptr), vf_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, h, ho, job, nullptr));
 }
 int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
@@ -482,6 +482,31 @@ int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const ui
     job->deliver_to = status;
     *job_out = job;
     return BBS_OK;
+}
+// verify from the wire: signature octet strings (compress(A) || e) decoded and checked on the device in front of
+// core_verify; statuses as bbs_signature_from_octets followed by core_verify would give them
+int bbs_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* m, const uint64_t* mo,
+                             const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
+    if (!ctx || !status || !job_out || (n && !sig_octets)) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets),
+                      vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets));
+    if (rc) return rc;
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* m, const uint64_t* mo,
+                            const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_verify_octets_submit(ctx, n, sig_octets, m, mo, h, ho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
 }
 int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                           const uint8_t* h, const uint64_t* ho, int8_t* status) {

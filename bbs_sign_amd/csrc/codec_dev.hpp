@@ -190,14 +190,7 @@ struct PvOctDecode {
 };
 template <class C>
 struct PvOctIngest {
-    // 32 big-endian bytes (any alignment) -> 8 little-endian words
-    static __host__ __device__ void be32(const uint8_t* b, uint32_t* w) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint8_t* q = b + 28 - 4 * k;
-            w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
-        }
-    }
+    static __host__ __device__ void be32(const uint8_t* b, uint32_t* w) { be32_words(b, w); }
     static __host__ __device__ void run(const PvOctArgs<C>& a, size_t i) {
         using R = typename C::FrP;
         constexpr size_t NB = 4 * C::FpP::NC;
@@ -263,6 +256,27 @@ struct PvOctIngest {
         }
         a.rcount[i] = (uint32_t)r;
         a.status0[i] = ok ? ST_PENDING : (int8_t)-40;
+    }
+};
+
+// ---- verify from the wire: signature OCTET strings compress(A) || e (32 bytes big-endian) --------------------------
+// VfOctDecode (lane per item): decompression, on-curve and subgroup checks of A into the SoA array VfIngest would have
+// filled from a record; VfIngest (stages.hpp) then applies bbs_signature_from_octets' verdicts before core_verify's.
+template <class C>
+struct VfOctArgs {
+    size_t n;
+    const uint8_t* oct;                   // n strings of fp_bytes + 32 octets
+    uint32_t* sig_a;                      // [2 NC][n] canonical words
+    int8_t* pcode;
+};
+template <class C>
+struct VfOctDecode {
+    static __host__ __device__ void run(const VfOctArgs<C>& a, size_t i) {
+        constexpr int NC = C::FpP::NC;
+        constexpr size_t NB = 4 * NC;
+        uint32_t o[2 * NC];
+        a.pcode[i] = g1_decode_octets<C>(a.oct + i * (NB + 32), o);
+        soa_st<2 * NC>(a.sig_a, a.n, i, o);
     }
 };
 

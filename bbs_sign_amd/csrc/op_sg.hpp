@@ -90,7 +90,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     a.status = job->d_status.template as<int8_t>();
     VfIngestArgs<C>& ia = job->ingest;
     ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 0;
-    ia.rec = nullptr;
+    ia.rec = nullptr; ia.oct = nullptr; ia.pcode = nullptr;
     ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
     ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
     ia.sig_a = nullptr; ia.sig_e = nullptr; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;

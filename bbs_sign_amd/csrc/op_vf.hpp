@@ -10,20 +10,24 @@ struct VfJob : JobBase<C> {
     VfArgs<C> a{};
     PairArgs<C> pa{};
     VfIngestArgs<C> ingest{};
+    VfOctArgs<C> oct{};               // wire form only
     BvState<C> bv{};                  // batch verification only
 };
 
 template <class C>
 int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, const uint64_t* msg_off,
-                     const uint8_t* headers, const uint64_t* hdr_off, bbs_job** out) {
+                     const uint8_t* headers, const uint64_t* hdr_off, bbs_job** out, const uint8_t* octets) {
+    // octets != nullptr: the wire form -- n strings compress(A) || e instead of the records `sigs`
     constexpr int N = C::FpP::N;
     constexpr int NC = C::FpP::NC;
     constexpr int FPB = 4 * NC;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
-    if (!out || (n && (!sigs || !msg_off))) return BBS_E_ARG;
+    if (!out || (n && ((!sigs && !octets) || !msg_off))) return BBS_E_ARG;
     if (ctx->use()) return BBS_E_HIP;
     const int L = ctx->L;
-    const size_t rec = 2 * FPB + 32;
+    const bool wire = octets != nullptr;
+    const size_t rec = wire ? (size_t)FPB + 32 : (size_t)2 * FPB + 32;
+    if (wire) sigs = octets;
     auto job = std::unique_ptr<VfJob<C>>(new VfJob<C>(ctx));
     job->n = n;
     // the batch as one staging image, one asynchronous copy; checks, range checks and the SoA transposition on the
@@ -36,7 +40,8 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     VfArgs<C>& a = job->a;
     a.n = n; a.L = L; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
+    // wire form: the decoder has checked that A is in G1, so the GLV split is sound without the caller's word
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup || wire)) ? 1 : 0;
     uint32_t* sig_a = job->template scratch<uint32_t>((size_t)2 * NC * nn, rc);
     uint32_t* sig_e = job->template scratch<uint32_t>((size_t)8 * nn, rc);
     uint32_t* smsgs = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
@@ -53,7 +58,16 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.status = job->d_status.template as<int8_t>();
     VfIngestArgs<C>& ia = job->ingest;
     ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 1;
-    ia.rec = reinterpret_cast<const uint32_t*>(dimg);
+    ia.rec = wire ? nullptr : reinterpret_cast<const uint32_t*>(dimg);
+    ia.oct = nullptr; ia.pcode = nullptr;
+    if (wire) {
+        int8_t* pcode = job->template scratch<int8_t>(nn, rc);
+        if (rc) return rc;
+        VfOctArgs<C>& oa = job->oct;
+        oa.n = n; oa.oct = dimg; oa.sig_a = sig_a; oa.pcode = pcode;
+        if (rt::launch<VfOctDecode<C>>(job->stream(), oa, n)) return BBS_E_HIP;
+        ia.oct = dimg; ia.pcode = pcode;
+    }
     ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
     ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
     ia.sig_a = sig_a; ia.sig_e = sig_e; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;

@@ -689,13 +689,26 @@ struct VfArgs {
     uint32_t* fmiller;
 };
 
+// 32 big-endian bytes (any alignment) -> 8 little-endian words
+BBS_HD void be32_words(const uint8_t* b, uint32_t* w) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint8_t* q = b + 28 - 4 * k;
+        w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+}
+
 // stage 0 of verify (lane per item, once per upload): verify.rs:69-71's length check, range checks of the signature
 // and the messages, transposition of the item-major staging image into the SoA arrays (see PvIngest)
 template <class C>
 struct VfIngestArgs {
     size_t n;
     int L, dst_too_long, has_sig;         // has_sig = 0: core_sign (no signature record, only messages)
-    const uint32_t* rec;                  // n records A || e, little-endian words (has_sig)
+    const uint32_t* rec;                  // n records A || e, little-endian words (has_sig, record form)
+    // wire form (has_sig, oct != nullptr): n octet strings compress(A) || e big-endian; A has been decoded into sig_a by
+    // VfOctDecode (codec_dev.hpp), its verdict is pcode[i]
+    const uint8_t* oct;
+    const int8_t* pcode;
     const uint64_t *m_off, *hdr_off64;    // n + 1 entries each, rebased to 0
     const uint32_t* m;                    // messages, 8 words each
     uint32_t *sig_a, *sig_e, *msgs, *hdr_off, *hdr_len;
@@ -710,11 +723,33 @@ struct VfIngest {
         const size_t n = a.n;
         a.hdr_off[i] = (uint32_t)a.hdr_off64[i];
         a.hdr_len[i] = (uint32_t)(a.hdr_off64[i + 1] - a.hdr_off64[i]);
+        if (a.has_sig && a.oct) {
+            // the verdicts of bbs_signature_from_octets come first, in its order: the point's code, the identity, e >= r,
+            // e = 0; only a decodable signature reaches core_verify's own checks
+            constexpr size_t NB = 4 * NC;
+            uint32_t e[8];
+            be32_words(a.oct + i * (NB + 32) + NB, e);
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) any |= e[k];
+            const int8_t c = a.pcode[i];
+            int8_t pre = ST_PENDING;
+            if (c < 0) pre = c;
+            else if (c == 1) pre = -42;
+            else if (!limbs_lt_mod<R>(e)) pre = -40;
+            else if (!any) pre = -42;
+            if (pre != ST_PENDING) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) e[k] = 0;
+            }
+            soa_st<8>(a.sig_e, n, i, e);
+            if (pre != ST_PENDING) { a.status0[i] = pre; return; }
+        }
         const uint64_t l = a.m_off[i + 1] - a.m_off[i];
         if (l != (uint64_t)a.L) { a.status0[i] = -1; return; }            // InvalidMessageAndGeneratorsLength
         if (a.dst_too_long) { a.status0[i] = -23; return; }
         bool ok = true;
-        if (a.has_sig) {
+        if (a.has_sig && !a.oct) {
             const uint32_t* sg = a.rec + i * (size_t)(2 * NC + 8);
             for (int c = 0; c < 2; c++) {
                 uint32_t w[NC];

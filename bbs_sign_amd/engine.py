@@ -326,6 +326,36 @@ class Engine:
         job.result = st[:n]
         return job
 
+    def _sig_octets(self, octets):
+        n = len(octets)
+        if any(len(o) != self.fpb + 32 for o in octets):
+            raise ValueError("signature octets: fp_bytes + 32 each (check the length before batching; -42 per item)")
+        return _bytes_arr(b"".join(octets)) if n else np.zeros(1, dtype=np.uint8)
+
+    def verify_octets_batch(self, sig_octets, messages, headers=None) -> np.ndarray:
+        """bbs_verify_octets_batch: signature octet strings in (decoded and subgroup-checked on the device), statuses out."""
+        n = len(sig_octets)
+        ob = self._sig_octets(sig_octets)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        self._chk(self.lib.bbs_verify_octets_batch(self.h, n, _u8(ob), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
+                                                   st.ctypes.data_as(_lib.c_i8p)), "bbs_verify_octets_batch")
+        return st[:n]
+
+    def verify_octets_submit(self, sig_octets, messages, headers=None) -> "Job":
+        n = len(sig_octets)
+        ob = self._sig_octets(sig_octets)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_verify_octets_submit(self.h, n, _u8(ob), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
+                                                    st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_verify_octets_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        return job
+
     def core_verify_upload(self, signatures, messages, headers=None) -> "Job":
         n = len(signatures)
         sg = self._sigs(signatures)

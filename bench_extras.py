@@ -140,6 +140,70 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         retire_o()
     bls["proof_verify_from_octets_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
 
+    # ---- the other three operations from HOST buffers through their submit forms, 8 batches in flight, results checked:
+    # verify from signature records and from signature octets (decompression + subgroup check on the device), sign and
+    # proof_gen with the records delivered at wait
+    def host_loop(submit, check, steps=48, depth=8):
+        pend = []
+        def retire():
+            j = pend.pop(0)
+            j.wait()
+            check(j)
+            j.free()
+        for _ in range(depth):
+            pend.append(submit())
+        while pend:
+            retire()
+        t = time.perf_counter()
+        for _ in range(steps):
+            if len(pend) >= depth:
+                retire()
+            pend.append(submit())
+        while pend:
+            retire()
+        return steps * n / (time.perf_counter() - t)
+
+    def all_true(j):
+        assert (j.result == 1).all()
+    sig_octs = [_api.signature_to_octets("bls12_381", s_) for s_ in sigs[:n]]
+    ob_s = eng._sig_octets(sig_octs)
+    ms_v, mo_v = eng._scalars(msgs)
+    hb_v, ho_v = _ragged_bytes([b""] * n)
+    sg_v = eng._sigs(sigs)
+    import ctypes as _ct
+
+    def packed_submit(fn, name, *a):
+        st_ = np.full(n, -128, dtype=np.int8)
+        jh = _ct.c_void_p()
+        eng._chk(fn(eng.h, n, *a, st_.ctypes.data_as(_l.c_i8p), _ct.byref(jh)), name)
+        j = Job(eng, jh, n)
+        j.result = st_
+        return j
+    u8 = lambda x: x.ctypes.data_as(_l.c_u8p)
+    u64 = lambda x: x.ctypes.data_as(_l.c_u64p)
+    bls["verify_from_octets_host_inclusive"] = host_loop(
+        lambda: packed_submit(eng.lib.bbs_verify_octets_submit, "bbs_verify_octets_submit", u8(ob_s), u8(ms_v), u64(mo_v), u8(hb_v), u64(ho_v)), all_true)
+    bls["verify_host_inclusive"] = host_loop(
+        lambda: packed_submit(eng.lib.bbs_core_verify_submit, "bbs_core_verify_submit", u8(sg_v), u8(ms_v), u64(mo_v), u8(hb_v), u64(ho_v)), all_true)
+    sig_out = [np.zeros(n * (2 * eng.fpb + 32), dtype=np.uint8) for _ in range(9)]
+    turn = [0]
+
+    def sign_submit():
+        o = sig_out[turn[0] % 9]; turn[0] += 1
+        return packed_submit(eng.lib.bbs_core_sign_submit, "bbs_core_sign_submit", u8(ms_v), u64(mo_v), u8(hb_v), u64(ho_v), u8(o))
+    bls["sign_host_inclusive"] = host_loop(sign_submit, all_true)
+    assert any(o.any() for o in sig_out)
+    pgn, pgkeep, pgargs = eng._pg_inputs(sigs, msgs, disclosed, rnds, None, None)
+    pf_out = [np.zeros(n * (6 * eng.fpb + 128), dtype=np.uint8) for _ in range(9)]
+    cm_out = [np.zeros(n * L * 32, dtype=np.uint8) for _ in range(9)]
+    cmo_out = [np.zeros(n + 1, dtype=np.uint64) for _ in range(9)]
+
+    def pg_submit():
+        k = turn[0] % 9; turn[0] += 1
+        return packed_submit(eng.lib.bbs_core_proof_gen_submit, "bbs_core_proof_gen_submit", *pgargs, u8(pf_out[k]), u8(cm_out[k]), u64(cmo_out[k]))
+    bls["proof_gen_host_inclusive"] = host_loop(pg_submit, all_true)
+    assert all(int(c_[n]) == n * (L - R) for c_ in cmo_out[:8])
+
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
     sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)
     mb, db, rb = pc.bench_items(sb_, eb, n, L, R, 0)

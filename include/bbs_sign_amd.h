@@ -207,6 +207,17 @@ int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                            const uint8_t* messages, const uint64_t* msg_off,
                            const uint8_t* headers, const uint64_t* hdr_off, int8_t* status, bbs_job** job_out);
 
+/* verify from the wire: n signature octet strings of fp_bytes + 32 octets each, compress(A) || I2OSP(e, 32) (the byte
+ * string of src/tests/test_vector.rs:188-191), decompressed, subgroup- and range-checked on the device in front of
+ * core_verify.  status[i] = what bbs_signature_from_octets gives when it fails (malformed / not on the curve or in the
+ * subgroup / identity / e = 0 or >= r), else what core_verify gives.  _submit as bbs_core_verify_submit. */
+int bbs_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                             const uint8_t* messages, const uint64_t* msg_off,
+                             const uint8_t* headers, const uint64_t* hdr_off, int8_t* status, bbs_job** job_out);
+int bbs_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                            const uint8_t* messages, const uint64_t* msg_off,
+                            const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
+
 /* core_sign (src/sign.rs:63-133); needs bbs_ctx_set_secret_key.
  * signatures_out: n records A || e (status 1 where written). */
 int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,

@@ -1126,3 +1126,95 @@ def check_proof_verify_octets(curve, lib_path=None, n=14, L=5, seed=61, disclose
         assert list(e2.proof_verify_octets_batch([kat], [m1], [[0]], [hdr], [ph])) == [1]      # test_vector.rs:199-260
         assert list(e2.proof_verify_octets_batch([kat], [m1], [[0]], [hdr], [ph + b"x"])) == [0]
         e2.close()
+
+
+def check_verify_octets(curve, lib_path=None, n=16, L=4, seed=71):
+    """bbs_verify_octets_*: signature OCTET strings in (compress(A) || e), statuses out, decoding on the device.  Against
+    (a) the composition it replaces, bbs_signatures_from_octets_batch -> bbs_core_verify_batch, item by item, (b) the
+    oracle on the decodable ones, (c) the reference's signature vector (src/tests/test_vector.rs:163-193)."""
+    from bbs_sign_amd import api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    fpb = c.fp_bytes
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 70]))) for _ in range(n)]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    octs = [bytearray(api.signature_to_octets(curve, s_, lib_path)) for s_ in sigs]
+    vm = [list(m) for m in msgs]
+    vh = list(headers)
+    vm[1][L - 1] = (vm[1][L - 1] + 1) % c.r                 # 1: forged message -> Ok(false)
+    vh[2] = vh[2] + b"x"                                    # 2: forged header -> Ok(false)
+    octs[3][fpb + 31] ^= 1                                  # 3: e altered (still < r) -> Ok(false)
+    if curve == "bls12_381":                                # 4: compression flag missing / infinity flag with a value
+        octs[4][0] &= 0x7F
+    else:
+        octs[4][fpb - 1] |= 0x40
+    x = 7                                                   # 5: x with no square root on the curve
+    while pow((x ** 3 + c.b) % c.p, (c.p - 1) // 2, c.p) == 1:
+        x += 1
+    octs[5][0:fpb] = bbs.g1_compress(c, (x, 0))
+    if curve == "bls12_381":                                # 6: on the curve, order 3: outside the subgroup
+        octs[6][0:fpb] = bbs.g1_compress(c, (0, 2))
+    octs[7][0:fpb] = bbs.g1_compress(c, None)              # 7: A = identity (rejected by octets_to_signature)
+    octs[8][fpb:] = (c.r + 2).to_bytes(32, "big")           # 8: e >= r
+    octs[9][fpb:] = bytes(32)                               # 9: e = 0
+    vm[10] = vm[10][:-1]                                    # 10: wrong message count (Err)
+    vm[11][0] = c.r                                         # 11: message >= r
+    octs[12][fpb:] = (c.r + 2).to_bytes(32, "big")          # 12: undecodable AND a wrong message count: the decoder's verdict
+    vm[12] = vm[12] + [1]
+    if curve == "bls12_381":                                # 13: another point of the curve in the subgroup: Ok(false)
+        octs[13][0:fpb] = bbs.g1_compress(c, c.g1)
+    octs = [bytes(o) for o in octs]
+    got = [int(x_) for x_ in eng.verify_octets_batch(octs, vm, vh)]
+    dec, dst = eng.signatures_from_octets_batch(octs)
+    want = []
+    for i in range(n):
+        if dst[i] != 1:
+            want.append(int(dst[i]))
+        else:
+            want.append(int(eng.core_verify_batch([dec[i]], [vm[i]], [vh[i]])[0]))
+    assert got == want, (curve, got, want)
+    assert got[0] == 1 and got[1] == 0 and got[2] == 0 and got[3] == 0 and got[4] == -40 and got[5] == -41 and got[7] == -42, got
+    assert got[8] == -40 and got[9] == -42 and got[10] == -1 and got[11] == -40 and got[12] == -40 and got[14] == 1 and got[15] == 1, got
+    if curve == "bls12_381":
+        assert got[6] == -41 and got[13] == 0, got
+    for i in (0, 1, 2, 3, 13, 14):
+        if dst[i] == 1:
+            assert int(bbs.core_verify(suite, pk, bbs.Signature(dec[i].a, dec[i].e), gens, vh[i], vm[i], api_id)) == got[i], i
+    # the same under batch verification and with subgroup vouching (the decoder has checked membership either way)
+    eng.set_batch_verification(True)
+    assert [int(x_) for x_ in eng.verify_octets_batch(octs, vm, vh)] == want
+    eng.set_batch_verification(False)
+    eng.set_points_in_subgroup(True)
+    assert [int(x_) for x_ in eng.verify_octets_batch(octs, vm, vh)] == want
+    eng.set_points_in_subgroup(False)
+    # submit form, two batches in flight; the empty batch
+    jobs = [eng.verify_octets_submit(octs, vm, vh) for _ in range(2)]
+    for j in jobs:
+        j.wait()
+        assert [int(x_) for x_ in j.result] == want
+        j.free()
+    assert list(eng.verify_octets_batch([], [], [])) == []
+    eng.close()
+    if curve == "bls12_381":
+        S = bbs.BLS_SUITE
+        H = bytes.fromhex
+        kat = H("84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f27164657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0")
+        ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+        key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+        key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+        sk2 = bbs.key_gen(S, ikm, key_info, key_dst)
+        e2 = make_engine("bls12_381", bbs.create_generators(S, 2, S.api_id), S.api_id, lib_path, sk=sk2)
+        m1 = bbs.msg_to_scalars(S, [H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")], S.api_id)
+        hdr = H("11223344556677889900aabbccddeeff")
+        assert list(e2.verify_octets_batch([kat], [m1], [hdr])) == [1]
+        assert list(e2.verify_octets_batch([kat], [m1], [hdr + b"x"])) == [0]
+        e2.close()
+

@@ -104,3 +104,10 @@ def test_proof_verify_octets(curve):
     pc.check_proof_verify_octets(curve, None)
     pc.check_proof_verify_octets(curve, None, n=150, L=7, seed=62)
     pc.check_proof_verify_octets(curve, None, seed=63, disclose_all_3=True)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_verify_octets(curve):
+    pc.check_verify_octets(curve, None)
+    pc.check_verify_octets(curve, None, n=200, L=6, seed=72)
+

@@ -93,3 +93,9 @@ def test_large_shapes(twin, curve):
 def test_proof_verify_octets(twin, curve):
     pc.check_proof_verify_octets(curve, twin)
     pc.check_proof_verify_octets(curve, twin, seed=63, disclose_all_3=True)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_verify_octets(twin, curve):
+    pc.check_verify_octets(curve, twin)
+

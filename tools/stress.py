@@ -16,6 +16,7 @@ while time.time() - t0 < budget:
         pc.check_submit(curve, None, n=7 + seed % 5, L=3 + seed % 4, seed=seed)
         pc.check_latency_mode(curve, None, n=12, L=4 + seed % 3, seed=seed)
         pc.check_proof_verify_octets(curve, None, n=14, L=5 + seed % 3, seed=seed)
+        pc.check_verify_octets(curve, None, n=16 + seed % 7, L=2 + seed % 5, seed=seed)
         done += 1
     seed += 1
     print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
