@@ -9,39 +9,34 @@ struct PgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     PgArgs<C> a{};
     PgIngestArgs<C> ingest{};
-    std::vector<std::vector<uint32_t>> undisclosed;     // per item, sorted
-    // proof records + the m^ of the undisclosed messages (ascending index) of the items whose status is 1
-    void unpack(const uint32_t* P, const uint32_t* S, const uint32_t* M, const int8_t* st, uint8_t* pf_out, uint8_t* commit_out,
+    // The proofs come off the device in the caller's layout (stage PgEmit): records, the m^ of the undisclosed messages
+    // in ascending index order (L slots per item, the first ucount[i] used) and those counts.  Host side of a delivery:
+    // one copy of the records, one contiguous copy per item of its commitments, the running offsets.
+    size_t rec_bytes() const { return (size_t)(24 * C::FpP::NC + 128); }
+    size_t mh_bytes() const { return (size_t)std::max(a.L, 1) * 32; }              // per item
+    void unpack(const uint8_t* rec, const uint8_t* mh, const uint32_t* ucount, uint8_t* pf_out, uint8_t* commit_out,
                 uint64_t* commit_off) const {
-        constexpr int N = C::FpP::NC;       // canonical words
-        constexpr int FPB = 4 * N;
-        const size_t n = this->n, rec = 6 * FPB + 128;
+        const size_t n = this->n;
+        if (pf_out && n) std::memcpy(pf_out, rec, n * rec_bytes());
         uint64_t off = 0;
         for (size_t i = 0; i < n; i++) {
             if (commit_off) commit_off[i] = off;
-            if (st[i] != 1) { if (pf_out) std::memset(pf_out + i * rec, 0, rec); continue; }
-            if (pf_out) {
-                for (int p = 0; p < 3; p++) unpack_words_le(P, n, (size_t)p * 2 * N, i, 2 * N, pf_out + i * rec + (size_t)p * 2 * FPB);
-                for (int k = 0; k < 4; k++) unpack_words_le(S, n, (size_t)k * 8, i, 8, pf_out + i * rec + 6 * FPB + 32 * k);
-            }
-            for (uint32_t j : undisclosed[i]) {
-                if (commit_out) unpack_words_le(M, n, (size_t)j * 8, i, 8, commit_out + off * 32);
-                off++;
-            }
+            const size_t u = ucount[i];
+            if (commit_out && u) std::memcpy(commit_out + off * 32, mh + i * mh_bytes(), u * 32);
+            off += u;
         }
         if (commit_off) commit_off[n] = off;
     }
-    size_t words_p() const { return (size_t)3 * 2 * C::FpP::NC * this->n; }
-    size_t words_s() const { return (size_t)4 * 8 * this->n; }
-    size_t words_m() const { return (size_t)std::max(a.L, 1) * 8 * this->n; }
+    size_t out_bytes() const { return this->n * (rec_bytes() + mh_bytes() + 4); }
+    // one device block [records | m^ | counts] so that a fetch is one copy
     int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
-        std::vector<uint32_t> P(words_p()), S(words_s()), M(words_m());
-        if (this->down(P, a.out_pts) || this->down(S, a.out_sc) || this->down(M, a.out_mhat)) return BBS_E_HIP;
-        std::vector<int8_t> st(n);
-        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
-        unpack(P.data(), S.data(), M.data(), st.data(), pf_out, commit_out, commit_off);
+        if (!n) { if (commit_off) commit_off[0] = 0; return BBS_OK; }
+        std::vector<uint8_t> h(out_bytes());
+        if (rt::d2h(h.data(), a.out_rec, h.size(), this->stream())) return BBS_E_HIP;
+        unpack(h.data(), h.data() + n * rec_bytes(), reinterpret_cast<const uint32_t*>(h.data() + n * (rec_bytes() + mh_bytes())),
+               pf_out, commit_out, commit_off);
         return BBS_OK;
     }
     // submit form
@@ -52,20 +47,17 @@ struct PgJob : JobBase<C> {
     void set_result_targets(uint8_t* pf, uint8_t* cm, uint64_t* cmo) override { pf_to = pf; cm_to = cm; cmo_to = cmo; }
     int enqueue_result_fetch() override {
         if (!this->n) return BBS_OK;
-        const size_t wp = words_p(), ws = words_s(), wm = words_m();
-        if (!h_out.p && h_out.alloc((wp + ws + wm) * 4)) return BBS_E_NOMEM;
-        uint32_t* h = h_out.template as<uint32_t>();
-        if (rt::d2h_async(h, a.out_pts, wp * 4, this->stream()) || rt::d2h_async(h + wp, a.out_sc, ws * 4, this->stream()) ||
-            rt::d2h_async(h + wp + ws, a.out_mhat, wm * 4, this->stream())) return BBS_E_HIP;
-        return BBS_OK;
+        if (!h_out.p && h_out.alloc(out_bytes())) return BBS_E_NOMEM;
+        return rt::d2h_async(h_out.p, a.out_rec, out_bytes(), this->stream()) ? BBS_E_HIP : BBS_OK;
     }
     int deliver() override {
         if (int rc = JobBase<C>::deliver()) return rc;
         if (!pf_to && !cm_to && !cmo_to) return BBS_OK;
-        if (!this->n) { if (cmo_to) cmo_to[0] = 0; return BBS_OK; }
+        const size_t n = this->n;
+        if (!n) { if (cmo_to) cmo_to[0] = 0; return BBS_OK; }
         if (!h_out.p) return BBS_E_STATE;
-        const uint32_t* h = h_out.template as<uint32_t>();
-        unpack(h, h + words_p(), h + words_p() + words_s(), this->h_status.template as<int8_t>(), pf_to, cm_to, cmo_to);
+        const uint8_t* h = h_out.template as<uint8_t>();
+        unpack(h, h + n * rec_bytes(), reinterpret_cast<const uint32_t*>(h + n * (rec_bytes() + mh_bytes())), pf_to, cm_to, cmo_to);
         return BBS_OK;
     }
 };
@@ -89,12 +81,10 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
              hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
     if (!ms.measure(n) || !di.measure(n) || !rs.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
-    // Host side, index bookkeeping only (no field data is touched): the contract of this ABI on the number of random
-    // scalars (proof_gen.rs:145-149; checked where the reference would have got that far) and, for fetch_proofs, the sorted
-    // undisclosed indexes of every item that passes the reference's checks.  Everything else -- the checks themselves,
-    // range checks, deduplication, unpacking, SoA transposition -- is stage PgIngest on the device.
-    job->undisclosed.resize(n);
-    std::vector<uint8_t> seen;
+    // Host side, one comparison per item (no field data is touched): the contract of this ABI on the number of random
+    // scalars (proof_gen.rs:145-149; checked where the reference would have got that far).  Everything else -- the
+    // reference's checks, range checks, deduplication, unpacking, SoA transposition, and the layout of the results
+    // (stage PgEmit) -- happens on the device.
     for (size_t i = 0; i < n; i++) {
         const size_t l = (size_t)(msg_off[i + 1] - msg_off[i]);
         const size_t r = (size_t)(didx_off[i + 1] - didx_off[i]);
@@ -105,10 +95,6 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
         for (size_t k = 0; k < r; k++) if (idx[k] >= l) bad = true;
         if (bad) continue;                                            // -> InvalidDisclosedIndex
         if (nr != 5 + l - r) return BBS_E_ARG;
-        if (l != (size_t)L) continue;
-        seen.assign(l, 0);
-        for (size_t k = 0; k < r; k++) seen[idx[k]] = 1;
-        for (size_t j = 0; j < l; j++) if (!seen[j]) job->undisclosed[i].push_back((uint32_t)j);
     }
     if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &di, &rs, &hb, &pb})) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
@@ -149,6 +135,13 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     a.out_pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * n, rc);
     a.out_sc = job->template scratch<uint32_t>((size_t)4 * 8 * n, rc);
     a.out_mhat = job->template scratch<uint32_t>((size_t)std::max(L, 1) * 8 * n, rc);
+    {   // [records | m^ | counts] in one block (PgJob::out_bytes)
+        const size_t wrec = (size_t)(6 * NC + 32) * nn, wmh = Lw * 8 * nn;
+        a.out_rec = job->template scratch<uint32_t>(wrec + wmh + nn, rc);
+        if (rc) return rc;
+        a.out_mh = a.out_rec + wrec;
+        a.ucount = a.out_mh + wmh;
+    }
     if (rc) return rc;
     if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
@@ -160,6 +153,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     j->stages.push_back({"pg_b_combine", [j]() { return rt::launch<PgBCombine<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"pg_msm_parts", [j]() { return rt::launch<PgMsmPart<C>>(j->stream(), j->a, j->n * PG_NPARTS); }});
     j->stages.push_back({"pg_finalize", [j]() { return rt::launch<PgFinalize<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"pg_emit", [j]() { return rt::launch<PgEmit<C>>(j->stream(), j->a, j->n); }});
     *out = job.release();
     return BBS_OK;
 }

@@ -9,47 +9,26 @@ struct SgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     SgArgs<C> a{};
     VfIngestArgs<C> ingest{};
-    // signature records (Rust layout: A affine LE, e LE) of the items whose status is 1, zeros for the others
-    void unpack(const uint32_t* A, const uint32_t* E, const int8_t* st, uint8_t* out) const {
-        constexpr int N = C::FpP::NC;       // canonical words
-        const size_t n = this->n, rec = 8 * N + 32;
-        for (size_t i = 0; i < n; i++) {
-            if (st[i] != 1) { std::memset(out + i * rec, 0, rec); continue; }
-            unpack_words_le(A, n, 0, i, 2 * N, out + i * rec);
-            unpack_words_le(E, n, 0, i, 8, out + i * rec + 8 * N);
-        }
-    }
+    // the records come off the device in the caller's layout (stage SgEmit): delivery is one copy
+    size_t rec_bytes() const { return (size_t)(8 * C::FpP::NC + 32); }
     int fetch_signatures(uint8_t* out) override {
-        constexpr int N = C::FpP::NC;
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
-        const size_t n = this->n;
-        std::vector<uint32_t> A((size_t)2 * N * n), E((size_t)8 * n);
-        if (this->down(A, a.out_a) || this->down(E, a.out_e)) return BBS_E_HIP;
-        std::vector<int8_t> st(n);
-        if (rt::d2h(st.data(), this->d_status.p, n, this->stream())) return BBS_E_HIP;
-        unpack(A.data(), E.data(), st.data(), out);
-        return BBS_OK;
+        return rt::d2h(out, a.out_rec, this->n * rec_bytes(), this->stream()) ? BBS_E_HIP : BBS_OK;
     }
     // submit form
     uint8_t* sigs_to = nullptr;
     HostBuf h_out;
     void set_result_targets(uint8_t* sigs, uint8_t*, uint64_t*) override { sigs_to = sigs; }
     int enqueue_result_fetch() override {
-        constexpr int N = C::FpP::NC;
-        const size_t n = this->n, wa = (size_t)2 * N * n, we = (size_t)8 * n;
-        if (!n) return BBS_OK;
-        if (!h_out.p && h_out.alloc((wa + we) * 4)) return BBS_E_NOMEM;
-        uint32_t* h = h_out.template as<uint32_t>();
-        if (rt::d2h_async(h, a.out_a, wa * 4, this->stream()) || rt::d2h_async(h + wa, a.out_e, we * 4, this->stream())) return BBS_E_HIP;
-        return BBS_OK;
+        if (!this->n) return BBS_OK;
+        if (!h_out.p && h_out.alloc(this->n * rec_bytes())) return BBS_E_NOMEM;
+        return rt::d2h_async(h_out.p, a.out_rec, this->n * rec_bytes(), this->stream()) ? BBS_E_HIP : BBS_OK;
     }
     int deliver() override {
-        constexpr int N = C::FpP::NC;
         if (int rc = JobBase<C>::deliver()) return rc;
         if (sigs_to && this->n) {
             if (!h_out.p) return BBS_E_STATE;
-            const uint32_t* h = h_out.template as<uint32_t>();
-            unpack(h, h + (size_t)2 * N * this->n, this->h_status.template as<int8_t>(), sigs_to);
+            std::memcpy(sigs_to, h_out.p, this->n * rec_bytes());
         }
         return BBS_OK;
     }
@@ -85,6 +64,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     a.partials = job->template scratch<uint32_t>((size_t)NFIX * 3 * N * n, rc);
     a.out_a = job->template scratch<uint32_t>((size_t)2 * C::FpP::NC * n, rc);
     a.out_e = job->template scratch<uint32_t>((size_t)8 * n, rc);
+    a.out_rec = job->template scratch<uint32_t>((size_t)(2 * C::FpP::NC + 8) * nn, rc);
     if (rc) return rc;
     if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();
@@ -100,6 +80,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     j->stages.push_back({"sg_scalars", [j]() { return rt::launch<SgScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"sg_msm_parts", [j]() { return rt::launch<SgMsmPart<C>>(j->stream(), j->a, j->n * NFIX); }});
     j->stages.push_back({"sg_combine", [j]() { return rt::launch<SgCombine<C>>(j->stream(), j->a, j->n); }});
+    j->stages.push_back({"sg_emit", [j]() { return rt::launch<SgEmit<C>>(j->stream(), j->a, j->n); }});
     *out = job.release();
     return BBS_OK;
 }

@@ -846,6 +846,7 @@ struct SgArgs {
     uint32_t* partials;       // [NFIX][3N][n]
     uint32_t* out_a;          // [2NC][n] canonical
     uint32_t* out_e;          // [8][n] canonical
+    uint32_t* out_rec;        // [n][2NC + 8]: the records A || e as the caller receives them (SgEmit)
 };
 
 template <class C>
@@ -913,6 +914,20 @@ struct SgCombine {
     }
 };
 
+// last stage of sign (lane per item): the signature record in the caller's layout (A affine || e, little-endian words,
+// zeros unless the status is 1), so that delivery is one contiguous copy
+template <class C>
+struct SgEmit {
+    static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
+        constexpr int NC = C::FpP::NC, W = 2 * NC + 8;
+        const size_t n = a.n;
+        uint32_t* r = a.out_rec + i * (size_t)W;
+        const bool ok = a.status[i] == 1;
+        for (int k = 0; k < 2 * NC; k++) r[k] = ok ? a.out_a[(size_t)k * n + i] : 0u;
+        for (int k = 0; k < 8; k++) r[2 * NC + k] = ok ? a.out_e[(size_t)k * n + i] : 0u;
+    }
+};
+
 // =============================================================================================
 // proof_gen
 // =============================================================================================
@@ -948,6 +963,11 @@ struct PgArgs {
     uint32_t* out_pts;        // [3][2NC][n] a_bar, b_bar, d (canonical)
     uint32_t* out_sc;         // [4][8][n]   e^, r1^, r3^, c
     uint32_t* out_mhat;       // [L][8][n]   m^_j at undisclosed slots
+    // what the caller receives (PgEmit): records [n][6NC + 32] (Abar, Bbar, D, e^, r1^, r3^, c), the m^ of the undisclosed
+    // messages in ascending index order [n][L][8], and their number per item
+    uint32_t* out_rec;
+    uint32_t* out_mh;
+    uint32_t* ucount;
 };
 
 // stage 0 of proof_gen (lane per item, once per upload): the checks of proof_gen.rs:133-143 and :229-239 in the
@@ -1198,6 +1218,30 @@ struct PgFinalize {
         }
         for (int p = 0; p < 3; p++) g1a_store_canon<C>(a.out_pts + (size_t)p * 2 * C::FpP::NC * n, n, i, pa[p]);
         a.status[i] = 1;
+    }
+};
+
+// last stage of proof_gen (lane per item): the proof in the caller's layout, zeros / no commitments unless the status is 1
+template <class C>
+struct PgEmit {
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
+        constexpr int NC = C::FpP::NC, W = 6 * NC + 32;
+        const size_t n = a.n;
+        uint32_t* r = a.out_rec + i * (size_t)W;
+        const bool ok = a.status[i] == 1;
+        for (int k = 0; k < 6 * NC; k++) r[k] = ok ? a.out_pts[(size_t)k * n + i] : 0u;
+        for (int k = 0; k < 32; k++) r[6 * NC + k] = ok ? a.out_sc[(size_t)k * n + i] : 0u;
+        uint32_t u = 0;
+        if (ok) {
+            uint32_t* m = a.out_mh + i * (size_t)(a.L > 1 ? a.L : 1) * 8;
+            for (int j = 0; j < a.L; j++) {
+                const uint32_t dm = a.dmask[(size_t)(j >> 5) * n + i];
+                if ((dm >> (j & 31)) & 1u) continue;
+                for (int k = 0; k < 8; k++) m[(size_t)u * 8 + k] = a.out_mhat[((size_t)j * 8 + k) * n + i];
+                u++;
+            }
+        }
+        a.ucount[i] = u;
     }
 };
 

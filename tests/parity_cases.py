@@ -329,6 +329,16 @@ def check_empty_batches(curve, lib_path=None):
         job.run(); job.wait()
         assert len(job.status()) == 0
         job.free()
+        for job in (eng.core_proof_verify_submit([], [], []), eng.core_verify_submit([], []), eng.verify_octets_submit([], []),
+                    eng.core_sign_submit([]), eng.core_proof_gen_submit([], [], [], [])):
+            job.wait()
+            assert len(job.result) == 0
+            if job._decode is not None:
+                out, st = job.output()
+                assert out == [] and len(st) == 0
+            job.free()
+        assert len(eng.verify_octets_batch([], [])) == 0
+        assert len(eng.proof_verify_octets_batch([], [], [])) == 0
     assert eng.hash_to_scalar_batch([], b"dst") == []
     out, st = eng.g1_msm_batch([], [], [])
     assert out == [] and len(st) == 0
