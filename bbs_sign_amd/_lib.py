@@ -24,6 +24,7 @@ SIGNATURES = {
     "bbs_fp_bytes": (sz, [ci]),
     "bbs_version": (ctypes.c_char_p, []),
     "bbs_source_hash": (ctypes.c_char_p, []),
+    "bbs_runtime_hw_queues": (ci, []),
     "bbs_device_count": (ci, []),
     "bbs_ctx_create": (ci, [ci, ci, ctypes.POINTER(vp)]),
     "bbs_ctx_destroy": (None, [vp]),

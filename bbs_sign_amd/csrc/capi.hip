@@ -8,6 +8,12 @@
 // its queue (measured on MI355X: 645k -> 780k proof_verify/s; 14: DESIGN.md 5 rule 6).  Takes effect only if this library
 // is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
 __attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "14", 0); }
+// what the process environment says now (0 = unset): a service can log it at start-up and, when it reads 4 or was set
+// after the first HIP call, prefer larger batches (two 16384-item batches in flight fill the chip: DESIGN.md 6a)
+extern "C" __attribute__((visibility("default"))) int bbs_runtime_hw_queues(void) {
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    return v ? atoi(v) : 0;
+}
 
 // =============================================================================================
 // C ABI

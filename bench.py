@@ -250,7 +250,7 @@ def main():
             "config": {"workload": "BLS12-381 core_proof_verify, batch %d per GPU, 32 msgs / 8 disclosed, empty "
                                    "header/ph, one issuer key (BASELINE configs[3], proof_verify leg)" % n,
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
-                       "batches_in_flight": n_slots,
+                       "batches_in_flight": n_slots, "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),
                        "timed_region": "host buffers -> page-locked staging -> one async H2D -> device-side validation/"
                                        "unpack -> kernels -> async D2H of statuses; one submitting thread per GPU "
                                        "(SURVEY 8d)",

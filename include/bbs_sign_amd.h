@@ -84,6 +84,10 @@ const char* bbs_version(void);
 /* Hash of the sources (every file under bbs_sign_amd/csrc and this header) the library was built from; bbs_sign_amd/build.py rebuilds
  * when it differs from the tree's (a prebuilt library travels with the tree: staleness is judged by content). */
 const char* bbs_source_hash(void);
+/* GPU_MAX_HW_QUEUES as the process environment has it (0 = unset).  The library sets 14 when it is loaded unless the
+ * variable is already set; the HIP runtime reads it at its own initialisation, so the setting only takes effect if
+ * this library was loaded before the process's first HIP call ("Build / deployment"). */
+int bbs_runtime_hw_queues(void);
 int bbs_device_count(void);
 
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);

@@ -1228,3 +1228,66 @@ def check_verify_octets(curve, lib_path=None, n=16, L=4, seed=71):
         assert list(e2.verify_octets_batch([kat], [m1], [hdr + b"x"])) == [0]
         e2.close()
 
+
+def check_threads(lib_path=None, threads=4, rounds=3, n=9, L=3, seed=81):
+    """Several host threads on ONE configured context per curve at the same time (every call builds its own
+    job; pools and the context's counters are locked): each thread signs, generates proofs, verifies -- submit forms and
+    one-shot calls mixed -- on its own data, with a tampered item per batch; results against the oracle."""
+    import threading
+    engines, ctxs = {}, {}
+    for curve in ("bls12_381", "bn254"):
+        suite = bbs.SUITES[curve]
+        rng = random.Random(seed)
+        sk = rng.randrange(1, suite.curve.r)
+        gens = gens_for(suite, L + 1)
+        engines[curve] = make_engine(curve, gens, suite.api_id, lib_path, sk=sk)
+        ctxs[curve] = (suite, sk, bbs.sk_to_pk(suite, sk), gens)
+    errors = []
+
+    def worker(t):
+        try:
+            rng = random.Random(seed * 100 + t)
+            for rd in range(rounds):
+                curve = ("bls12_381", "bn254")[(t + rd) % 2]
+                eng = engines[curve]
+                suite, sk, pk, gens = ctxs[curve]
+                c = suite.curve
+                msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+                headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 6]))) for _ in range(n)]
+                disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+                rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+                sj = eng.core_sign_submit(msgs, headers)
+                sj.wait()
+                sigs, st = sj.output()
+                sj.free()
+                assert list(st) == [1] * n
+                w = bbs.core_sign(suite, sk, gens, headers[t % n], msgs[t % n], suite.api_id)
+                assert sigs[t % n].a == w.a and sigs[t % n].e == w.e
+                vm = [list(m) for m in msgs]
+                vm[rd][0] = (vm[rd][0] + 1) % c.r
+                vj = eng.core_verify_submit(sigs, vm, headers)
+                proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers)
+                assert list(st) == [1] * n
+                wp = bbs.core_proof_gen(suite, pk, bbs.Signature(sigs[0].a, sigs[0].e), headers[0], gens, b"", msgs[0], disclosed[0],
+                                        suite.api_id, rnds[0])
+                assert proof_eq(proofs[0], wp)
+                dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+                proofs[rd + 1].e_cap = (proofs[rd + 1].e_cap + 1) % c.r
+                pj = eng.core_proof_verify_submit(proofs, dm, disclosed, headers)
+                vj.wait(); pj.wait()
+                assert [int(x) for x in vj.result] == [0 if i == rd else 1 for i in range(n)]
+                assert [int(x) for x in pj.result] == [0 if i == rd + 1 else 1 for i in range(n)]
+                vj.free(); pj.free()
+        except BaseException as e:                      # noqa: BLE001 -- reported by the main thread
+            import traceback
+            errors.append((t, traceback.format_exc()))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in engines.values():
+        e.close()
+    assert not errors, errors[0][1]
+

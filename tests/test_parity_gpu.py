@@ -111,3 +111,7 @@ def test_verify_octets(curve):
     pc.check_verify_octets(curve, None)
     pc.check_verify_octets(curve, None, n=200, L=6, seed=72)
 
+
+def test_threads():
+    pc.check_threads(None, threads=6, rounds=4, n=64, L=5)
+

@@ -99,3 +99,7 @@ def test_proof_verify_octets(twin, curve):
 def test_verify_octets(twin, curve):
     pc.check_verify_octets(curve, twin)
 
+
+def test_threads(twin):
+    pc.check_threads(twin)
+

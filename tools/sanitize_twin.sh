@@ -1,11 +1,11 @@
 #!/bin/bash
 # TEST-ONLY: AddressSanitizer + UBSan build of the host twin (CPU; GPU sanitizers are not available on this pool) and a
 # run of the parity cases through it.  ~20 min of compile time on 8 cores.  usage: tools/sanitize_twin.sh [outdir]
-set -e
+set -e -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$ROOT/bbs_sign_amd/build/san}; mkdir -p $OUT
 pids=()
-for tu in $ROOT/bbs_sign_amd/csrc/*.hip; do
+[ -n "$SKIP_BUILD" ] && [ -f $OUT/libbbs_hosttwin_san_TESTONLY.so ] || for tu in $ROOT/bbs_sign_amd/csrc/*.hip; do
   hipcc -O1 -g --offload-host-only -x hip -DBBS_HOST_TWIN -DBBS_CHECK_BOUNDS -fPIC -fsanitize=address,undefined \
         -fno-omit-frame-pointer -fno-sanitize=vptr -c $tu -o $OUT/$(basename $tu .hip).o &
   pids+=($!)
@@ -27,7 +27,21 @@ for curve in ("bls12_381", "bn254"):
     pc.check_points_in_subgroup(curve, lib)
     pc.check_pippenger(curve, lib, n=24)
     pc.check_empty_batches(curve, lib)
+    pc.check_fail_closed(curve, lib)
+    pc.check_submit(curve, lib)
+    pc.check_latency_mode(curve, lib)
+    pc.check_window_widths(curve, lib, widths=(5, 13))
+    pc.check_large_shapes(curve, lib, L=40, n=2)
+    pc.check_proof_verify_octets(curve, lib)
+    pc.check_proof_verify_octets(curve, lib, seed=63, disclose_all_3=True)
+    pc.check_verify_octets(curve, lib)
     print(curve, "ok", flush=True)
+pc.check_threads(lib, threads=3, rounds=2, n=5)
 print("sanitizer run ok")
 PY
-ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT python3 $OUT/run_san.py 2>&1 | tee $OUT/run.log | grep -E "runtime error|AddressSanitizer|ok" | sort | uniq -c
+# SKIP_BUILD=1 tools/sanitize_twin.sh re-runs the cases against an existing instrumented library
+set +e
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT python3 $OUT/run_san.py > $OUT/run.log 2>&1
+rc=$?
+grep -E "runtime error|AddressSanitizer|ok" $OUT/run.log | sort | uniq -c
+if [ $rc -ne 0 ] || ! grep -q "sanitizer run ok" $OUT/run.log; then echo "SANITIZER RUN FAILED (rc=$rc)"; tail -20 $OUT/run.log; exit 1; fi
