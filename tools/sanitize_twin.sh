@@ -45,3 +45,5 @@ ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 LD_
 rc=$?
 grep -E "runtime error|AddressSanitizer|ok" $OUT/run.log | sort | uniq -c
 if [ $rc -ne 0 ] || ! grep -q "sanitizer run ok" $OUT/run.log; then echo "SANITIZER RUN FAILED (rc=$rc)"; tail -20 $OUT/run.log; exit 1; fi
+# the instrumented objects are ~400 MB and would ride along with every gpurun snapshot: remove them unless asked to keep
+[ -n "$KEEP_SAN" ] || rm -f $OUT/*.o $OUT/libbbs_hosttwin_san_TESTONLY.so
