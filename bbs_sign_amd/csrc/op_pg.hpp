@@ -33,6 +33,7 @@ struct PgJob : JobBase<C> {
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
         if (!n) { if (commit_off) commit_off[0] = 0; return BBS_OK; }
+        if (int rc = this->require_decided()) return rc;        // a job that never ran holds no records (fail closed)
         std::vector<uint8_t> h(out_bytes());
         if (rt::d2h(h.data(), a.out_rec, h.size(), this->stream())) return BBS_E_HIP;
         unpack(h.data(), h.data() + n * rec_bytes(), reinterpret_cast<const uint32_t*>(h.data() + n * (rec_bytes() + mh_bytes())),

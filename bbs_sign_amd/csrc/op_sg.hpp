@@ -13,6 +13,7 @@ struct SgJob : JobBase<C> {
     size_t rec_bytes() const { return (size_t)(8 * C::FpP::NC + 32); }
     int fetch_signatures(uint8_t* out) override {
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
+        if (int rc = this->require_decided()) return rc;        // a job that never ran holds no records (fail closed)
         return rt::d2h(out, a.out_rec, this->n * rec_bytes(), this->stream()) ? BBS_E_HIP : BBS_OK;
     }
     // submit form

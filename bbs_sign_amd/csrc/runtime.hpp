@@ -655,6 +655,14 @@ struct JobBase : bbs_job {
         if (rt::d2h(out, d_status.p, n, stream())) return BBS_E_HIP;
         return statuses_final(out, n) ? BBS_OK : BBS_E_STATE;
     }
+    // the stream has been synchronised: BBS_E_STATE unless every item of the last run has been decided.  The record
+    // buffers of sign / proof_gen are written by the last stage of a run; before that they hold whatever the pooled
+    // allocation held, which must never reach a caller.
+    int require_decided() {
+        std::vector<int8_t> st(n);
+        if (n && rt::d2h(st.data(), d_status.p, n, stream())) return BBS_E_HIP;
+        return statuses_final(st.data(), n) ? BBS_OK : BBS_E_STATE;
+    }
     int enqueue_status_fetch() override {
         if (!h_status.p && h_status.alloc(n ? n : 1)) return BBS_E_NOMEM;
         return rt::d2h_async(h_status.p, d_status.p, n, stream()) ? BBS_E_HIP : BBS_OK;

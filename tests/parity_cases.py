@@ -13,7 +13,10 @@ import json
 import os
 import random
 
+import numpy as np
+
 from bbs_sign_amd import BbsError, Engine, Proof, Signature
+from bbs_sign_amd import _lib
 from oracle import bbs
 from oracle.hashing import expand_message, i2osp
 
@@ -826,8 +829,25 @@ def check_fail_closed(curve, lib_path=None):
             assert e.rc == -102, e.rc
         else:
             raise AssertionError("a job that never ran returned statuses %r" % list(st))
+    # ... and no records either: the output buffers of sign / proof_gen are only written by a run
+    for job, fetch in ((jobs[2], "bbs_job_fetch_signatures"), (jobs[3], "bbs_job_fetch_proofs")):
+        out = np.zeros(3 * (6 * eng.fpb + 128), dtype=np.uint8)
+        cm = np.zeros(3 * L * 32, dtype=np.uint8)
+        cmo = np.zeros(4, dtype=np.uint64)
+        u8 = lambda x: x.ctypes.data_as(_lib.c_u8p)
+        if fetch == "bbs_job_fetch_signatures":
+            rc = eng.lib.bbs_job_fetch_signatures(job.h, u8(out))
+        else:
+            rc = eng.lib.bbs_job_fetch_proofs(job.h, u8(out), u8(cm), cmo.ctypes.data_as(_lib.c_u64p))
+        assert rc == -102 and not out.any() and not cm.any(), (fetch, rc)
+    for job in jobs:
         job.run(); job.wait()
         assert list(job.status()) == [1, 1, 1]
+    got_s, st = jobs[2].signatures()
+    assert [(s_.a, s_.e) for s_ in got_s] == [(s_.a, s_.e) for s_ in sigs]
+    got_p, st = jobs[3].proofs()
+    assert all(proof_eq(p_, q_) for p_, q_ in zip(got_p, proofs))
+    for job in jobs:
         job.free()
     eng.close()
 
