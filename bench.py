@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def load_counters():
-    """Per-kernel counters of one 4096-item launch, measured by rocprofv3 (--pmc passes, tools/run_pmc.sh) and kept
+    """Per-kernel counters of one 4096-item launch, measured by rocprofv3 (--pmc passes, tools/run_profile.sh) and kept
     under profiles/: SQ_INSTS_VALU, FETCH_SIZE (KiB, doubled for gfx950 per MI355X_MICROARCH.md), WRITE_SIZE (KiB),
     and the issue-cost model of tools/valu_model.py (cycles per wave-instruction from the ISA histogram x the
     micro-benchmarked cost of every opcode).  bench.py only reads the newest committed file."""
