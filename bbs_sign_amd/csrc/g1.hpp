@@ -109,7 +109,9 @@ BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
 }
 
 // add-2007-bl: Jacobian + Jacobian, 11M + 5S, with the exceptional cases resolved
-template <class C>
+// TAG: a separate instance for callers that live in register-capped kernels (the register budget of a device function is
+// the loosest one among the kernels that reach it, and the kernel is charged the maximum over everything it can reach)
+template <class C, int TAG = 0>
 BBS_HD_NOINLINE G1Jac<C> g1j_add(const G1Jac<C>& p, const G1Jac<C>& q) {
     if (g1j_is_inf<C>(q)) return p;
     if (g1j_is_inf<C>(p)) return q;
@@ -707,7 +709,7 @@ BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<
     // which falls back to the generic chain on its own; their tables reuse the caller's buffer
     constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
     const AtHbm<C> w0{tabs, stride}, w1{tabs + TW * stride, stride}, w2{tabs + 2 * TW * stride, stride};
-    return g1j_add<C>(g1j_add<C>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1)),
+    return g1j_add<C, 1>(g1j_add<C, 1>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1)),
                       g1_mul_aff_tab<C, AtHbm<C>>(p2, k2, w2));
 }
 
