@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_cases as pc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 t0 = time.time()
-seed = 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 done = 0
 while time.time() - t0 < budget:
     for curve in ("bls12_381", "bn254"):
