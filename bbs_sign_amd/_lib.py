@@ -32,6 +32,7 @@ SIGNATURES = {
     "bbs_ctx_set_batch_verification": (ci, [vp, ci, c_u8p]),
     "bbs_ctx_set_points_in_subgroup": (ci, [vp, ci]),
     "bbs_ctx_set_latency_mode": (ci, [vp, ci]),
+    "bbs_ctx_set_fixed_base_tree": (ci, [vp, ci]),
     "bbs_selftest_glv_split": (ci, [ci, c_u8p, c_u8p, c_u8p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bbs_selftest_lin_pm": (ci, [ci, ci, c_u8p, c_u8p, c_u8p]),
     "bbs_selftest_mul3": (ci, [ci, ci, c_u8p, c_u8p, c_u8p]),

@@ -266,6 +266,11 @@ int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled) {
     if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->latency_mode = enabled != 0; else AS_BN(ctx)->latency_mode = enabled != 0;
     return BBS_OK;
 }
+int bbs_ctx_set_fixed_base_tree(bbs_ctx* ctx, int enabled) {
+    if (!ctx) return BBS_E_ARG;
+    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->fix_tree = enabled != 0; else AS_BN(ctx)->fix_tree = enabled != 0;
+    return BBS_OK;
+}
 int bbs_selftest_glv_split(int curve, const uint8_t* k32, uint8_t* k1_16, uint8_t* k2_16, int* neg1, int* neg2) {
     if ((curve != BBS_CURVE_BLS12_381 && curve != BBS_CURVE_BN254) || !k32 || !k1_16 || !k2_16 || !neg1 || !neg2) return BBS_E_ARG;
     uint32_t k[8], k1[4], k2[4];

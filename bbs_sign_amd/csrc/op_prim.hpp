@@ -97,6 +97,14 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
     a.fscal = dF.as<uint32_t>(); a.vpts = dVP.as<uint32_t>(); a.vscal = dVS.as<uint32_t>();
     a.status = dSt.as<int8_t>(); a.partials = dPart.as<uint32_t>(); a.out = dOut.as<uint32_t>();
+    a.fixwk = FixTreeWork<C>{nullptr, nullptr, nullptr};
+    DevBuf dW0, dW1, dW2;
+    if (ctx->fix_tree && n) {
+        const size_t T = nf * (size_t)ctx->hc.n_windows;
+        if (dW0.alloc(std::max<size_t>(T, 1) * 2 * N * n * 4) || dW1.alloc(std::max<size_t>((T + 1) / 2, 1) * 2 * N * n * 4) ||
+            dW2.alloc(std::max<size_t>(T / 2, 1) * N * n * 4)) return BBS_E_NOMEM;
+        a.fixwk = FixTreeWork<C>{dW0.as<uint32_t>(), dW1.as<uint32_t>(), dW2.as<uint32_t>()};
+    }
     if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
     std::vector<uint32_t> w((size_t)2 * NC * n);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;

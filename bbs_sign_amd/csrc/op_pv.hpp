@@ -71,6 +71,13 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     a.aff = job->template scratch<uint32_t>((size_t)5 * 2 * N * n, rc);
     a.fmiller = job->template scratch<uint32_t>((size_t)2 * 12 * N * n, rc);
     a.vtab = job->template scratch<uint32_t>((size_t)4 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);   // T1's three tables + the one of D * r3^
+    a.fixwk = FixTreeWork<C>{nullptr, nullptr, nullptr};
+    if (ctx->fix_tree) {
+        const size_t T = (size_t)(L + 2) * (size_t)ctx->hc.n_windows, nn1 = std::max<size_t>(n, 1);
+        a.fixwk.pts0 = job->template scratch<uint32_t>(T * 2 * N * nn1, rc);
+        a.fixwk.pts1 = job->template scratch<uint32_t>(((T + 1) / 2) * 2 * N * nn1, rc);
+        a.fixwk.pre = job->template scratch<uint32_t>(std::max<size_t>(T / 2, 1) * N * nn1, rc);
+    }
     if (rc) return rc;
     if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();

@@ -400,6 +400,7 @@ struct Ctx : bbs_ctx {
     bool points_in_subgroup = false;
     // proof_verify: the three terms of T1 on three lanes instead of one joint chain (shorter critical lane, more work)
     bool latency_mode = false;
+    bool fix_tree = false;           // bbs_ctx_set_fixed_base_tree: the fixed-base sums as trees of affine additions
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
     std::mutex mu;                   // uploads may come from several host threads: counter and constant sync

@@ -238,6 +238,134 @@ BBS_HD G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, s
     return r;
 }
 
+// ---- the fixed-base sum as a tree of AFFINE additions (bbs_ctx_set_fixed_base_tree) -------------------------------------
+// All T = n_terms * W table entries of an item are summed by ONE lane, pairwise, level by level.  The slopes of a level
+// share one inversion (Montgomery's trick: prefix products on the way up, one fe_inv, back-substitution on the way
+// down): 5M + 1S per addition instead of the 7M + 4S of a mixed Jacobian addition, ceil(log2 T) inversions per item.
+// The points of a level live in HBM work arrays of the job ([slot][2N words][n items]: coalesced over the items of a
+// wavefront); (0, 0) is the identity.  Every exceptional case of affine addition is resolved per pair: an identity
+// operand (digit 0), equal points (doubling, slope 3x^2 / 2y -- caller-supplied generators may repeat), opposite points
+// (identity).  The result is the same group element as the sum of the NFIX chunks of fixed_msm_chunk.
+template <class C>
+struct FixTreeWork {
+    uint32_t* pts0;     // [T][2N][n]
+    uint32_t* pts1;     // [ceil(T/2)][2N][n]
+    uint32_t* pre;      // [floor(T/2)][N][n]   prefix products of a level
+};
+
+template <class C>
+__host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i, int n_terms,
+                                                  const FixTreeWork<C>& wk, G1Jac<C>& out) {
+    using P = typename C::FpP;
+    constexpr int N = P::N;
+    const int W = cc.n_windows, c = cc.win_bits;
+    const int T = n_terms * W;
+    const size_t per_win = ((size_t)1 << c) - 1;
+    auto ld = [&](const uint32_t* a, int slot) {
+        G1Aff<C> q;
+        const uint32_t* b = a + (size_t)slot * 2 * N * n + i;
+#pragma unroll
+        for (int j = 0; j < N; j++) { q.x.v[j] = b[(size_t)j * n]; q.y.v[j] = b[(size_t)(N + j) * n]; }
+        return q;
+    };
+    auto st = [&](uint32_t* a, int slot, const G1Aff<C>& q) {
+        uint32_t* b = a + (size_t)slot * 2 * N * n + i;
+#pragma unroll
+        for (int j = 0; j < N; j++) { b[(size_t)j * n] = q.x.v[j]; b[(size_t)(N + j) * n] = q.y.v[j]; }
+    };
+    // level 0: the table entries themselves (digit 0 -> identity)
+    {
+        int k_cur = -1;
+        uint32_t sc[8];
+        for (int t = 0; t < T; t++) {
+            const int k = t / W, w = t - k * W;
+            if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); k_cur = k; }
+            const int bit = w * c;
+            const int li = bit >> 5, sh = bit & 31;
+            uint64_t two = sc[li];
+            if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
+            uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
+            if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
+            G1Aff<C> q = g1a_inf<C>();
+            if (d) {
+                const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
+#pragma unroll
+                for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
+            }
+            st(wk.pts0, t, q);
+        }
+    }
+    // what a pair needs: the denominator of its slope (1 when the result needs none), and how to finish it
+    struct Pair { Fp<C> den, dy; bool trivial, dbl, pinf, qinf; };
+    auto classify = [&](const G1Aff<C>& p, const G1Aff<C>& q) {
+        Pair r;
+        r.pinf = g1a_is_inf<C>(p); r.qinf = g1a_is_inf<C>(q);
+        const Fp<C> dx = fe_sub<P>(q.x, p.x);
+        r.dy = fe_sub<P>(q.y, p.y);
+        const bool same_x = fe_is_zero<P>(dx), same_y = fe_is_zero<P>(r.dy);
+        r.trivial = r.pinf | r.qinf | (same_x & !same_y);            // the other operand, or P + (-P) = identity
+        r.dbl = !r.pinf & !r.qinf & same_x & same_y;                 // P + P (y != 0: no point of order two on these curves)
+        r.den = fe_select<P>(r.trivial, fe_one<P>(), fe_select<P>(r.dbl, fe_dbl<P>(p.y), dx));
+        return r;
+    };
+    uint32_t* src = wk.pts0;
+    uint32_t* dst = wk.pts1;
+    int m = T;
+    while (m > 1) {
+        const int h = m >> 1;
+        // up: prefix products of the denominators (pre[j] = product of den_0 .. den_{j-1})
+        Fp<C> acc = fe_one<P>();
+        {
+            G1Aff<C> pn = ld(src, 0), qn = ld(src, 1);
+            for (int j = 0; j < h; j++) {
+                const G1Aff<C> p = pn, q = qn;
+                if (j + 1 < h) { pn = ld(src, 2 * j + 2); qn = ld(src, 2 * j + 3); }     // requested one pair ahead
+                const Pair pr = classify(p, q);
+                uint32_t* b = wk.pre + (size_t)j * N * n + i;
+#pragma unroll
+                for (int l = 0; l < N; l++) b[(size_t)l * n] = acc.v[l];
+                acc = fe_mul_i<P>(acc, pr.den);
+            }
+        }
+        Fp<C> inv = fe_inv<P>(acc);                                   // never zero: every den is non-zero by construction
+        // down: slope of pair j = num_j * inv(den_j), inv(den_j) = pre[j] * inv(den_0 .. den_j)
+        {
+            G1Aff<C> pn = ld(src, 2 * h - 2), qn = ld(src, 2 * h - 1);
+            Fp<C> pren;
+            { const uint32_t* b = wk.pre + (size_t)(h - 1) * N * n + i;
+#pragma unroll
+              for (int l = 0; l < N; l++) pren.v[l] = b[(size_t)l * n]; }
+            for (int j = h - 1; j >= 0; j--) {
+                const G1Aff<C> p = pn, q = qn;
+                const Fp<C> pre_j = pren;
+                if (j > 0) {
+                    pn = ld(src, 2 * j - 2); qn = ld(src, 2 * j - 1);
+                    const uint32_t* b = wk.pre + (size_t)(j - 1) * N * n + i;
+#pragma unroll
+                    for (int l = 0; l < N; l++) pren.v[l] = b[(size_t)l * n];
+                }
+                const Pair pr = classify(p, q);
+                const Fp<C> inv_j = fe_mul_i<P>(inv, pre_j);
+                inv = fe_mul_i<P>(inv, pr.den);
+                Fp<C> num = pr.dy;
+                if (pr.dbl) num = fe_scale<P, 3>(fe_sqr_i<P>(p.x));
+                const Fp<C> lam = fe_mul_i<P>(num, inv_j);
+                G1Aff<C> r;
+                r.x = fe_lin<P, 1, -1, -1>(fe_sqr_i<P>(lam), p.x, q.x);
+                r.y = fe_sub<P>(fe_mul_i<P>(lam, fe_sub<P>(p.x, r.x)), p.y);
+                const G1Aff<C> other = pr.pinf ? q : (pr.qinf ? p : g1a_inf<C>());
+                r.x = fe_select<P>(pr.trivial, other.x, r.x);
+                r.y = fe_select<P>(pr.trivial, other.y, r.y);
+                st(dst, j, r);
+            }
+        }
+        if (m & 1) st(dst, h, ld(src, m - 1));
+        m = h + (m & 1);
+        uint32_t* t = src; src = dst; dst = t;
+    }
+    out = T > 0 ? g1j_from_aff<C>(ld(src, 0)) : g1j_inf<C>();
+}
+
 // shared inversion for two Jacobian points -> affine (Montgomery trick), identities preserved
 template <class C>
 __host__ __device__ inline void g1j_to_aff2(const G1Jac<C>& a, const G1Jac<C>& b, G1Aff<C>& oa, G1Aff<C>& ob) {
@@ -283,6 +411,7 @@ struct PvArgs {
     uint32_t* aff;            // [5][2N][n] Montgomery affine: a_bar, b_bar, d, T1, T2
     uint32_t* fmiller;        // [2][12N][n]
     uint32_t* vtab;           // [4][G1_TAB][2N][n] window tables: three of the joint multiplication, one of D * r3^ (g1.hpp)
+    FixTreeWork<C> fixwk;     // pts0 != nullptr: the fixed-base sum as one tree of affine additions per item (chunk 0's lane)
 };
 
 // stage 0 (lane per item, once per upload): the work the reference does before any arithmetic, on the raw batch as the
@@ -449,6 +578,10 @@ struct PvMsmPart {
             soa_ld<8>(a.sc + (size_t)sc * 8 * n, n, i, k);
             const int slot = last ? 3 : part;                                   // vtab slot 3 is D * r3^ in both modes
             g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(p, k, a.glv != 0, a.vtab + (size_t)slot * G1_TAB * 2 * N * n + i, n));
+        } else if (a.fixwk.pts0) {
+            G1Jac<C> r = g1j_inf<C>();
+            if (part == a.nvar) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.L + 2, a.fixwk, r);
+            g1j_store<C>(out, n, i, r);
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - a.nvar));
         }
@@ -1281,6 +1414,7 @@ struct MsmArgs {
     int8_t* status;
     uint32_t* partials;       // [n_var + NFIX][3N][n]
     uint32_t* out;            // [2NC][n] canonical
+    FixTreeWork<C> fixwk;     // see PvArgs
 };
 
 template <class C>
@@ -1299,6 +1433,10 @@ struct MsmPart {
             uint32_t k[8];
             soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
             g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
+        } else if (a.fixwk.pts0) {
+            G1Jac<C> r = g1j_inf<C>();
+            if (part == a.n_var) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.n_fixed, a.fixwk, r);
+            g1j_store<C>(out, n, i, r);
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.n_fixed, part - a.n_var));
         }

@@ -194,6 +194,10 @@ class Engine:
         """bbs_ctx_set_points_in_subgroup: the caller vouches that every G1 input is in the prime-order subgroup."""
         self._chk(self.lib.bbs_ctx_set_points_in_subgroup(self.h, 1 if vouched else 0), "bbs_ctx_set_points_in_subgroup")
 
+    def set_fixed_base_tree(self, enabled: bool):
+        """bbs_ctx_set_fixed_base_tree: fixed-base sums as one tree of affine additions per item (jobs created afterwards)."""
+        self._chk(self.lib.bbs_ctx_set_fixed_base_tree(self.h, 1 if enabled else 0), "bbs_ctx_set_fixed_base_tree")
+
     def set_latency_mode(self, enabled: bool):
         """bbs_ctx_set_latency_mode: proof_verify's T1 as three multiplications on three lanes (one batch at a time)."""
         self._chk(self.lib.bbs_ctx_set_latency_mode(self.h, 1 if enabled else 0), "bbs_ctx_set_latency_mode")

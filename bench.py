@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--config", default="proof_verify_4096", choices=["proof_verify_4096", "mixed65536"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sign/verify/proof_gen/BN254 figures")
+    ap.add_argument("--fixed-base-tree", type=int, default=None, help="A/B: bbs_ctx_set_fixed_base_tree on (1) / off (0); default = the library's")
     ap.add_argument("--no-stage-timing", action="store_true", help="no HIP events in the timed region (A/B of their cost)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 path on a box with fewer GPUs than ranks)")
@@ -206,6 +207,8 @@ def main():
     n, L, R = args.batch, 32, 8
     n_slots = max(1, args.inflight)
     suite, eng, gens, sk = pc.bench_engine("bls12_381", L, None, args.window_bits, device=local_rank)
+    if args.fixed_base_tree is not None:
+        eng.set_fixed_base_tree(bool(args.fixed_base_tree))
     # every rank and every slot verifies its own batch: item ids offset by rank and slot
     slots, raw0 = make_slots(pc, suite, eng, n, L, R, n_slots, first_item=rank * n_slots * n)
     msgs, disclosed, rnds, sigs, proofs, dm = raw0

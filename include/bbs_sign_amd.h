@@ -114,6 +114,11 @@ int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched);
  * critical lane about one third shorter, about 10 % more instructions per batch.  For callers that verify one batch
  * at a time; with several batches in flight the default is faster.  Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled);
+/* Fixed-base sums (the generators' multiples: B of sign / verify / proof_gen, the fixed part of T2 of proof_verify) as
+ * ONE tree of affine additions per item with one shared inversion per level, instead of eight chains of mixed Jacobian
+ * additions: fewer field multiplications, the same group element, bit-identical results.  Needs work memory of about
+ * 90 bytes x table points (messages + 2) x windows per item of a job.  Applies to jobs created afterwards. */
+int bbs_ctx_set_fixed_base_tree(bbs_ctx* ctx, int enabled);
 
 /* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
  * products of a batch (src/proof_verify.rs:112-115, src/verify.rs:88-92) are replaced by 16 products over random

@@ -1311,3 +1311,89 @@ def check_threads(lib_path=None, threads=4, rounds=3, n=9, L=3, seed=81):
         e.close()
     assert not errors, errors[0][1]
 
+
+def check_fixed_base_tree(curve, lib_path=None, L=6, seed=91, window_bits=None, n_pv=10):
+    """bbs_ctx_set_fixed_base_tree: the fixed-base sum as one tree of affine additions per item.  (a) Group elements of the
+    MSM primitive against the oracle's plain sum, with generators chosen to hit every exceptional case of affine addition
+    -- repeated generators (equal table entries: doubling), opposite generators (cancellation to the identity, at the
+    leaves and higher up), zero digits and all-zero scalars (identity operands), odd and even numbers of terms; (b) the
+    same proof_verify / verify / sign / proof_gen results as the chunked sums and the oracle."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    neg = lambda pt: (pt[0], (c.p - pt[1]) % c.p)
+    # Q1, H1..HL with H2 = H1, H3 = -H1, H5 = -H4 (caller-supplied generators are arbitrary points)
+    g2 = list(gens)
+    g2[2] = g2[1]
+    g2[3] = neg(g2[1])
+    g2[5] = neg(g2[4])
+    for gset in (gens, g2):
+        bases = [suite.p1] + gset
+        eng = make_engine(curve, gset, api_id, lib_path, sk=rng.randrange(1, c.r), window_bits=window_bits)
+        eng.set_fixed_base_tree(True)
+        top = (1 << 256) - 1
+        rows = [[0] * (L + 2), [1] * (L + 2), [c.r - 1] * (L + 2), [top % c.r] * (L + 2)]
+        rows.append([0, 0, 5, 5, 5, 0, 0, 0][:L + 2])                       # H1 + H2 (= 2 H1) + H3 (= -H1): doubling and cancellation
+        rows.append([0, 0, 7, 0, 7, 0, 0, 0][:L + 2])                       # H1 + (-H1) = identity at the leaves, everything else zero
+        rows.append([0, 0, 0, 0, 0, 9, 9, 0][:L + 2])                       # H4 + (-H4)
+        rows.append([3, 0, 11, 11, 0, 0, 0, 2][:L + 2])
+        rows += [[rng.randrange(c.r) for _ in range(L + 2)] for _ in range(6)]
+        rows += [[rng.randrange(1 << 20) for _ in range(L + 2)] for _ in range(3)]       # mostly zero digits
+        for nf in (L + 2, 1, 3):                                             # odd / even numbers of table points
+            fs = [r_[:nf] for r_ in rows]
+            out, st = eng.g1_msm_batch(fs, [], [])
+            assert list(st) == [1] * len(fs)
+            for i, row in enumerate(fs):
+                want = None
+                for k in range(nf):
+                    want = c.g1_add(want, c.g1_mul(bases[k], row[k]))
+                assert out[i] == want, (curve, gset is g2, nf, i, row)
+        eng.close()
+    # (b) the four operations: tree on vs off vs oracle
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    off = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    on = make_engine(curve, gens, api_id, lib_path, sk=sk, window_bits=window_bits)
+    on.set_fixed_base_tree(True)
+    n = n_pv
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    msgs[0] = [0] * L
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 7, 66]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 3]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = on.core_sign_batch(msgs, headers)
+    sigs0, st0 = off.core_sign_batch(msgs, headers)
+    assert list(st) == list(st0) == [1] * n
+    for i in range(n):
+        w = bbs.core_sign(suite, sk, gens, headers[i], msgs[i], api_id) if i < 3 else sigs0[i]
+        assert (sigs[i].a, sigs[i].e) == (w.a, w.e) == (sigs0[i].a, sigs0[i].e), (curve, i, "sign")
+    vm = [list(m) for m in msgs]
+    vm[1][0] = (vm[1][0] + 1) % c.r
+    assert list(on.core_verify_batch(sigs, vm, headers)) == list(off.core_verify_batch(sigs, vm, headers)) == [1] + [0] + [1] * (n - 2)
+    proofs, st = on.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    proofs0, st0 = off.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == list(st0) == [1] * n and all(proof_eq(a_, b_) for a_, b_ in zip(proofs, proofs0))
+    assert proof_eq(proofs[2], bbs.core_proof_gen(suite, pk, bbs.Signature(sigs[2].a, sigs[2].e), headers[2], gens, phs[2], msgs[2],
+                                                 disclosed[2], api_id, rnds[2]))
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    bad = [to_engine_proof(p_) for p_ in proofs]
+    bad[3].commitments = list(bad[3].commitments)
+    if bad[3].commitments:
+        bad[3].commitments[0] = (bad[3].commitments[0] + 1) % c.r
+    else:
+        bad[3].e_cap = (bad[3].e_cap + 1) % c.r
+    bad[4].challenge = (bad[4].challenge + 1) % c.r
+    got = list(on.core_proof_verify_batch(bad, dm, disclosed, headers, phs))
+    assert got == list(off.core_proof_verify_batch(bad, dm, disclosed, headers, phs)) == [1, 1, 1, 0, 0] + [1] * (n - 5), got
+    for i in (0, 3):
+        op = bbs.Proof(bad[i].a_bar, bad[i].b_bar, bad[i].d, bad[i].e_cap, bad[i].r1_cap, bad[i].r3_cap, bad[i].commitments, bad[i].challenge)
+        assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], disclosed[i], api_id)) == got[i]
+    j = on.core_proof_verify_submit(bad, dm, disclosed, headers, phs)
+    j.wait()
+    assert [int(x) for x in j.result] == got
+    j.free()
+    on.close(); off.close()
+

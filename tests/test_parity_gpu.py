@@ -115,3 +115,11 @@ def test_verify_octets(curve):
 def test_threads():
     pc.check_threads(None, threads=6, rounds=4, n=64, L=5)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("window_bits", [8, 13, 20])
+def test_fixed_base_tree(curve, window_bits):
+    if curve == "bn254" and window_bits == 20:
+        window_bits = 16
+    pc.check_fixed_base_tree(curve, None, window_bits=window_bits, n_pv=70)
+

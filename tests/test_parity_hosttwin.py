@@ -103,3 +103,9 @@ def test_verify_octets(twin, curve):
 def test_threads(twin):
     pc.check_threads(twin)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_fixed_base_tree(twin, curve):
+    pc.check_fixed_base_tree(curve, twin)
+    pc.check_fixed_base_tree(curve, twin, L=6, seed=92, window_bits=7, n_pv=6)
+
