@@ -117,7 +117,9 @@ int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled);
 /* Fixed-base sums (the generators' multiples: B of sign / verify / proof_gen, the fixed part of T2 of proof_verify) as
  * ONE tree of affine additions per item with one shared inversion per level, instead of eight chains of mixed Jacobian
  * additions: fewer field multiplications, the same group element, bit-identical results.  Needs work memory of about
- * 90 bytes x table points (messages + 2) x windows per item of a job.  Applies to jobs created afterwards. */
+ * 90 bytes x table points (messages + 2) x windows per item of a job.  EXPERIMENTAL and off by default: in its present
+ * form it is not faster (measured); today it covers proof_verify and bbs_g1_msm_batch.  Applies to jobs
+ * created afterwards. */
 int bbs_ctx_set_fixed_base_tree(bbs_ctx* ctx, int enabled);
 
 /* Batch verification for core_proof_verify and core_verify (off by default).  When enabled, the n two-pairing
