@@ -76,8 +76,8 @@ inline int stream_create(Stream* s);      // pooled, defined below
 inline void stream_destroy(Stream& s);
 // Device buffers, streams and events are recycled per device: a one-shot batch call allocated ~20 buffers and two
 // streams and released them again, 6 ms of hipMalloc / hipFree / stream creation per 4096-proof call.  Buffers up
-// to 64 MiB go back to a free list by size class (powers of two below 1 MiB, multiples of 1 MiB above), at most
-// 2 GiB per device; larger ones (the window tables) are allocated and freed directly.
+// to 256 MiB go back to a free list by size class (powers of two below 1 MiB, multiples of 1 MiB above), at most
+// 8 GiB per device; larger ones (the window tables) are allocated and freed directly.
 struct Pools {
     std::mutex mu;
     std::map<int, std::multimap<size_t, void*>> bufs;
@@ -105,7 +105,7 @@ inline size_t size_class(size_t b) {
     if (b <= (1u << 20)) { size_t c = 256; while (c < b) c <<= 1; return c; }
     return (b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
 }
-constexpr size_t POOL_MAX_BUF = (size_t)64 << 20, POOL_MAX_TOTAL = (size_t)2 << 30;
+constexpr size_t POOL_MAX_BUF = (size_t)256 << 20, POOL_MAX_TOTAL = (size_t)8 << 30;
 inline int dmalloc(void** p, size_t b) {
     const size_t cls = size_class(b);
     if (cls <= POOL_MAX_BUF) {

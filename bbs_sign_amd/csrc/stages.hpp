@@ -273,26 +273,36 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
 #pragma unroll
         for (int j = 0; j < N; j++) { b[(size_t)j * n] = q.x.v[j]; b[(size_t)(N + j) * n] = q.y.v[j]; }
     };
-    // level 0: the table entries themselves (digit 0 -> identity)
+    // level 0: the table entries themselves (digit 0 -> identity).  The reads are random 112-byte HBM accesses and nothing
+    // depends on them but the store behind them: four are in flight at a time (a load -> store chain per entry would pay
+    // the full memory latency 442 times per item)
     {
-        int k_cur = -1;
-        uint32_t sc[8];
-        for (int t = 0; t < T; t++) {
+        auto entry = [&](int t) -> const uint32_t* {
             const int k = t / W, w = t - k * W;
-            if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); k_cur = k; }
+            uint32_t sc[8];
+            soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc);
             const int bit = w * c;
             const int li = bit >> 5, sh = bit & 31;
             uint64_t two = sc[li];
             if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
             uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
             if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
-            G1Aff<C> q = g1a_inf<C>();
-            if (d) {
-                const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
+            return d ? cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N) : nullptr;
+        };
+        constexpr int G = 4;
+        for (int t0 = 0; t0 < T; t0 += G) {
+            G1Aff<C> q[G];
 #pragma unroll
-                for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
+            for (int g = 0; g < G; g++) {
+                q[g] = g1a_inf<C>();
+                const uint32_t* e = t0 + g < T ? entry(t0 + g) : nullptr;
+                if (e) {
+#pragma unroll
+                    for (int j = 0; j < N; j++) { q[g].x.v[j] = e[j]; q[g].y.v[j] = e[N + j]; }
+                }
             }
-            st(wk.pts0, t, q);
+#pragma unroll
+            for (int g = 0; g < G; g++) if (t0 + g < T) st(wk.pts0, t0 + g, q[g]);
         }
     }
     // what a pair needs: the denominator of its slope (1 when the result needs none), and how to finish it
