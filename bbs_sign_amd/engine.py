@@ -331,25 +331,29 @@ class Engine:
         return job
 
     def _sig_octets(self, octets):
-        n = len(octets)
-        if any(len(o) != self.fpb + 32 for o in octets):
-            raise ValueError("signature octets: fp_bytes + 32 each (check the length before batching; -42 per item)")
-        return _bytes_arr(b"".join(octets)) if n else np.zeros(1, dtype=np.uint8)
+        """-> (flat buffer of n strings of fp_bytes + 32 octets, indexes of the items whose string has another length).
+        The C ABI takes a fixed stride; a string of the wrong length is malformed (-42, as octets_to_signature gives) and
+        travels as zeros, its status is overwritten afterwards."""
+        want = self.fpb + 32
+        bad = [i for i, o in enumerate(octets) if len(o) != want]
+        flat = b"".join(o if len(o) == want else bytes(want) for o in octets)
+        return (_bytes_arr(flat) if octets else np.zeros(1, dtype=np.uint8)), bad
 
     def verify_octets_batch(self, sig_octets, messages, headers=None) -> np.ndarray:
         """bbs_verify_octets_batch: signature octet strings in (decoded and subgroup-checked on the device), statuses out."""
         n = len(sig_octets)
-        ob = self._sig_octets(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
         ms, mo = self._scalars(messages)
         hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
         st = np.full(max(n, 1), -128, dtype=np.int8)
         self._chk(self.lib.bbs_verify_octets_batch(self.h, n, _u8(ob), _u8(ms), _u64(mo), _u8(hb), _u64(ho),
                                                    st.ctypes.data_as(_lib.c_i8p)), "bbs_verify_octets_batch")
+        st[bad] = -42
         return st[:n]
 
     def verify_octets_submit(self, sig_octets, messages, headers=None) -> "Job":
         n = len(sig_octets)
-        ob = self._sig_octets(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
         ms, mo = self._scalars(messages)
         hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
         st = np.full(max(n, 1), -128, dtype=np.int8)
@@ -358,6 +362,7 @@ class Engine:
                                                     st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_verify_octets_submit")
         job = Job(self, j, n)
         job.result = st[:n]
+        job._fixup = (lambda: st.__setitem__(bad, -42)) if bad else None
         return job
 
     def core_verify_upload(self, signatures, messages, headers=None) -> "Job":
@@ -619,6 +624,7 @@ class Job:
         self.total_msgs = 0
         self.result = None          # submit form: the statuses, valid after wait()
         self._decode = None         # submit form of sign / proof_gen: decodes the delivered records
+        self._fixup = None          # applied to `result` once the statuses have been delivered
         self._waited = False
 
     def run(self):
@@ -627,6 +633,8 @@ class Job:
     def wait(self):
         Engine._chk(self.eng.lib.bbs_job_wait(self.h), "bbs_job_wait")
         self._waited = True
+        if self._fixup is not None:
+            self._fixup()
 
     def output(self):
         """Submit form of sign / proof_gen, after wait(): (signatures | proofs with None for failed items, statuses)."""

@@ -166,7 +166,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     def all_true(j):
         assert (j.result == 1).all()
     sig_octs = [_api.signature_to_octets("bls12_381", s_) for s_ in sigs[:n]]
-    ob_s = eng._sig_octets(sig_octs)
+    ob_s, _ = eng._sig_octets(sig_octs)
     ms_v, mo_v = eng._scalars(msgs)
     hb_v, ho_v = _ragged_bytes([b""] * n)
     sg_v = eng._sigs(sigs)

@@ -1232,6 +1232,13 @@ def check_verify_octets(curve, lib_path=None, n=16, L=4, seed=71):
         assert [int(x_) for x_ in j.result] == want
         j.free()
     assert list(eng.verify_octets_batch([], [], [])) == []
+    # a string of the wrong length is malformed (the Python mirror pads it for the fixed-stride ABI and reports -42)
+    short = [octs[0][:-1], octs[14], octs[15] + b"\x00"]
+    assert list(eng.verify_octets_batch(short, [vm[0], vm[14], vm[15]], [vh[0], vh[14], vh[15]])) == [-42, 1, -42]
+    j = eng.verify_octets_submit(short, [vm[0], vm[14], vm[15]], [vh[0], vh[14], vh[15]])
+    j.wait()
+    assert list(j.result) == [-42, 1, -42]
+    j.free()
     eng.close()
     if curve == "bls12_381":
         S = bbs.BLS_SUITE
