@@ -67,6 +67,7 @@ SIGNATURES = {
     "bbs_job_run": (ci, [vp]),
     "bbs_job_wait": (ci, [vp]),
     "bbs_job_size": (sz, [vp]),
+    "bbs_job_device_bytes": (sz, [vp]),
     "bbs_job_fetch_status": (ci, [vp, c_i8p]),
     "bbs_job_fetch_signatures": (ci, [vp, c_u8p]),
     "bbs_job_fetch_proofs": (ci, [vp, c_u8p, c_u8p, c_u64p]),

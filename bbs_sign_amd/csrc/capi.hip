@@ -353,6 +353,7 @@ int bbs_job_run(bbs_job* job) { return job ? job->run() : BBS_E_ARG; }
 int bbs_job_wait(bbs_job* job) { return job ? job->wait() : BBS_E_ARG; }
 size_t bbs_job_size(const bbs_job* job) { return job ? job->n : 0; }
 int bbs_job_fetch_status(bbs_job* job, int8_t* st) { return (job && st) ? job->fetch_status(st) : BBS_E_ARG; }
+size_t bbs_job_device_bytes(const bbs_job* job) { return job ? job->device_bytes() : 0; }
 int bbs_job_fetch_signatures(bbs_job* job, uint8_t* out) { return (job && out) ? job->fetch_signatures(out) : BBS_E_ARG; }
 int bbs_job_fetch_proofs(bbs_job* job, uint8_t* pf, uint8_t* cm, uint64_t* cmo) { return job ? job->fetch_proofs(pf, cm, cmo) : BBS_E_ARG; }
 void bbs_job_free(bbs_job* job) { delete job; }

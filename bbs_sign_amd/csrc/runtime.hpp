@@ -37,6 +37,7 @@ inline int set_device(int) { return 0; }
 inline int device_count() { return 1; }
 inline int stream_create(Stream*) { return 0; }
 inline void stream_destroy(Stream&) {}
+inline size_t size_class(size_t b) { return b; }
 inline int dmalloc(void** p, size_t b) { *p = std::calloc(b ? b : 1, 1); return *p ? 0 : -1; }
 inline void dfree(void* p, size_t, int) { std::free(p); }
 inline int current_device() { return 0; }
@@ -566,6 +567,7 @@ struct bbs_job {
     // caller's buffers
     virtual int enqueue_result_fetch() { return BBS_OK; }
     virtual void set_result_targets(uint8_t*, uint8_t*, uint64_t*) {}
+    virtual size_t device_bytes() const { return 0; }     // device memory this job holds (allocation size classes)
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
     virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }
     // One pass over the stages.  ev != nullptr: one event before the first stage, then a (start, stop) pair around
@@ -630,6 +632,13 @@ struct JobBase : bbs_job {
         if (main_ready) { rt::sync(main); rt::stream_destroy(main); }
     }
     int use() override { return ctx->use(); }
+    size_t device_bytes() const override {
+        size_t t = 0;
+        auto add = [&](const DevBuf& b) { if (b.p) t += rt::size_class(b.bytes); };
+        add(d_status); add(d_status0); add(d_raw);
+        for (const auto& b : bufs) add(*b);
+        return t;
+    }
     rt::Stream& stream() override { return main_ready ? main : ctx->stream; }
     int ensure_aux() {
         if (aux_ready) return 0;

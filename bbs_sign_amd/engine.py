@@ -642,6 +642,9 @@ class Job:
             raise RuntimeError("output(): a sign / proof_gen submit job that has been waited for")
         return self._decode()
 
+    def device_bytes(self) -> int:
+        return int(self.eng.lib.bbs_job_device_bytes(self.h))
+
     def status(self) -> np.ndarray:
         st = np.zeros(max(self.n, 1), dtype=np.int8)
         Engine._chk(self.eng.lib.bbs_job_fetch_status(self.h, st.ctypes.data_as(_lib.c_i8p)), "bbs_job_fetch_status")

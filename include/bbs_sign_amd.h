@@ -274,6 +274,8 @@ int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
 int bbs_job_run(bbs_job* job);                       /* asynchronous */
 int bbs_job_wait(bbs_job* job);
 size_t bbs_job_size(const bbs_job* job);
+/* device memory the job holds until bbs_job_free, in bytes (sizing: INTEGRATION.md); batch verification adds its own */
+size_t bbs_job_device_bytes(const bbs_job* job);
 int bbs_job_fetch_status(bbs_job* job, int8_t* status);
 int bbs_job_fetch_signatures(bbs_job* job, uint8_t* signatures_out);
 int bbs_job_fetch_proofs(bbs_job* job, uint8_t* proofs_fixed_out, uint8_t* commitments_out,
