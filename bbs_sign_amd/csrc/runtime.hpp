@@ -728,6 +728,7 @@ struct RaggedIn {
         if (!off) return true;
         for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
         total = off[n] - off[0];
+        if (total > ((uint64_t)1 << 36)) return false;       // no batch holds 2^36 elements: garbage offsets, and total * elem must not wrap
         return total == 0 || data != nullptr;
     }
     void place(size_t& cur, size_t n) {
