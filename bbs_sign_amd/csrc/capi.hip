@@ -559,6 +559,47 @@ int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const
     if (rc) return rc;
     return submit_with_results(job, status, pf_out, cm_out, cmo_out, job_out);
 }
+// sign / proof_gen to the WIRE: the results leave the device as octet strings (compression on the device)
+int bbs_sign_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
+                           uint8_t* sig_octets_out, int8_t* status, bbs_job** job_out) {
+    if (!status || !job_out || (n && !sig_octets_out)) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = bbs_core_sign_upload(ctx, n, m, mo, h, ho, &job);
+    if (rc) return rc;
+    if ((rc = job->set_octet_form())) { delete job; return rc; }
+    return submit_with_results(job, status, sig_octets_out, nullptr, nullptr, job_out);
+}
+int bbs_sign_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
+                          uint8_t* sig_octets_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_sign_octets_submit(ctx, n, m, mo, h, ho, sig_octets_out, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
+int bbs_proof_gen_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                                const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                                const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_job** job_out) {
+    if (!status || !job_out || !oct_off_out || (n && !octets_out)) return BBS_E_ARG;
+    bbs_job* job = nullptr;
+    int rc = bbs_core_proof_gen_upload(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, &job);
+    if (rc) return rc;
+    if ((rc = job->set_octet_form())) { delete job; return rc; }
+    return submit_with_results(job, status, octets_out, nullptr, oct_off_out, job_out);
+}
+int bbs_proof_gen_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
+                               const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                               const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                               uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_proof_gen_octets_submit(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, octets_out, oct_off_out, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
 int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
                         uint8_t* sigs_out, int8_t* status) {
     bbs_job* job = nullptr;

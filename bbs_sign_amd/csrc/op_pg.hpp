@@ -28,10 +28,26 @@ struct PgJob : JobBase<C> {
         if (commit_off) commit_off[n] = off;
     }
     size_t out_bytes() const { return this->n * (rec_bytes() + mh_bytes() + 4); }
+    // wire form (PgEmit, oct_form): the octet strings sit at a fixed stride at the start of the block, the counts where
+    // they always are; ucount = 0xFFFFFFFF marks a failed item (no string)
+    int set_octet_form() override { a.oct_form = 1; return BBS_OK; }
+    size_t oct_stride() const { return (size_t)(12 * C::FpP::NC) + 32 * (size_t)(4 + std::max(a.L, 1)); }
+    void unpack_octets(const uint8_t* blk, const uint32_t* ucount, uint8_t* oct_out, uint64_t* oct_off) const {
+        uint64_t off = 0;
+        for (size_t i = 0; i < this->n; i++) {
+            if (oct_off) oct_off[i] = off;
+            if (ucount[i] == 0xFFFFFFFFu) continue;
+            const size_t len = (size_t)(12 * C::FpP::NC) + 32 * (size_t)(4 + ucount[i]);
+            if (oct_out) std::memcpy(oct_out + off, blk + i * oct_stride(), len);
+            off += len;
+        }
+        if (oct_off) oct_off[this->n] = off;
+    }
     // one device block [records | m^ | counts] so that a fetch is one copy
     int fetch_proofs(uint8_t* pf_out, uint8_t* commit_out, uint64_t* commit_off) override {
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         const size_t n = this->n;
+        if (a.oct_form) return BBS_E_STATE;                     // the wire form is delivered by bbs_job_wait only
         if (!n) { if (commit_off) commit_off[0] = 0; return BBS_OK; }
         if (int rc = this->require_decided()) return rc;        // a job that never ran holds no records (fail closed)
         std::vector<uint8_t> h(out_bytes());
@@ -58,6 +74,10 @@ struct PgJob : JobBase<C> {
         if (!n) { if (cmo_to) cmo_to[0] = 0; return BBS_OK; }
         if (!h_out.p) return BBS_E_STATE;
         const uint8_t* h = h_out.template as<uint8_t>();
+        if (a.oct_form) {
+            unpack_octets(h, reinterpret_cast<const uint32_t*>(h + n * (rec_bytes() + mh_bytes())), pf_to, cmo_to);
+            return BBS_OK;
+        }
         unpack(h, h + n * rec_bytes(), reinterpret_cast<const uint32_t*>(h + n * (rec_bytes() + mh_bytes())), pf_to, cm_to, cmo_to);
         return BBS_OK;
     }
@@ -142,6 +162,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
         if (rc) return rc;
         a.out_mh = a.out_rec + wrec;
         a.ucount = a.out_mh + wmh;
+        a.oct_form = 0;
     }
     if (rc) return rc;
     if ((rc = job->finish_setup_device())) return rc;

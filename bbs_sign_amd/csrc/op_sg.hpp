@@ -10,7 +10,8 @@ struct SgJob : JobBase<C> {
     SgArgs<C> a{};
     VfIngestArgs<C> ingest{};
     // the records come off the device in the caller's layout (stage SgEmit): delivery is one copy
-    size_t rec_bytes() const { return (size_t)(8 * C::FpP::NC + 32); }
+    size_t rec_bytes() const { return a.oct_form ? (size_t)(4 * C::FpP::NC + 32) : (size_t)(8 * C::FpP::NC + 32); }
+    int set_octet_form() override { a.oct_form = 1; return BBS_OK; }
     int fetch_signatures(uint8_t* out) override {
         if (this->use() || rt::sync(this->stream())) return BBS_E_HIP;
         if (int rc = this->require_decided()) return rc;        // a job that never ran holds no records (fail closed)
@@ -66,6 +67,7 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     a.out_a = job->template scratch<uint32_t>((size_t)2 * C::FpP::NC * n, rc);
     a.out_e = job->template scratch<uint32_t>((size_t)8 * n, rc);
     a.out_rec = job->template scratch<uint32_t>((size_t)(2 * C::FpP::NC + 8) * nn, rc);
+    a.oct_form = 0;
     if (rc) return rc;
     if ((rc = job->finish_setup_device())) return rc;
     a.status = job->d_status.template as<int8_t>();

@@ -567,6 +567,7 @@ struct bbs_job {
     // caller's buffers
     virtual int enqueue_result_fetch() { return BBS_OK; }
     virtual void set_result_targets(uint8_t*, uint8_t*, uint64_t*) {}
+    virtual int set_octet_form() { return BBS_E_ARG; }    // sign / proof_gen: results leave as octet strings (before run)
     virtual size_t device_bytes() const { return 0; }     // device memory this job holds (allocation size classes)
     virtual int fetch_signatures(uint8_t*) { return BBS_E_ARG; }
     virtual int fetch_proofs(uint8_t*, uint8_t*, uint64_t*) { return BBS_E_ARG; }

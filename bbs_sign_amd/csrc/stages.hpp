@@ -841,6 +841,43 @@ BBS_HD void be32_words(const uint8_t* b, uint32_t* w) {
     }
 }
 
+// 8 little-endian words -> 32 big-endian bytes (I2OSP(x, 32))
+BBS_HD void words_be32(const uint32_t* w, uint8_t* b) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t v = w[7 - k];
+        b[4 * k] = (uint8_t)(v >> 24); b[4 * k + 1] = (uint8_t)(v >> 16); b[4 * k + 2] = (uint8_t)(v >> 8); b[4 * k + 3] = (uint8_t)v;
+    }
+}
+// compressed G1 octets from CANONICAL affine words (x: NC words, y: NC words; all zero = identity), the formats of
+// codec_dev.hpp: BLS12-381 48 bytes big-endian with flags 0x80 / 0x40 / 0x20 in byte 0, BN254 32 bytes little-endian with
+// flags 0x80 (y is the larger root) / 0x40 (identity) in the last byte
+template <class C>
+BBS_HD void g1_words_to_octets(const uint32_t* xw, const uint32_t* yw, uint8_t* out) {
+    using P = typename C::FpP;
+    constexpr int NC = P::NC, NB = 4 * NC;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) any |= xw[k] | yw[k];
+    const bool inf = any == 0;
+    const bool ybig = !inf && words_gt_half<P>(yw);
+    if constexpr (C::ID == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const uint32_t v = xw[NC - 1 - k];
+            out[4 * k] = (uint8_t)(v >> 24); out[4 * k + 1] = (uint8_t)(v >> 16); out[4 * k + 2] = (uint8_t)(v >> 8); out[4 * k + 3] = (uint8_t)v;
+        }
+        out[0] |= (uint8_t)(0x80u | (inf ? 0x40u : 0u) | (ybig ? 0x20u : 0u));
+    } else {
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const uint32_t v = xw[k];
+            out[4 * k] = (uint8_t)v; out[4 * k + 1] = (uint8_t)(v >> 8); out[4 * k + 2] = (uint8_t)(v >> 16); out[4 * k + 3] = (uint8_t)(v >> 24);
+        }
+        out[NB - 1] |= (uint8_t)((inf ? 0x40u : 0u) | (ybig ? 0x80u : 0u));
+    }
+}
+
 // stage 0 of verify (lane per item, once per upload): verify.rs:69-71's length check, range checks of the signature
 // and the messages, transposition of the item-major staging image into the SoA arrays (see PvIngest)
 template <class C>
@@ -990,6 +1027,7 @@ struct SgArgs {
     uint32_t* out_a;          // [2NC][n] canonical
     uint32_t* out_e;          // [8][n] canonical
     uint32_t* out_rec;        // [n][2NC + 8]: the records A || e as the caller receives them (SgEmit)
+    int oct_form;             // 1: out_rec holds n octet strings compress(A) || I2OSP(e, 32) instead (fp_bytes + 32 each)
 };
 
 template <class C>
@@ -1064,8 +1102,19 @@ struct SgEmit {
     static __host__ __device__ void run(const SgArgs<C>& a, size_t i) {
         constexpr int NC = C::FpP::NC, W = 2 * NC + 8;
         const size_t n = a.n;
-        uint32_t* r = a.out_rec + i * (size_t)W;
         const bool ok = a.status[i] == 1;
+        if (a.oct_form) {
+            constexpr size_t NB = 4 * NC;
+            uint8_t* o = reinterpret_cast<uint8_t*>(a.out_rec) + i * (NB + 32);
+            if (!ok) { for (size_t k = 0; k < NB + 32; k++) o[k] = 0; return; }
+            uint32_t pw[2 * NC], e[8];
+            for (int k = 0; k < 2 * NC; k++) pw[k] = a.out_a[(size_t)k * n + i];
+            for (int k = 0; k < 8; k++) e[k] = a.out_e[(size_t)k * n + i];
+            g1_words_to_octets<C>(pw, pw + NC, o);
+            words_be32(e, o + NB);
+            return;
+        }
+        uint32_t* r = a.out_rec + i * (size_t)W;
         for (int k = 0; k < 2 * NC; k++) r[k] = ok ? a.out_a[(size_t)k * n + i] : 0u;
         for (int k = 0; k < 8; k++) r[2 * NC + k] = ok ? a.out_e[(size_t)k * n + i] : 0u;
     }
@@ -1111,6 +1160,10 @@ struct PgArgs {
     uint32_t* out_rec;
     uint32_t* out_mh;
     uint32_t* ucount;
+    // 1: the wire form instead -- out_rec holds, at a stride of 3 fp_bytes + 32 (4 + max(L, 1)) bytes per item, the octet
+    // string compress(Abar) || compress(Bbar) || compress(D) || e^ || r1^ || r3^ || m^_1 .. m^_U || c (scalars big-endian),
+    // 3 fp_bytes + 32 (4 + U) bytes of it used; out_mh is not written
+    int oct_form;
 };
 
 // stage 0 of proof_gen (lane per item, once per upload): the checks of proof_gen.rs:133-143 and :229-239 in the
@@ -1370,8 +1423,37 @@ struct PgEmit {
     static __host__ __device__ void run(const PgArgs<C>& a, size_t i) {
         constexpr int NC = C::FpP::NC, W = 6 * NC + 32;
         const size_t n = a.n;
-        uint32_t* r = a.out_rec + i * (size_t)W;
         const bool ok = a.status[i] == 1;
+        if (a.oct_form) {
+            constexpr size_t NB = 4 * NC;
+            const size_t stride = 3 * NB + 32 * (size_t)(4 + (a.L > 1 ? a.L : 1));
+            uint8_t* o = reinterpret_cast<uint8_t*>(a.out_rec) + i * stride;
+            uint32_t u = 0;
+            if (ok) {
+                for (int p = 0; p < 3; p++) {
+                    uint32_t pw[2 * NC];
+                    for (int k = 0; k < 2 * NC; k++) pw[k] = a.out_pts[((size_t)p * 2 * NC + k) * n + i];
+                    g1_words_to_octets<C>(pw, pw + NC, o + (size_t)p * NB);
+                }
+                uint32_t w[8];
+                for (int q = 0; q < 3; q++) {
+                    for (int k = 0; k < 8; k++) w[k] = a.out_sc[((size_t)q * 8 + k) * n + i];
+                    words_be32(w, o + 3 * NB + 32 * (size_t)q);
+                }
+                for (int j = 0; j < a.L; j++) {
+                    const uint32_t dm = a.dmask[(size_t)(j >> 5) * n + i];
+                    if ((dm >> (j & 31)) & 1u) continue;
+                    for (int k = 0; k < 8; k++) w[k] = a.out_mhat[((size_t)j * 8 + k) * n + i];
+                    words_be32(w, o + 3 * NB + 96 + 32 * (size_t)u);
+                    u++;
+                }
+                for (int k = 0; k < 8; k++) w[k] = a.out_sc[((size_t)3 * 8 + k) * n + i];
+                words_be32(w, o + 3 * NB + 96 + 32 * (size_t)u);
+            }
+            a.ucount[i] = ok ? u : 0xFFFFFFFFu;          // no string at all for a failed item
+            return;
+        }
+        uint32_t* r = a.out_rec + i * (size_t)W;
         for (int k = 0; k < 6 * NC; k++) r[k] = ok ? a.out_pts[(size_t)k * n + i] : 0u;
         for (int k = 0; k < 32; k++) r[6 * NC + k] = ok ? a.out_sc[(size_t)k * n + i] : 0u;
         uint32_t u = 0;

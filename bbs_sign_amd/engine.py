@@ -414,6 +414,52 @@ class Engine:
         job._decode = lambda: (self._dec_sigs(out, st, n), st[:n])
         return job
 
+    def sign_octets_submit(self, messages, headers=None) -> "Job":
+        """bbs_sign_octets_submit: signatures leave as octet strings; ``job.wait()`` then ``job.output()`` ->
+        (list of bytes, b"" for failed items; statuses)."""
+        n = len(messages)
+        ms, mo = self._scalars(messages)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        rec = self.fpb + 32
+        out = np.zeros(max(n, 1) * rec, dtype=np.uint8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_sign_octets_submit(self.h, n, _u8(ms), _u64(mo), _u8(hb), _u64(ho), _u8(out),
+                                                  st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)), "bbs_sign_octets_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        job._decode = lambda: ([out[i * rec:(i + 1) * rec].tobytes() if st[i] == 1 else b"" for i in range(n)], st[:n])
+        return job
+
+    def sign_octets_batch(self, messages, headers=None):
+        job = self.sign_octets_submit(messages, headers)
+        job.wait()
+        r = job.output()
+        job.free()
+        return r
+
+    def proof_gen_octets_submit(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None) -> "Job":
+        """bbs_proof_gen_octets_submit: proofs leave as octet strings; ``job.output()`` -> (list of bytes, statuses)."""
+        n, keep, args = self._pg_inputs(signatures, messages, disclosed_idx, random_scalars, headers, phs)
+        cap = sum(3 * self.fpb + 32 * (4 + len(m)) for m in messages)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        oc = np.zeros(max(cap, 1), dtype=np.uint8)
+        oo = np.zeros(n + 1, dtype=np.uint64)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_proof_gen_octets_submit(self.h, n, *args, _u8(oc), _u64(oo), st.ctypes.data_as(_lib.c_i8p),
+                                                       ctypes.byref(j)), "bbs_proof_gen_octets_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        job._decode = lambda: ([oc[int(oo[i]):int(oo[i + 1])].tobytes() for i in range(n)], st[:n])
+        return job
+
+    def proof_gen_octets_batch(self, signatures, messages, disclosed_idx, random_scalars, headers=None, phs=None):
+        job = self.proof_gen_octets_submit(signatures, messages, disclosed_idx, random_scalars, headers, phs)
+        job.wait()
+        r = job.output()
+        job.free()
+        return r
+
     def core_sign_upload(self, messages, headers=None) -> "Job":
         n = len(messages)
         ms, mo = self._scalars(messages)

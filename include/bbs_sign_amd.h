@@ -242,6 +242,15 @@ int bbs_core_sign_submit(bbs_ctx* ctx, size_t n, const uint8_t* messages, const 
                          const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signatures_out,
                          int8_t* status, bbs_job** job_out);
 
+/* sign to the wire: signature_octets_out receives n strings of fp_bytes + 32 octets, compress(A) || I2OSP(e, 32) (the
+ * byte string of src/tests/test_vector.rs:188-191), all zero for an item whose status is not 1; compression on the device. */
+int bbs_sign_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
+                           const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signature_octets_out,
+                           int8_t* status, bbs_job** job_out);
+int bbs_sign_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,
+                          const uint8_t* headers, const uint64_t* hdr_off, uint8_t* signature_octets_out,
+                          int8_t* status);
+
 /* core_proof_gen (src/proof_gen.rs:116-208: proof_init :211-269, proof_challenge_calculate
  * :272-328, proof_finalize :331-365).  random_scalars replaces the draw at :145-149 and must hold
  * 5 + L - R scalars per item (R = number of disclosed indexes BEFORE dedup, as the reference
@@ -261,6 +270,24 @@ int bbs_core_proof_gen_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                              const uint8_t* ph, const uint64_t* ph_off,
                              uint8_t* proofs_fixed_out, uint8_t* commitments_out,
                              uint64_t* commit_off_out, int8_t* status);
+/* proof_gen to the wire: the proofs as octet strings (src/tests/test_vector.rs:199-260: three compressed points, e^,
+ * r1^, r3^, the m^ of the undisclosed messages, c; scalars 32 bytes big-endian) packed into octets_out, item i at
+ * oct_off_out[i] .. oct_off_out[i + 1] (n + 1 byte offsets; an item whose status is not 1 has an empty string).
+ * Capacity n x (3 fp_bytes + 32 (4 + L)) is always enough. */
+int bbs_proof_gen_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                                const uint8_t* messages, const uint64_t* msg_off,
+                                const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                const uint8_t* random_scalars, const uint64_t* rnd_off,
+                                const uint8_t* headers, const uint64_t* hdr_off,
+                                const uint8_t* ph, const uint64_t* ph_off,
+                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_job** job_out);
+int bbs_proof_gen_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
+                               const uint8_t* messages, const uint64_t* msg_off,
+                               const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                               const uint8_t* random_scalars, const uint64_t* rnd_off,
+                               const uint8_t* headers, const uint64_t* hdr_off,
+                               const uint8_t* ph, const uint64_t* ph_off,
+                               uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
 /* asynchronous form, as bbs_core_sign_submit: bbs_job_wait(job) delivers `status` and the three outputs */
 int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                               const uint8_t* messages, const uint64_t* msg_off,

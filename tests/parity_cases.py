@@ -110,6 +110,12 @@ def check_kat_vectors(lib_path=None):
         "94916292a7a6bade28456c601d3af33fcf39278d6594b467e128a3f83686a104ef2b2fcf72df0215eeaf69262ffe8194a19fab31a82ddbe06908985abc4c9825788b8a1610942d12b7f5debbea8985296361206dbace7af0cc834c80f33e0aadaeea5597befbb651827b5eed5a66f1a959bb46cfd5ca1a817a14475960f69b32c54db7587b5ee3ab665fbd37b506830a49f21d592f5e634f47cee05a025a2f8f94e73a6c15f02301d1178a92873b6e8634bafe4983c3e15a663d64080678dbf29417519b78af042be2b3e1c4d08b8d520ffab008cbaaca5671a15b22c239b38e940cfeaa5e72104576a9ec4a6fad78c532381aeaa6fb56409cef56ee5c140d455feeb04426193c57086c9b6d397d9418")
     assert eng.core_proof_verify(proof, header, ph, [msg[0]], [0]) is True
     assert eng.core_proof_verify(proof, header, ph + b"x", [msg[0]], [0]) is False
+    # the same two vectors as octet strings straight off the device (bbs_sign_octets_*, bbs_proof_gen_octets_*)
+    so, st = eng.sign_octets_batch([[msg[0]]], [header])
+    assert list(st) == [1] and so[0].hex() == ("84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f271"
+                                               "64657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0")
+    po, st = eng.proof_gen_octets_batch([sig], [[msg[0]]], [[0]], [rnd], [header], [ph])
+    assert list(st) == [1] and po[0].hex() == got
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1403,4 +1409,61 @@ def check_fixed_base_tree(curve, lib_path=None, L=6, seed=91, window_bits=None, 
     assert [int(x) for x in j.result] == got
     j.free()
     on.close(); off.close()
+
+
+def check_octets_out(curve, lib_path=None, n=12, L=5, seed=95):
+    """bbs_sign_octets_* / bbs_proof_gen_octets_*: the results as octet strings compressed on the device, against the
+    host encoder applied to the records of the core_* calls (bbs_signature_to_octets / bbs_proof_to_octets, themselves
+    pinned by the reference's vectors), failed items included, and back through the wire-form verifiers."""
+    from bbs_sign_amd import api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9, 64]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5]))) for _ in range(n)]
+    sm = [list(m) for m in msgs]
+    sm[2] = sm[2][:-1]                                     # Err: wrong message count
+    sm[5][1] = c.r + 9                                     # malformed scalar
+    sigs, st = eng.core_sign_batch(sm, headers)
+    octs, st2 = eng.sign_octets_batch(sm, headers)
+    assert list(st) == list(st2) and st[2] < 0 and st[5] == -40 and list(st).count(1) == n - 2
+    for i in range(n):
+        want = api.signature_to_octets(curve, sigs[i], lib_path) if st[i] == 1 else b""
+        assert octs[i] == want, (curve, i, "sign octets")
+    good, st = eng.core_sign_batch(msgs, headers)
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    disclosed[0] = list(range(L))                          # no commitments at all
+    disclosed[1] = []                                      # every message undisclosed
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    ps = [Signature(s_.a, s_.e) for s_ in good]
+    ps[3] = Signature(good[3].a, c.r + 1)                  # malformed e
+    di = [list(d) for d in disclosed]
+    di[4] = di[4] + [L + 1]; rn4 = rnds[4]                 # InvalidDisclosedIndex (the scalar count is not looked at then)
+    proofs, st = eng.core_proof_gen_batch(ps, msgs, di, rnds, headers, phs)
+    pocts, st2 = eng.proof_gen_octets_batch(ps, msgs, di, rnds, headers, phs)
+    assert list(st) == list(st2) and st[3] == -40 and st[4] == -3 and list(st).count(1) == n - 2, list(st)
+    for i in range(n):
+        want = api.proof_to_octets(curve, proofs[i], lib_path) if st[i] == 1 else b""
+        assert pocts[i] == want, (curve, i, "proof octets", len(pocts[i]), len(want))
+    # round trip through the wire-form verifiers
+    ok = [i for i in range(n) if st[i] == 1]
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in ok]
+    assert list(eng.proof_verify_octets_batch([pocts[i] for i in ok], dm, [disclosed[i] for i in ok], [headers[i] for i in ok],
+                                              [phs[i] for i in ok])) == [1] * len(ok)
+    so, st = eng.sign_octets_batch(msgs, headers)
+    assert list(eng.verify_octets_batch(so, msgs, headers)) == [1] * n
+    # two submits in flight, the empty batch
+    jobs = [eng.proof_gen_octets_submit(ps, msgs, di, rnds, headers, phs), eng.sign_octets_submit(sm, headers)]
+    for j in jobs:
+        j.wait()
+    assert jobs[0].output()[0] == pocts and jobs[1].output()[0] == octs
+    for j in jobs:
+        j.free()
+    assert eng.sign_octets_batch([])[0] == [] and eng.proof_gen_octets_batch([], [], [], [])[0] == []
+    eng.close()
 

@@ -123,3 +123,9 @@ def test_fixed_base_tree(curve, window_bits):
         window_bits = 16
     pc.check_fixed_base_tree(curve, None, window_bits=window_bits, n_pv=70)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_octets_out(curve):
+    pc.check_octets_out(curve, None)
+    pc.check_octets_out(curve, None, n=300, L=9, seed=96)
+

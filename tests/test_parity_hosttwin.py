@@ -109,3 +109,8 @@ def test_fixed_base_tree(twin, curve):
     pc.check_fixed_base_tree(curve, twin)
     pc.check_fixed_base_tree(curve, twin, L=6, seed=92, window_bits=7, n_pv=6)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_octets_out(twin, curve):
+    pc.check_octets_out(curve, twin)
+
