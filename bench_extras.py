@@ -203,6 +203,22 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         return packed_submit(eng.lib.bbs_core_proof_gen_submit, "bbs_core_proof_gen_submit", *pgargs, u8(pf_out[k]), u8(cm_out[k]), u64(cmo_out[k]))
     bls["proof_gen_host_inclusive"] = host_loop(pg_submit, all_true)
     assert all(int(c_[n]) == n * (L - R) for c_ in cmo_out[:8])
+    # ... and to the wire: signature / proof octet strings compressed on the device
+    so_out = [np.zeros(n * (eng.fpb + 32), dtype=np.uint8) for _ in range(9)]
+
+    def sign_oct_submit():
+        o = so_out[turn[0] % 9]; turn[0] += 1
+        return packed_submit(eng.lib.bbs_sign_octets_submit, "bbs_sign_octets_submit", u8(ms_v), u64(mo_v), u8(hb_v), u64(ho_v), u8(o))
+    bls["sign_to_octets_host_inclusive"] = host_loop(sign_oct_submit, all_true)
+    po_len = 3 * eng.fpb + 32 * (4 + L - R)
+    po_out = [np.zeros(n * (3 * eng.fpb + 32 * (4 + L)), dtype=np.uint8) for _ in range(9)]
+    poo_out = [np.zeros(n + 1, dtype=np.uint64) for _ in range(9)]
+
+    def pg_oct_submit():
+        k = turn[0] % 9; turn[0] += 1
+        return packed_submit(eng.lib.bbs_proof_gen_octets_submit, "bbs_proof_gen_octets_submit", *pgargs, u8(po_out[k]), u64(poo_out[k]))
+    bls["proof_gen_to_octets_host_inclusive"] = host_loop(pg_oct_submit, all_true)
+    assert all(int(o_[n]) == n * po_len for o_ in poo_out[:8])
 
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
     sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)
