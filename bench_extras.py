@@ -150,7 +150,9 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
             j.wait()
             check(j)
             j.free()
-        for _ in range(depth):
+        for _ in range(4 * depth):                     # warm: pools (page-locked and device buffers, streams) reach their size
+            if len(pend) >= depth:
+                retire()
             pend.append(submit())
         while pend:
             retire()
