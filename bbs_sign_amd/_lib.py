@@ -50,6 +50,10 @@ SIGNATURES = {
     "bbs_proof_verify_octets_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
                                             c_i8p, ctypes.POINTER(vp)]),
     "bbs_proof_verify_octets_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
+    "bbs_proof_verify_wire_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                          c_i8p, ctypes.POINTER(vp)]),
+    "bbs_proof_verify_wire_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                         c_i8p]),
     "bbs_core_verify_upload": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
     "bbs_core_verify_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_core_verify_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),

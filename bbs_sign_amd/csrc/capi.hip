@@ -329,8 +329,8 @@ int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
                                  const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                  const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr),
-                    pv_upload<BnCurve>(AS_BN(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr));
+    return DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr, nullptr, nullptr),
+                    pv_upload<BnCurve>(AS_BN(ctx), n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, job, nullptr, nullptr, nullptr, nullptr));
 }
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                            const uint8_t* h, const uint64_t* ho, bbs_job** job) {
@@ -462,8 +462,8 @@ int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, c
                                    bbs_job** job_out) {
     if (!ctx || !status || !job_out || (n && !oct_off)) return BBS_E_ARG;
     bbs_job* job = nullptr;
-    int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off),
-                      pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off));
+    int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr),
+                      pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr));
     if (rc) return rc;
     rc = job->run();
     if (!rc) rc = job->enqueue_status_fetch();
@@ -471,6 +471,41 @@ int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, c
     job->deliver_to = status;
     *job_out = job;
     return BBS_OK;
+}
+// the public proof_verify of the reference for a fixed number of messages, in one call: proof octets AND the disclosed
+// messages as raw bytes (msg_to_scalars on the device in front of the ingest stage)
+int bbs_proof_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
+                                 const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                 const uint64_t* di, const uint64_t* dio,
+                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
+                                 bbs_job** job_out) {
+    if (!ctx || !status || !job_out || (n && (!oct_off || !msg_item_off))) return BBS_E_ARG;
+    static const uint64_t zero_off[1] = {0};
+    if (!msg_byte_off) {                                  // no disclosed message in the whole batch
+        if (n && msg_item_off[n] != msg_item_off[0]) return BBS_E_ARG;
+        msg_byte_off = zero_off;
+    }
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off),
+                      pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off));
+    if (rc) return rc;
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_proof_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
+                                const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                const uint64_t* di, const uint64_t* dio,
+                                const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_proof_verify_wire_submit(ctx, n, oct, oct_off, msg_bytes, msg_byte_off, msg_item_off, di, dio, h, ho, ph, pho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
 }
 int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
                                   const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,

@@ -160,6 +160,30 @@ struct PvOctArgs {
     uint32_t *pts, *sc, *slots, *dmask, *didx, *rcount, *hdr_off, *hdr_len, *ph_off, *ph_len;
     int8_t* pcode;                        // [3 n] per point: G1 decode code
     int8_t* status0;
+    int msg_dst_too_long;                 // raw-message form: api_id || "MAP_MSG_TO_SCALAR_AS_HASH_" exceeds 255 bytes
+};
+// msg_to_scalars (interface_utilities.rs:76-88) for the raw-message form of the wire path: lane per disclosed message,
+// scalar t = hash_to_scalar(message t, api_id || "MAP_MSG_TO_SCALAR_AS_HASH_"), canonical words [t][8]
+struct MsgHashArgs {
+    size_t nm;
+    const uint64_t* off;                  // nm + 1 byte offsets, rebased to 0
+    const uint8_t* bytes;
+    uint8_t dst[256];
+    uint32_t dst_len;
+    uint32_t* out;
+};
+template <class C>
+struct MsgHash {
+    static __host__ __device__ void run(const MsgHashArgs& a, size_t t) {
+        Sha256 s;
+        xmd48_begin(s);
+        sha256_bytes(s, a.bytes + a.off[t], (uint32_t)(a.off[t + 1] - a.off[t]));
+        uint32_t okm[12];
+        xmd48_finish(s, a.dst, a.dst_len, okm);
+        const Fr<C> r = fe_to_canonical<typename C::FrP>(fr_from_okm<C>(okm));
+#pragma unroll
+        for (int k = 0; k < 8; k++) a.out[t * 8 + k] = r.v[k];
+    }
 };
 template <class C>
 BBS_HD bool pv_oct_shape(const PvOctArgs<C>& a, size_t i, size_t& u) {
@@ -220,6 +244,9 @@ struct PvOctIngest {
         if (verdict != ST_PENDING) { a.status0[i] = verdict; return; }
         // from here: proof_verify_init's checks (src/proof_verify.rs:139-150) exactly as PvIngest
         const uint64_t r = a.di_off[i + 1] - a.di_off[i], rm = a.dm_off[i + 1] - a.dm_off[i];
+        // raw-message form: the reference hashes the disclosed messages before anything else (proof_verify.rs:43-47), and
+        // expand_message panics on a DST longer than 255 bytes (utilities_helper.rs:46-52)
+        if (a.msg_dst_too_long && rm > 0) { a.status0[i] = -23; return; }
         const uint64_t l = (uint64_t)u + r;
         const uint64_t* idx = a.di + a.di_off[i];
         bool bad = false;

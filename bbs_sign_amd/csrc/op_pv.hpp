@@ -12,6 +12,7 @@ struct PvJob : JobBase<C> {
     PvFinishArgs fin{};
     PvIngestArgs<C> ingest{};
     PvOctArgs<C> oct{};               // wire form only
+    MsgHashArgs mh{};                 // wire form with raw messages only
     BvState<C> bv{};                  // batch verification only
 };
 
@@ -22,8 +23,13 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
                      const uint64_t* commit_off, const uint8_t* dmsgs, const uint64_t* dmsg_off,
                      const uint64_t* didx, const uint64_t* didx_off, const uint8_t* headers,
                      const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off, bbs_job** out,
-                     const uint8_t* octets, const uint64_t* oct_off) {
+                     const uint8_t* octets, const uint64_t* oct_off, const uint8_t* msg_bytes, const uint64_t* msg_byte_off) {
+    // msg_byte_off != nullptr (wire form only): the disclosed messages arrive as RAW BYTES -- message t of the batch is
+    // msg_bytes[msg_byte_off[t] .. msg_byte_off[t + 1]), dmsg_off counts messages per item as before, dmsgs is ignored --
+    // and are mapped to scalars on the device (msg_to_scalars, interface_utilities.rs:76-88)
     const bool wire = oct_off != nullptr;
+    const bool raw = msg_byte_off != nullptr;
+    if (raw && !wire) return BBS_E_ARG;
     constexpr int N = C::FpP::N;        // internal limbs
     constexpr int NC = C::FpP::NC;      // canonical 32-bit words
     constexpr int FPB = 4 * NC;
@@ -41,9 +47,15 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     // first ragged section: the commitments (core form) or the proof octet strings (wire form)
     RaggedIn cm{wire ? oct_off : commit_off, wire ? octets : commitments, wire ? (size_t)1 : (size_t)32}, dm{dmsg_off, dmsgs, 32},
              di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8}, hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
+    dm.offsets_only = raw;
     if (!cm.measure(n) || !dm.measure(n) || !di.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
-    if (int rc0 = stage_image(job.get(), n, wire ? nullptr : proofs_fixed, wire ? 0 : rec, {&cm, &dm, &di, &hb, &pb})) return rc0;
+    const size_t nm = raw ? (size_t)dm.total : 0;                   // disclosed messages of the whole batch
+    RaggedIn mb{raw ? msg_byte_off : nullptr, msg_bytes, 1};
+    if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
+    // (the message section is ragged over MESSAGES, not items: stage_image places and fills it with nm as its count)
+    if (int rc0 = stage_image(job.get(), n, wire ? nullptr : proofs_fixed, wire ? 0 : rec, {&cm, &dm, &di, &hb, &pb}, raw ? &mb : nullptr, nm)) return rc0;
+
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
     auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };
@@ -101,6 +113,24 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         oa.oct = dimg + cm.at_data; oa.oct_off = d64(cm.at_off);
         oa.dm_off = d64(dm.at_off); oa.di_off = d64(di.at_off); oa.hdr_off64 = d64(hb.at_off); oa.ph_off64 = d64(pb.at_off);
         oa.dm = d32(dm.at_data); oa.di = d64(di.at_data);
+        oa.msg_dst_too_long = 0;
+        if (raw) {
+            static const char SUFFIX[] = "MAP_MSG_TO_SCALAR_AS_HASH_";
+            const size_t dl = ctx->api_id.size() + sizeof(SUFFIX) - 1;
+            uint32_t* dmsc = job->template scratch<uint32_t>(std::max<size_t>(nm, 1) * 8, rc);
+            if (rc) return rc;
+            oa.dm = dmsc;
+            if (dl > 255) oa.msg_dst_too_long = 1;
+            else if (nm) {
+                MsgHashArgs& ma = job->mh;
+                std::memset(&ma, 0, sizeof(ma));
+                ma.nm = nm; ma.off = d64(mb.at_off); ma.bytes = dimg + mb.at_data; ma.out = dmsc;
+                std::memcpy(ma.dst, ctx->api_id.data(), ctx->api_id.size());
+                std::memcpy(ma.dst + ctx->api_id.size(), SUFFIX, sizeof(SUFFIX) - 1);
+                ma.dst_len = (uint32_t)dl;
+                if (rt::launch<MsgHash<C>>(job->stream(), ma, nm)) return BBS_E_HIP;
+            }
+        }
         oa.pts = pts; oa.sc = sc; oa.slots = slots; oa.dmask = dmask; oa.didx = didx_s; oa.rcount = rcount;
         oa.hdr_off = offs; oa.hdr_len = offs + nn; oa.ph_off = offs + 2 * nn; oa.ph_len = offs + 3 * nn;
         oa.pcode = job->template scratch<int8_t>(3 * nn, rc);

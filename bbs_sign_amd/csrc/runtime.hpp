@@ -723,6 +723,7 @@ struct RaggedIn {
     size_t elem;              // bytes per element
     uint64_t total = 0;       // elements
     size_t at_off = 0, at_data = 0;
+    bool offsets_only = false; // the elements themselves are produced on the device (no data behind the offsets)
     // false: offsets decrease, or data missing
     bool measure(size_t n) {
         total = 0;
@@ -730,31 +731,34 @@ struct RaggedIn {
         for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
         total = off[n] - off[0];
         if (total > ((uint64_t)1 << 36)) return false;       // no batch holds 2^36 elements: garbage offsets, and total * elem must not wrap
-        return total == 0 || data != nullptr;
+        return total == 0 || data != nullptr || offsets_only;
     }
     void place(size_t& cur, size_t n) {
         at_off = cur; cur += ((n + 1) * 8 + 15) & ~(size_t)15;
-        at_data = cur; cur += ((size_t)total * elem + 4 + 15) & ~(size_t)15;
+        at_data = cur; if (!offsets_only) cur += ((size_t)total * elem + 4 + 15) & ~(size_t)15;
     }
     void fill(uint8_t* img, size_t n) const {
         uint64_t* o = reinterpret_cast<uint64_t*>(img + at_off);
         if (!off) { std::memset(o, 0, (n + 1) * 8); return; }
         const uint64_t b = off[0];
         for (size_t i = 0; i <= n; i++) o[i] = off[i] - b;
-        if (total) std::memcpy(img + at_data, data + b * elem, (size_t)total * elem);
+        if (total && !offsets_only) std::memcpy(img + at_data, data + b * elem, (size_t)total * elem);
     }
 };
 
 // Fixed-size records at the start of the image + the ragged sections behind them; allocates the job's page-locked and
 // device buffers, fills the host image and enqueues the ONE host-to-device copy on the job's stream.
 template <class J>
-inline int stage_image(J* job, size_t n, const uint8_t* records, size_t rec_bytes, std::initializer_list<RaggedIn*> sections) {
+inline int stage_image(J* job, size_t n, const uint8_t* records, size_t rec_bytes, std::initializer_list<RaggedIn*> sections,
+                       RaggedIn* extra = nullptr, size_t extra_count = 0) {      // extra: a section ragged over extra_count entries
     size_t cur = (n * rec_bytes + 15) & ~(size_t)15;
     for (RaggedIn* s : sections) s->place(cur, n);
+    if (extra) extra->place(cur, extra_count);
     if (job->h_raw.alloc(cur) || job->d_raw.alloc(cur)) return BBS_E_NOMEM;
     uint8_t* img = job->h_raw.template as<uint8_t>();
     if (n && rec_bytes) std::memcpy(img, records, n * rec_bytes);
     for (RaggedIn* s : sections) s->fill(img, n);
+    if (extra) extra->fill(img, extra_count);
     return rt::h2d_async(job->d_raw.p, img, cur, job->stream()) ? BBS_E_HIP : BBS_OK;
 }
 

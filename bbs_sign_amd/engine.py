@@ -307,6 +307,40 @@ class Engine:
         self._chk(self.lib.bbs_proof_verify_octets_batch(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)), "bbs_proof_verify_octets_batch")
         return st[:n]
 
+    def _wire_inputs(self, octets, disclosed_raw, disclosed_idx, headers, phs):
+        """disclosed_raw[i]: the disclosed messages of item i as byte strings (hashed on the device)."""
+        n = len(octets)
+        ob, oo = _ragged_bytes(octets)
+        flat = [m for item in disclosed_raw for m in item]
+        mb, mbo = _ragged_bytes(flat)
+        mio = np.zeros(n + 1, dtype=np.uint64)
+        for i, item in enumerate(disclosed_raw):
+            mio[i + 1] = mio[i] + len(item)
+        di, dio = self._indexes(disclosed_idx)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        keep = (ob, oo, mb, mbo, mio, di, dio, hb, ho, pb, po)
+        args = (_u8(ob), _u64(oo), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio), _u8(hb), _u64(ho), _u8(pb), _u64(po))
+        return n, keep, args
+
+    def proof_verify_wire_batch(self, octets, disclosed_raw, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+        """bbs_proof_verify_wire_batch: proof octets and raw disclosed messages in, statuses out (the reference's public
+        proof_verify for this context's number of messages)."""
+        n, keep, args = self._wire_inputs(octets, disclosed_raw, disclosed_idx, headers, phs)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        self._chk(self.lib.bbs_proof_verify_wire_batch(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)), "bbs_proof_verify_wire_batch")
+        return st[:n]
+
+    def proof_verify_wire_submit(self, octets, disclosed_raw, disclosed_idx, headers=None, phs=None) -> "Job":
+        n, keep, args = self._wire_inputs(octets, disclosed_raw, disclosed_idx, headers, phs)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        self._chk(self.lib.bbs_proof_verify_wire_submit(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)),
+                  "bbs_proof_verify_wire_submit")
+        job = Job(self, j, n)
+        job.result = st[:n]
+        return job
+
     def proof_verify_octets_submit_packed(self, n, args) -> "Job":
         st = np.full(max(n, 1), -128, dtype=np.int8)
         j = ctypes.c_void_p()

@@ -1,5 +1,6 @@
 """Untimed legs of bench.py (rank 0, N = 1): the other three operations of the path, the second curve, the opt-in
 modes, the window-width comparison on distinct data and the reference's own bench sweeps.  Nothing here feeds `value`."""
+import ctypes
 import time
 
 
@@ -139,6 +140,33 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     while pend:
         retire_o()
     bls["proof_verify_from_octets_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
+    # ... and with the disclosed messages as raw bytes too (msg_to_scalars on the device: the reference's public
+    # proof_verify in one call), the 32-byte messages of the workload
+    raw_msgs = [[pc.expand_message(b"bbs-bench-msg" + pc.i2osp(b, 8) + pc.i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32) for j in range(R)]
+                for b in range(n)]
+    nn_w, keep_w, args_w = eng._wire_inputs(octs, raw_msgs, disclosed, None, None)
+
+    def wire_submit():
+        st_ = np.full(n, -128, dtype=np.int8)
+        jh = ctypes.c_void_p()
+        eng._chk(eng.lib.bbs_proof_verify_wire_submit(eng.h, nn_w, *args_w, st_.ctypes.data_as(_l.c_i8p), ctypes.byref(jh)), "bbs_proof_verify_wire_submit")
+        j = Job(eng, jh, n)
+        j.result = st_
+        return j
+    for k in range(16):
+        if len(pend) >= 8:
+            retire_o()
+        pend.append(wire_submit())
+    while pend:
+        retire_o()
+    t1 = time.perf_counter()
+    for k in range(64):
+        if len(pend) >= 8:
+            retire_o()
+        pend.append(wire_submit())
+    while pend:
+        retire_o()
+    bls["proof_verify_wire_raw_messages_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
 
     # ---- the other three operations from HOST buffers through their submit forms, 8 batches in flight, results checked:
     # verify from signature records and from signature octets (decompression + subgroup check on the device), sign and

@@ -205,6 +205,23 @@ int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* proof_o
                                   const uint64_t* disclosed_idx, const uint64_t* didx_off,
                                   const uint8_t* headers, const uint64_t* hdr_off,
                                   const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
+/* The reference's PUBLIC proof_verify (src/proof_verify.rs:19-61) for contexts of a fixed number of messages, in one
+ * call: proof octet strings and the disclosed messages as RAW BYTES.  Message t of the batch is
+ * msg_bytes[msg_byte_off[t] .. msg_byte_off[t + 1]) (t counts the disclosed messages of all items in order);
+ * msg_item_off[i] .. msg_item_off[i + 1] are the messages of item i (n + 1 entries, in messages).  msg_to_scalars
+ * (interface_utilities.rs:76-88, dst = api_id || "MAP_MSG_TO_SCALAR_AS_HASH_") runs on the device in front of the checks;
+ * statuses as bbs_proof_verify_octets_* on the hashed messages (BBS_ST_PANIC_DST_TOO_LONG for an item with disclosed
+ * messages when that dst exceeds 255 bytes, as the reference's expand_message panics). */
+int bbs_proof_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                                 const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                 const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                 const uint8_t* headers, const uint64_t* hdr_off,
+                                 const uint8_t* ph, const uint64_t* ph_off, int8_t* status, bbs_job** job_out);
+int bbs_proof_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                                const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                const uint8_t* headers, const uint64_t* hdr_off,
+                                const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
 
 /* core_verify (src/verify.rs:53-93).  signatures: n records  A (G1 affine) || e (scalar). */
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* signatures,

@@ -1470,3 +1470,90 @@ def check_octets_out(curve, lib_path=None, n=12, L=5, seed=95):
     assert eng.sign_octets_batch([])[0] == [] and eng.proof_gen_octets_batch([], [], [], [])[0] == []
     eng.close()
 
+
+def check_proof_verify_wire(curve, lib_path=None, n=12, L=5, seed=97):
+    """bbs_proof_verify_wire_*: proof octet strings and the disclosed messages as RAW BYTES in, statuses out -- the
+    reference's public proof_verify (src/proof_verify.rs:19-61) in one call.  Against (a) the composition it replaces,
+    bbs_hash_to_scalar_batch -> bbs_proof_verify_octets_batch, item by item, (b) the oracle's public proof_verify where
+    the context's generators are the suite's (BLS12-381), (c) the reference's proof vector with its raw message."""
+    from bbs_sign_amd import api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    raw = [[bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 32, 55, 56, 64, 200]))) for _ in range(L)] for _ in range(n)]
+    flat = eng.hash_to_scalar_batch([m for item in raw for m in item], api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
+    msgs = [flat[i * L:(i + 1) * L] for i in range(n)]
+    assert msgs[0] == bbs.msg_to_scalars(suite, raw[0], api_id)
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 70]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    disclosed[0] = []                                      # nothing disclosed: no message to hash
+    disclosed[1] = list(range(L))
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n
+    octs = [bytearray(api.proof_to_octets(curve, p_, lib_path)) for p_ in proofs]
+    idx = [list(d) for d in disclosed]
+    draw = [[raw[i][j] for j in disclosed[i]] for i in range(n)]
+    if draw[2]:
+        draw[2][0] = draw[2][0] + b"!"                     # 2: a disclosed message altered -> Ok(false)
+    else:
+        octs[2][-1] ^= 1
+    octs[3] = octs[3][:-1]                                 # 3: malformed string
+    idx[4] = idx[4] + [L + 2]; draw[4] = draw[4] + [b"extra"]          # 4: index out of range
+    draw[5] = draw[5] + [b"one too many"]                  # 5: more messages than indexes
+    octs[6][3 * c.fp_bytes + 31] ^= 1                      # 6: e^ altered
+    octs = [bytes(o) for o in octs]
+    got = [int(x) for x in eng.proof_verify_wire_batch(octs, draw, idx, headers, phs)]
+    # (a) the composition
+    dsc = eng.hash_to_scalar_batch([m for item in draw for m in item], api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
+    dm, k = [], 0
+    for item in draw:
+        dm.append(dsc[k:k + len(item)]); k += len(item)
+    want = [int(x) for x in eng.proof_verify_octets_batch(octs, dm, idx, headers, phs)]
+    assert got == want, (curve, got, want)
+    assert got[0] == 1 and got[1] == 1 and got[2] == 0 and got[3] == -42 and got[5] == -6 and got[6] == 0 and got[7:] == [1] * (n - 7), got
+    assert got[4] in (-3, -1), got
+    # (b) the oracle's public function (BLS12-381: the context's generators are create_generators(L + 1, api_id))
+    if curve == "bls12_381":
+        for i in (0, 1, 2, 7):
+            p = proofs[i]
+            op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
+            if i == 2 and not disclosed[2]:
+                continue
+            assert int(bbs.proof_verify(suite, pk, op, headers[i], phs[i], draw[i], idx[i])) == got[i], i
+    # submit form, two in flight; the empty batch
+    jobs = [eng.proof_verify_wire_submit(octs, draw, idx, headers, phs) for _ in range(2)]
+    for j in jobs:
+        j.wait()
+        assert [int(x) for x in j.result] == want
+        j.free()
+    assert list(eng.proof_verify_wire_batch([], [], [])) == []
+    eng.close()
+    # a DST longer than 255 bytes: the reference's expand_message panics inside msg_to_scalars for items with messages
+    long_id = b"x" * 240
+    e3 = make_engine(curve, gens, long_id, lib_path, sk=sk)
+    got3 = [int(x) for x in e3.proof_verify_wire_batch(octs[:2], draw[:2], idx[:2], headers[:2], phs[:2])]
+    assert got3[1] == -23 and got3[0] != -23, got3          # item 0 discloses nothing: nothing is hashed for it
+    e3.close()
+    if curve == "bls12_381":
+        S = bbs.BLS_SUITE
+        H = bytes.fromhex
+        kat = H("94916292a7a6bade28456c601d3af33fcf39278d6594b467e128a3f83686a104ef2b2fcf72df0215eeaf69262ffe8194a19fab31a82ddbe06908985abc4c9825788b8a1610942d12b7f5debbea8985296361206dbace7af0cc834c80f33e0aadaeea5597befbb651827b5eed5a66f1a959bb46cfd5ca1a817a14475960f69b32c54db7587b5ee3ab665fbd37b506830a49f21d592f5e634f47cee05a025a2f8f94e73a6c15f02301d1178a92873b6e8634bafe4983c3e15a663d64080678dbf29417519b78af042be2b3e1c4d08b8d520ffab008cbaaca5671a15b22c239b38e940cfeaa5e72104576a9ec4a6fad78c532381aeaa6fb56409cef56ee5c140d455feeb04426193c57086c9b6d397d9418")
+        ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+        key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+        key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+        sk2 = bbs.key_gen(S, ikm, key_info, key_dst)
+        e2 = make_engine("bls12_381", bbs.create_generators(S, 2, S.api_id), S.api_id, lib_path, sk=sk2)
+        m1 = H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")
+        hdr, ph = H("11223344556677889900aabbccddeeff"), H("bed231d880675ed101ead304512e043ade9958dd0241ea70b4b3957fba941501")
+        assert list(e2.proof_verify_wire_batch([kat], [[m1]], [[0]], [hdr], [ph])) == [1]      # test_vector.rs:199-260, raw message
+        assert list(e2.proof_verify_wire_batch([kat], [[m1 + b"x"]], [[0]], [hdr], [ph])) == [0]
+        e2.close()
+

@@ -129,3 +129,9 @@ def test_octets_out(curve):
     pc.check_octets_out(curve, None)
     pc.check_octets_out(curve, None, n=300, L=9, seed=96)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_verify_wire(curve):
+    pc.check_proof_verify_wire(curve, None)
+    pc.check_proof_verify_wire(curve, None, n=200, L=8, seed=98)
+

@@ -114,3 +114,8 @@ def test_fixed_base_tree(twin, curve):
 def test_octets_out(twin, curve):
     pc.check_octets_out(curve, twin)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_verify_wire(twin, curve):
+    pc.check_proof_verify_wire(curve, twin)
+
