@@ -335,11 +335,11 @@ int bbs_core_proof_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
 int bbs_core_verify_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                            const uint8_t* h, const uint64_t* ho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, h, ho, job, nullptr), vf_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, h, ho, job, nullptr));
+    return DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, h, ho, job, nullptr, nullptr, nullptr), vf_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, h, ho, job, nullptr, nullptr, nullptr));
 }
 int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, sg_upload<BlsCurve>(AS_BLS(ctx), n, m, mo, h, ho, job), sg_upload<BnCurve>(AS_BN(ctx), n, m, mo, h, ho, job));
+    return DISPATCH(ctx, sg_upload<BlsCurve>(AS_BLS(ctx), n, m, mo, h, ho, job, nullptr, nullptr), sg_upload<BnCurve>(AS_BN(ctx), n, m, mo, h, ho, job, nullptr, nullptr));
 }
 int bbs_core_proof_gen_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                               const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
@@ -536,8 +536,8 @@ int bbs_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, 
                              const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
     if (!ctx || !status || !job_out || (n && !sig_octets)) return BBS_E_ARG;
     bbs_job* job = nullptr;
-    int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets),
-                      vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets));
+    int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr),
+                      vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr));
     if (rc) return rc;
     rc = job->run();
     if (!rc) rc = job->enqueue_status_fetch();
@@ -550,6 +550,60 @@ int bbs_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, c
                             const uint8_t* h, const uint64_t* ho, int8_t* status) {
     bbs_job* job = nullptr;
     int rc = bbs_verify_octets_submit(ctx, n, sig_octets, m, mo, h, ho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
+// the reference's PUBLIC verify / sign for a context's number of messages, in one call: raw messages in (msg_to_scalars on
+// the device), signatures as octet strings in (verify) / out (sign)
+static const uint64_t BBS_ZERO_OFF[1] = {0};
+static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out);
+int bbs_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                           const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
+    if (!ctx || !status || !job_out || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
+    if (!msg_byte_off) {
+        if (n && msg_item_off[n] != msg_item_off[0]) return BBS_E_ARG;
+        msg_byte_off = BBS_ZERO_OFF;
+    }
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off),
+                      vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off));
+    if (rc) return rc;
+    rc = job->run();
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    *job_out = job;
+    return BBS_OK;
+}
+int bbs_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                          const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_verify_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, h, ho, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
+int bbs_sign_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                         const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status, bbs_job** job_out) {
+    if (!ctx || !status || !job_out || (n && (!sig_octets_out || !msg_item_off))) return BBS_E_ARG;
+    if (!msg_byte_off) {
+        if (n && msg_item_off[n] != msg_item_off[0]) return BBS_E_ARG;
+        msg_byte_off = BBS_ZERO_OFF;
+    }
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, sg_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, msg_item_off, h, ho, &job, msg_bytes, msg_byte_off),
+                      sg_upload<BnCurve>(AS_BN(ctx), n, nullptr, msg_item_off, h, ho, &job, msg_bytes, msg_byte_off));
+    if (rc) return rc;
+    if ((rc = job->set_octet_form())) { delete job; return rc; }
+    return submit_with_results(job, status, sig_octets_out, nullptr, nullptr, job_out);
+}
+int bbs_sign_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                        const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_sign_wire_submit(ctx, n, msg_bytes, msg_byte_off, msg_item_off, h, ho, sig_octets_out, status, &job);
     if (rc) return rc;
     rc = job->wait();
     delete job;

@@ -115,21 +115,9 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         oa.dm = d32(dm.at_data); oa.di = d64(di.at_data);
         oa.msg_dst_too_long = 0;
         if (raw) {
-            static const char SUFFIX[] = "MAP_MSG_TO_SCALAR_AS_HASH_";
-            const size_t dl = ctx->api_id.size() + sizeof(SUFFIX) - 1;
-            uint32_t* dmsc = job->template scratch<uint32_t>(std::max<size_t>(nm, 1) * 8, rc);
+            uint32_t* dmsc = hash_raw_messages<C>(job.get(), ctx, mb, nm, job->mh, oa.msg_dst_too_long, rc);
             if (rc) return rc;
             oa.dm = dmsc;
-            if (dl > 255) oa.msg_dst_too_long = 1;
-            else if (nm) {
-                MsgHashArgs& ma = job->mh;
-                std::memset(&ma, 0, sizeof(ma));
-                ma.nm = nm; ma.off = d64(mb.at_off); ma.bytes = dimg + mb.at_data; ma.out = dmsc;
-                std::memcpy(ma.dst, ctx->api_id.data(), ctx->api_id.size());
-                std::memcpy(ma.dst + ctx->api_id.size(), SUFFIX, sizeof(SUFFIX) - 1);
-                ma.dst_len = (uint32_t)dl;
-                if (rt::launch<MsgHash<C>>(job->stream(), ma, nm)) return BBS_E_HIP;
-            }
         }
         oa.pts = pts; oa.sc = sc; oa.slots = slots; oa.dmask = dmask; oa.didx = didx_s; oa.rcount = rcount;
         oa.hdr_off = offs; oa.hdr_len = offs + nn; oa.ph_off = offs + 2 * nn; oa.ph_len = offs + 3 * nn;

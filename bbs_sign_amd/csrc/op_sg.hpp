@@ -9,6 +9,7 @@ struct SgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     SgArgs<C> a{};
     VfIngestArgs<C> ingest{};
+    MsgHashArgs mh{};                 // raw-message form only
     // the records come off the device in the caller's layout (stage SgEmit): delivery is one copy
     size_t rec_bytes() const { return a.oct_form ? (size_t)(4 * C::FpP::NC + 32) : (size_t)(8 * C::FpP::NC + 32); }
     int set_octet_form() override { a.oct_form = 1; return BBS_OK; }
@@ -38,7 +39,8 @@ struct SgJob : JobBase<C> {
 
 template <class C>
 int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* headers,
-                     const uint64_t* hdr_off, bbs_job** out) {
+                     const uint64_t* hdr_off, bbs_job** out, const uint8_t* msg_bytes, const uint64_t* msg_byte_off) {
+    // msg_byte_off != nullptr: raw messages, hashed to scalars on the device (see vf_upload)
     constexpr int N = C::FpP::N;
     if (!ctx->gens_set || !ctx->sk_set) return BBS_E_STATE;
     if (!out || (n && !msg_off)) return BBS_E_ARG;
@@ -48,9 +50,14 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     job->n = n;
     // staging image + device-side checks (stage VfIngest without a signature record: sign.rs:77-79's length check,
     // range checks of the messages, SoA transposition)
+    const bool raw = msg_byte_off != nullptr;
     RaggedIn ms{msg_off, msgs, 32}, hb{hdr_off, headers, 1};
+    ms.offsets_only = raw;
     if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
-    if (int rc0 = stage_image(job.get(), n, nullptr, 0, {&ms, &hb})) return rc0;
+    const size_t nm = raw ? (size_t)ms.total : 0;
+    RaggedIn mb{raw ? msg_byte_off : nullptr, msg_bytes, 1};
+    if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
+    if (int rc0 = stage_image(job.get(), n, nullptr, 0, {&ms, &hb}, raw ? &mb : nullptr, nm)) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     int rc = BBS_OK;
     const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
@@ -73,9 +80,13 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     a.status = job->d_status.template as<int8_t>();
     VfIngestArgs<C>& ia = job->ingest;
     ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 0;
-    ia.rec = nullptr; ia.oct = nullptr; ia.pcode = nullptr;
+    ia.rec = nullptr; ia.oct = nullptr; ia.pcode = nullptr; ia.msg_dst_too_long = 0;
     ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
     ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
+    if (raw) {
+        ia.m = hash_raw_messages<C>(job.get(), ctx, mb, nm, job->mh, ia.msg_dst_too_long, rc);
+        if (rc) return rc;
+    }
     ia.sig_a = nullptr; ia.sig_e = nullptr; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;
     ia.status0 = job->d_status0.template as<int8_t>();
     if (rt::launch<VfIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;

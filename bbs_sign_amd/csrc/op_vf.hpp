@@ -11,12 +11,16 @@ struct VfJob : JobBase<C> {
     PairArgs<C> pa{};
     VfIngestArgs<C> ingest{};
     VfOctArgs<C> oct{};               // wire form only
+    MsgHashArgs mh{};                 // raw-message form only
     BvState<C> bv{};                  // batch verification only
 };
 
 template <class C>
 int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, const uint64_t* msg_off,
-                     const uint8_t* headers, const uint64_t* hdr_off, bbs_job** out, const uint8_t* octets) {
+                     const uint8_t* headers, const uint64_t* hdr_off, bbs_job** out, const uint8_t* octets,
+                     const uint8_t* msg_bytes, const uint64_t* msg_byte_off) {
+    // msg_byte_off != nullptr: the messages arrive as RAW BYTES (message t of the batch = msg_bytes[msg_byte_off[t] ..
+    // msg_byte_off[t + 1]), msg_off counts messages per item, msgs is ignored) and are hashed to scalars on the device
     // octets != nullptr: the wire form -- n strings compress(A) || e instead of the records `sigs`
     constexpr int N = C::FpP::N;
     constexpr int NC = C::FpP::NC;
@@ -32,9 +36,14 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     job->n = n;
     // the batch as one staging image, one asynchronous copy; checks, range checks and the SoA transposition on the
     // device (stage VfIngest), as for proof_verify
+    const bool raw = msg_byte_off != nullptr;
     RaggedIn ms{msg_off, msgs, 32}, hb{hdr_off, headers, 1};
+    ms.offsets_only = raw;
     if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
-    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &hb})) return rc0;
+    const size_t nm = raw ? (size_t)ms.total : 0;
+    RaggedIn mb{raw ? msg_byte_off : nullptr, msg_bytes, 1};
+    if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
+    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &hb}, raw ? &mb : nullptr, nm)) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     int rc = BBS_OK;
     const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
@@ -59,7 +68,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     VfIngestArgs<C>& ia = job->ingest;
     ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0; ia.has_sig = 1;
     ia.rec = wire ? nullptr : reinterpret_cast<const uint32_t*>(dimg);
-    ia.oct = nullptr; ia.pcode = nullptr;
+    ia.oct = nullptr; ia.pcode = nullptr; ia.msg_dst_too_long = 0;
     if (wire) {
         int8_t* pcode = job->template scratch<int8_t>(nn, rc);
         if (rc) return rc;
@@ -70,6 +79,10 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     }
     ia.m_off = reinterpret_cast<const uint64_t*>(dimg + ms.at_off); ia.hdr_off64 = reinterpret_cast<const uint64_t*>(dimg + hb.at_off);
     ia.m = reinterpret_cast<const uint32_t*>(dimg + ms.at_data);
+    if (raw) {
+        ia.m = hash_raw_messages<C>(job.get(), ctx, mb, nm, job->mh, ia.msg_dst_too_long, rc);
+        if (rc) return rc;
+    }
     ia.sig_a = sig_a; ia.sig_e = sig_e; ia.msgs = smsgs; ia.hdr_off = offs; ia.hdr_len = offs + nn;
     ia.status0 = job->d_status0.template as<int8_t>();
     if (rt::launch<VfIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;

@@ -762,6 +762,27 @@ inline int stage_image(J* job, size_t n, const uint8_t* records, size_t rec_byte
     return rt::h2d_async(job->d_raw.p, img, cur, job->stream()) ? BBS_E_HIP : BBS_OK;
 }
 
+// msg_to_scalars on the device (codec_dev.hpp MsgHash): the nm raw messages of a batch, placed in the staging image as
+// section `mb`, become nm canonical scalars [message][8 words] -- the array the ingest stages read messages from.
+// dst_too_long = 1 (and no launch): api_id || "MAP_MSG_TO_SCALAR_AS_HASH_" exceeds 255 bytes, the reference panics.
+template <class C, class J>
+inline uint32_t* hash_raw_messages(J* job, Ctx<C>* ctx, const RaggedIn& mb, size_t nm, MsgHashArgs& ma, int& dst_too_long, int& rc) {
+    static const char SUFFIX[] = "MAP_MSG_TO_SCALAR_AS_HASH_";
+    const size_t dl = ctx->api_id.size() + sizeof(SUFFIX) - 1;
+    uint32_t* out = job->template scratch<uint32_t>(std::max<size_t>(nm, 1) * 8, rc);
+    if (rc) return nullptr;
+    dst_too_long = dl > 255 ? 1 : 0;
+    if (dst_too_long || !nm) return out;
+    const uint8_t* dimg = job->d_raw.template as<uint8_t>();
+    std::memset(&ma, 0, sizeof(ma));
+    ma.nm = nm; ma.off = reinterpret_cast<const uint64_t*>(dimg + mb.at_off); ma.bytes = dimg + mb.at_data; ma.out = out;
+    std::memcpy(ma.dst, ctx->api_id.data(), ctx->api_id.size());
+    std::memcpy(ma.dst + ctx->api_id.size(), SUFFIX, sizeof(SUFFIX) - 1);
+    ma.dst_len = (uint32_t)dl;
+    if (rt::launch<MsgHash<C>>(job->stream(), ma, nm)) rc = BBS_E_HIP;
+    return out;
+}
+
 // =============================================================================================
 // batch verification plumbing shared by proof_verify and verify (pippenger.hpp)
 // =============================================================================================

@@ -889,6 +889,7 @@ struct VfIngestArgs {
     // VfOctDecode (codec_dev.hpp), its verdict is pcode[i]
     const uint8_t* oct;
     const int8_t* pcode;
+    int msg_dst_too_long;                 // raw-message form: the reference's msg_to_scalars panics (DST > 255 bytes)
     const uint64_t *m_off, *hdr_off64;    // n + 1 entries each, rebased to 0
     const uint32_t* m;                    // messages, 8 words each
     uint32_t *sig_a, *sig_e, *msgs, *hdr_off, *hdr_len;
@@ -926,6 +927,8 @@ struct VfIngest {
             if (pre != ST_PENDING) { a.status0[i] = pre; return; }
         }
         const uint64_t l = a.m_off[i + 1] - a.m_off[i];
+        // raw-message form: msg_to_scalars runs first in the reference's public functions (sign.rs:45, verify.rs:32)
+        if (a.msg_dst_too_long && l > 0) { a.status0[i] = -23; return; }
         if (l != (uint64_t)a.L) { a.status0[i] = -1; return; }            // InvalidMessageAndGeneratorsLength
         if (a.dst_too_long) { a.status0[i] = -23; return; }
         bool ok = true;

@@ -307,6 +307,39 @@ class Engine:
         self._chk(self.lib.bbs_proof_verify_octets_batch(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)), "bbs_proof_verify_octets_batch")
         return st[:n]
 
+    @staticmethod
+    def _raw_msgs(items):
+        """items[i] = the messages of item i as byte strings -> (flat bytes, per-message byte offsets, per-item message offsets)."""
+        mb, mbo = _ragged_bytes([m for item in items for m in item])
+        mio = np.zeros(len(items) + 1, dtype=np.uint64)
+        for i, item in enumerate(items):
+            mio[i + 1] = mio[i] + len(item)
+        return mb, mbo, mio
+
+    def verify_wire_batch(self, sig_octets, messages_raw, headers=None) -> np.ndarray:
+        """bbs_verify_wire_batch: the reference's public verify -- signature octets and raw messages in, statuses out."""
+        n = len(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
+        mb, mbo, mio = self._raw_msgs(messages_raw)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        self._chk(self.lib.bbs_verify_wire_batch(self.h, n, _u8(ob), _u8(mb), _u64(mbo), _u64(mio), _u8(hb), _u64(ho),
+                                                 st.ctypes.data_as(_lib.c_i8p)), "bbs_verify_wire_batch")
+        st[bad] = -42
+        return st[:n]
+
+    def sign_wire_batch(self, messages_raw, headers=None):
+        """bbs_sign_wire_batch: the reference's public sign -- raw messages in, (signature octet strings, statuses) out."""
+        n = len(messages_raw)
+        mb, mbo, mio = self._raw_msgs(messages_raw)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        rec = self.fpb + 32
+        out = np.zeros(max(n, 1) * rec, dtype=np.uint8)
+        self._chk(self.lib.bbs_sign_wire_batch(self.h, n, _u8(mb), _u64(mbo), _u64(mio), _u8(hb), _u64(ho), _u8(out),
+                                               st.ctypes.data_as(_lib.c_i8p)), "bbs_sign_wire_batch")
+        return [out[i * rec:(i + 1) * rec].tobytes() if st[i] == 1 else b"" for i in range(n)], st[:n]
+
     def _wire_inputs(self, octets, disclosed_raw, disclosed_idx, headers, phs):
         """disclosed_raw[i]: the disclosed messages of item i as byte strings (hashed on the device)."""
         n = len(octets)

@@ -246,6 +246,23 @@ int bbs_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* signature_oct
                             const uint8_t* messages, const uint64_t* msg_off,
                             const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
 
+/* The reference's PUBLIC verify (src/verify.rs:18-50) for a context's number of messages in one call: signature octet
+ * strings and the messages as RAW BYTES (layout of the message arrays as bbs_proof_verify_wire_submit); msg_to_scalars on
+ * the device.  Statuses as bbs_verify_octets_* on the hashed messages. */
+int bbs_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                           const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                           const uint8_t* headers, const uint64_t* hdr_off, int8_t* status, bbs_job** job_out);
+int bbs_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                          const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                          const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
+/* The reference's PUBLIC sign (src/sign.rs:32-60): raw messages in, signature octet strings out (as bbs_sign_octets_*). */
+int bbs_sign_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                         const uint64_t* msg_item_off, const uint8_t* headers, const uint64_t* hdr_off,
+                         uint8_t* signature_octets_out, int8_t* status, bbs_job** job_out);
+int bbs_sign_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                        const uint64_t* msg_item_off, const uint8_t* headers, const uint64_t* hdr_off,
+                        uint8_t* signature_octets_out, int8_t* status);
+
 /* core_sign (src/sign.rs:63-133); needs bbs_ctx_set_secret_key.
  * signatures_out: n records A || e (status 1 where written). */
 int bbs_core_sign_upload(bbs_ctx* ctx, size_t n, const uint8_t* messages, const uint64_t* msg_off,

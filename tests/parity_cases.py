@@ -1557,3 +1557,73 @@ def check_proof_verify_wire(curve, lib_path=None, n=12, L=5, seed=97):
         assert list(e2.proof_verify_wire_batch([kat], [[m1 + b"x"]], [[0]], [hdr], [ph])) == [0]
         e2.close()
 
+
+def check_sign_verify_wire(curve, lib_path=None, n=10, L=4, seed=99):
+    """bbs_sign_wire_* / bbs_verify_wire_*: the reference's public sign (src/sign.rs:32-60) and verify (src/verify.rs:18-50)
+    in one call each -- raw messages in, signatures as octet strings out / in.  Against the oracle's public functions
+    (BLS12-381: the context's generators are the suite's), the composition hash -> core call -> host encoder, and the
+    reference's signature vector with its raw message."""
+    from bbs_sign_amd import api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    raw = [[bytes(rng.randrange(256) for _ in range(rng.choice([0, 3, 32, 64, 119, 120, 300]))) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 8, 65]))) for _ in range(n)]
+    sraw = [list(m) for m in raw]
+    sraw[2] = sraw[2][:-1]                                 # Err: one message short
+    sraw[3] = sraw[3] + [b"extra"]                         # Err: one too many
+    octs, st = eng.sign_wire_batch(sraw, headers)
+    assert [int(x) for x in st] == [1, 1, -1, -1] + [1] * (n - 4), list(st)
+    flat = eng.hash_to_scalar_batch([m for item in raw for m in item], api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_")
+    msgs = [flat[i * L:(i + 1) * L] for i in range(n)]
+    sigs, st0 = eng.core_sign_batch(msgs, headers)
+    for i in range(n):
+        if st[i] == 1:
+            assert octs[i] == api.signature_to_octets(curve, sigs[i], lib_path), (curve, i)
+        else:
+            assert octs[i] == b""
+    if curve == "bls12_381":
+        w = bbs.sign(suite, sk, raw[0], headers[0])
+        assert octs[0] == bbs.g1_compress(c, w.a) + bbs.scalar_be(c, w.e)
+    good = [api.signature_to_octets(curve, s_, lib_path) for s_ in sigs]
+    vraw = [list(m) for m in raw]
+    vraw[1][L - 1] = vraw[1][L - 1] + b"."                 # forged message -> Ok(false)
+    vh = list(headers)
+    vh[4] = vh[4] + b"x"                                   # forged header
+    vo = list(good)
+    vo[5] = vo[5][:-1] + bytes([vo[5][-1] ^ 1])            # e altered
+    vo[6] = vo[6][:-2]                                     # malformed length
+    vraw[7] = vraw[7][:-1]                                 # wrong count
+    got = [int(x) for x in eng.verify_wire_batch(vo, vraw, vh)]
+    assert got == [1, 0, 1, 1, 0, 0, -42, -1] + [1] * (n - 8), got
+    if curve == "bls12_381":
+        for i in (0, 1, 4):
+            assert int(bbs.verify(suite, pk, bbs.Signature(sigs[i].a, sigs[i].e), vh[i], vraw[i])) == got[i], i
+    assert eng.sign_wire_batch([])[0] == [] and list(eng.verify_wire_batch([], [])) == []
+    eng.close()
+    e3 = make_engine(curve, gens, b"y" * 235, lib_path, sk=sk)       # DST of msg_to_scalars longer than 255 bytes
+    o3, st3 = e3.sign_wire_batch(raw[:2], headers[:2])
+    assert [int(x) for x in st3] == [-23, -23] and o3 == [b"", b""]
+    e3.close()
+    if curve == "bls12_381":
+        S = bbs.BLS_SUITE
+        H = bytes.fromhex
+        ikm = H("746869732d49532d6a7573742d616e2d546573742d494b4d2d746f2d67656e65726174652d246528724074232d6b6579")
+        key_info = H("746869732d49532d736f6d652d6b65792d6d657461646174612d746f2d62652d757365642d696e2d746573742d6b65792d67656e")
+        key_dst = H("4242535f424c53313233383147315f584d443a5348412d3235365f535357555f524f5f4832475f484d32535f4b455947454e5f4453545f")
+        sk2 = bbs.key_gen(S, ikm, key_info, key_dst)
+        e2 = make_engine("bls12_381", bbs.create_generators(S, 2, S.api_id), S.api_id, lib_path, sk=sk2)
+        m1 = H("9872ad089e452c7b6e283dfac2a80d58e8d0ff71cc4d5e310a1debdda4a45f02")
+        hdr = H("11223344556677889900aabbccddeeff")
+        o, st = e2.sign_wire_batch([[m1]], [hdr])                    # src/tests/test_vector.rs:163-193, raw message in, octets out
+        assert list(st) == [1] and o[0].hex() == ("84773160b824e194073a57493dac1a20b667af70cd2352d8af241c77658da5253aa8458317cca0eae615690d55b1f271"
+                                                  "64657dcafee1d5c1973947aa70e2cfbb4c892340be5969920d0916067b4565a0")
+        assert list(e2.verify_wire_batch(o, [[m1]], [hdr])) == [1]
+        assert list(e2.verify_wire_batch(o, [[m1 + b"x"]], [hdr])) == [0]
+        e2.close()
+

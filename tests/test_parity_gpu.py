@@ -135,3 +135,9 @@ def test_proof_verify_wire(curve):
     pc.check_proof_verify_wire(curve, None)
     pc.check_proof_verify_wire(curve, None, n=200, L=8, seed=98)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_sign_verify_wire(curve):
+    pc.check_sign_verify_wire(curve, None)
+    pc.check_sign_verify_wire(curve, None, n=150, L=9, seed=100)
+

@@ -119,3 +119,8 @@ def test_octets_out(twin, curve):
 def test_proof_verify_wire(twin, curve):
     pc.check_proof_verify_wire(curve, twin)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_sign_verify_wire(twin, curve):
+    pc.check_sign_verify_wire(curve, twin)
+

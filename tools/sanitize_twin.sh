@@ -37,6 +37,7 @@ for curve in ("bls12_381", "bn254"):
     pc.check_verify_octets(curve, lib)
     pc.check_octets_out(curve, lib)
     pc.check_proof_verify_wire(curve, lib)
+    pc.check_sign_verify_wire(curve, lib)
     pc.check_fixed_base_tree(curve, lib, n_pv=6)
     print(curve, "ok", flush=True)
 pc.check_threads(lib, threads=3, rounds=2, n=5)

@@ -19,6 +19,7 @@ while time.time() - t0 < budget:
         pc.check_verify_octets(curve, None, n=16 + seed % 7, L=2 + seed % 5, seed=seed)
         pc.check_octets_out(curve, None, n=12 + seed % 6, L=3 + seed % 5, seed=seed)
         pc.check_proof_verify_wire(curve, None, n=12 + seed % 5, L=3 + seed % 5, seed=seed)
+        pc.check_sign_verify_wire(curve, None, n=10 + seed % 5, L=1 + seed % 6, seed=seed)
         done += 1
     seed += 1
     print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
