@@ -61,6 +61,10 @@ SIGNATURES = {
     "bbs_verify_octets_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_core_sign_upload": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
     "bbs_core_sign_batch": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p]),
+    "bbs_proof_gen_wire_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                       c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_proof_gen_wire_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                      c_u8p, c_u64p, c_i8p]),
     "bbs_verify_wire_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
     "bbs_verify_wire_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_sign_wire_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p, ctypes.POINTER(vp)]),

@@ -345,8 +345,8 @@ int bbs_core_proof_gen_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const
                               const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
                               const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, bbs_job** job) {
     if (!ctx) return BBS_E_ARG;
-    return DISPATCH(ctx, pg_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job),
-                    pg_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job));
+    return DISPATCH(ctx, pg_upload<BlsCurve>(AS_BLS(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job, nullptr, nullptr, nullptr),
+                    pg_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job, nullptr, nullptr, nullptr));
 }
 
 int bbs_job_run(bbs_job* job) { return job ? job->run() : BBS_E_ARG; }
@@ -684,6 +684,35 @@ int bbs_proof_gen_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, cons
                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
     bbs_job* job = nullptr;
     int rc = bbs_proof_gen_octets_submit(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, octets_out, oct_off_out, status, &job);
+    if (rc) return rc;
+    rc = job->wait();
+    delete job;
+    return rc;
+}
+// the reference's PUBLIC proof_gen (src/proof_gen.rs:78-113) in one call: signature octets and raw messages in, proof octets out
+int bbs_proof_gen_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                              const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                              const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                              uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_job** job_out) {
+    if (!ctx || !status || !job_out || !oct_off_out || (n && (!octets_out || !sig_octets || !msg_item_off))) return BBS_E_ARG;
+    if (!msg_byte_off) {
+        if (n && msg_item_off[n] != msg_item_off[0]) return BBS_E_ARG;
+        msg_byte_off = BBS_ZERO_OFF;
+    }
+    bbs_job* job = nullptr;
+    int rc = DISPATCH(ctx, pg_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho, &job, sig_octets, msg_bytes, msg_byte_off),
+                      pg_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho, &job, sig_octets, msg_bytes, msg_byte_off));
+    if (rc) return rc;
+    if ((rc = job->set_octet_form())) { delete job; return rc; }
+    return submit_with_results(job, status, octets_out, nullptr, oct_off_out, job_out);
+}
+int bbs_proof_gen_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                             const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                             const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                             uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
+    bbs_job* job = nullptr;
+    int rc = bbs_proof_gen_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho,
+                                       octets_out, oct_off_out, status, &job);
     if (rc) return rc;
     rc = job->wait();
     delete job;

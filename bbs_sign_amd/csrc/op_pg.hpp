@@ -9,6 +9,8 @@ struct PgJob : JobBase<C> {
     using JobBase<C>::JobBase;
     PgArgs<C> a{};
     PgIngestArgs<C> ingest{};
+    VfOctArgs<C> oct{};               // signature octets in (wire form) only
+    MsgHashArgs mh{};                 // raw-message form only
     // The proofs come off the device in the caller's layout (stage PgEmit): records, the m^ of the undisclosed messages
     // in ascending index order (L slots per item, the first ucount[i] used) and those counts.  Host side of a delivery:
     // one copy of the records, one contiguous copy per item of its commitments, the running offsets.
@@ -87,20 +89,28 @@ template <class C>
 int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, const uint64_t* msg_off,
                      const uint64_t* didx, const uint64_t* didx_off, const uint8_t* rnd, const uint64_t* rnd_off,
                      const uint8_t* headers, const uint64_t* hdr_off, const uint8_t* ph, const uint64_t* ph_off,
-                     bbs_job** out) {
+                     bbs_job** out, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off) {
+    // sig_octets != nullptr: the signatures arrive as octet strings compress(A) || e (decoded and subgroup-checked on the
+    // device, `sigs` ignored); msg_byte_off != nullptr: the messages arrive as raw bytes (see vf_upload)
     constexpr int N = C::FpP::N;
     constexpr int NC = C::FpP::NC;
     constexpr int FPB = 4 * NC;
     if (!ctx->gens_set || !ctx->pk_set) return BBS_E_STATE;
-    if (!out || (n && (!sigs || !msg_off || !didx_off || !rnd_off || !rnd))) return BBS_E_ARG;
+    const bool wire = sig_octets != nullptr, raw = msg_byte_off != nullptr;
+    if (!out || (n && ((!sigs && !wire) || !msg_off || !didx_off || !rnd_off || !rnd))) return BBS_E_ARG;
+    if (wire) sigs = sig_octets;
     if (ctx->use()) return BBS_E_HIP;
     const int L = ctx->L;
-    const size_t rec = 2 * FPB + 32;
+    const size_t rec = wire ? (size_t)FPB + 32 : (size_t)2 * FPB + 32;
     auto job = std::unique_ptr<PgJob<C>>(new PgJob<C>(ctx));
     job->n = n;
     RaggedIn ms{msg_off, msgs, 32}, di{didx_off, reinterpret_cast<const uint8_t*>(didx), 8}, rs{rnd_off, rnd, 32},
              hb{hdr_off, headers, 1}, pb{ph_off, ph, 1};
+    ms.offsets_only = raw;
     if (!ms.measure(n) || !di.measure(n) || !rs.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
+    const size_t nm = raw ? (size_t)ms.total : 0;
+    RaggedIn mb{raw ? msg_byte_off : nullptr, msg_bytes, 1};
+    if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
     // Host side, one comparison per item (no field data is touched): the contract of this ABI on the number of random
     // scalars (proof_gen.rs:145-149; checked where the reference would have got that far).  Everything else -- the
@@ -117,7 +127,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
         if (bad) continue;                                            // -> InvalidDisclosedIndex
         if (nr != 5 + l - r) return BBS_E_ARG;
     }
-    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &di, &rs, &hb, &pb})) return rc0;
+    if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &di, &rs, &hb, &pb}, raw ? &mb : nullptr, nm)) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();
     auto d64 = [&](size_t at) { return reinterpret_cast<const uint64_t*>(dimg + at); };
     auto d32 = [&](size_t at) { return reinterpret_cast<const uint32_t*>(dimg + at); };
@@ -125,10 +135,11 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     const size_t Lw = (size_t)std::max(L, 1), nn = std::max<size_t>(n, 1);
     PgArgs<C>& a = job->a;
     a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
-    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup)) ? 1 : 0;
+    a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup || wire)) ? 1 : 0;   // wire: the decoder checked A
     PgIngestArgs<C>& ia = job->ingest;
     ia.n = n; ia.L = L; ia.dst_too_long = ctx->dst_too_long ? 1 : 0;
-    ia.rec = d32(0);
+    ia.rec = wire ? nullptr : d32(0);
+    ia.oct = nullptr; ia.pcode = nullptr; ia.msg_dst_too_long = 0;
     ia.m_off = d64(ms.at_off); ia.di_off = d64(di.at_off); ia.rnd_off = d64(rs.at_off); ia.hdr_off64 = d64(hb.at_off); ia.ph_off64 = d64(pb.at_off);
     ia.m = d32(ms.at_data); ia.di = d64(di.at_data); ia.rnd = d32(rs.at_data);
     ia.sig_a = job->template scratch<uint32_t>((size_t)2 * NC * nn, rc);
@@ -141,6 +152,18 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     ia.mtilde = job->template scratch<uint32_t>(Lw * 8 * nn, rc);
     uint32_t* offs = job->template scratch<uint32_t>(4 * nn, rc);
     if (rc) return rc;
+    if (wire) {
+        int8_t* pcode = job->template scratch<int8_t>(nn, rc);
+        if (rc) return rc;
+        VfOctArgs<C>& oa = job->oct;
+        oa.n = n; oa.oct = dimg; oa.sig_a = ia.sig_a; oa.pcode = pcode;
+        if (rt::launch<VfOctDecode<C>>(job->stream(), oa, n)) return BBS_E_HIP;
+        ia.oct = dimg; ia.pcode = pcode;
+    }
+    if (raw) {
+        ia.m = hash_raw_messages<C>(job.get(), ctx, mb, nm, job->mh, ia.msg_dst_too_long, rc);
+        if (rc) return rc;
+    }
     ia.hdr_off = offs; ia.hdr_len = offs + nn; ia.ph_off = offs + 2 * nn; ia.ph_len = offs + 3 * nn;
     a.sig_a = ia.sig_a; a.sig_e = ia.sig_e; a.msgs = ia.msgs; a.dmask = ia.dmask; a.didx = ia.didx; a.rcount = ia.rcount;
     a.rnd5 = ia.rnd5; a.mtilde = ia.mtilde;

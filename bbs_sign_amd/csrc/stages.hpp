@@ -1177,6 +1177,11 @@ struct PgIngestArgs {
     size_t n;
     int L, dst_too_long;
     const uint32_t* rec;                  // n signature records A || e
+    // wire form (oct != nullptr): n signature octet strings compress(A) || e big-endian; A has been decoded into sig_a by
+    // VfOctDecode, its verdict is pcode[i] (as VfIngestArgs)
+    const uint8_t* oct;
+    const int8_t* pcode;
+    int msg_dst_too_long;                 // raw-message form: the reference's msg_to_scalars panics (DST > 255 bytes)
     const uint64_t *m_off, *di_off, *rnd_off, *hdr_off64, *ph_off64;
     const uint32_t* m;                    // messages
     const uint64_t* di;                   // disclosed indexes, caller order, duplicates possible
@@ -1200,6 +1205,25 @@ struct PgIngest {
         const int MW = ((a.L > 1 ? a.L : 1) + 31) / 32;
         for (int w = 0; w < MW; w++) a.dmask[(size_t)w * n + i] = 0;
         a.rcount[i] = 0;
+        if (a.oct) {
+            // the verdicts of bbs_signature_from_octets first, in its order (see VfIngest)
+            constexpr size_t NB = 4 * NC;
+            uint32_t e[8];
+            be32_words(a.oct + i * (NB + 32) + NB, e);
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) any |= e[k];
+            const int8_t c = a.pcode[i];
+            int8_t pre = ST_PENDING;
+            if (c < 0) pre = c;
+            else if (c == 1) pre = -42;
+            else if (!limbs_lt_mod<R>(e)) pre = -40;
+            else if (!any) pre = -42;
+            if (pre != ST_PENDING) { a.status0[i] = pre; return; }
+            soa_st<8>(a.sig_e, n, i, e);
+        }
+        // raw-message form: msg_to_scalars runs first in the reference's public proof_gen (proof_gen.rs:95)
+        if (a.msg_dst_too_long && l > 0) { a.status0[i] = -23; return; }
         if (r > l) { a.status0[i] = -2; return; }                          // InvalidDisclosedIndicesLength
         bool bad = false;
         for (uint64_t k = 0; k < r; k++) bad |= idx[k] >= l;
@@ -1216,18 +1240,20 @@ struct PgIngest {
         if (distinct != r) { a.status0[i] = -4; return; }
         if (a.dst_too_long) { a.status0[i] = -23; return; }
         bool ok = true;
-        const uint32_t* sg = a.rec + i * (size_t)(2 * NC + 8);
-        for (int c = 0; c < 2; c++) {
-            uint32_t w[NC];
+        if (!a.oct) {
+            const uint32_t* sg = a.rec + i * (size_t)(2 * NC + 8);
+            for (int c = 0; c < 2; c++) {
+                uint32_t w[NC];
 #pragma unroll
-            for (int k = 0; k < NC; k++) w[k] = sg[c * NC + k];
-            ok &= limbs_lt_mod<P>(w);
-            soa_st<NC>(a.sig_a + (size_t)c * NC * n, n, i, w);
+                for (int k = 0; k < NC; k++) w[k] = sg[c * NC + k];
+                ok &= limbs_lt_mod<P>(w);
+                soa_st<NC>(a.sig_a + (size_t)c * NC * n, n, i, w);
+            }
+            uint32_t e[8];
+            soa_ld<8>(sg + 2 * NC, 1, 0, e);
+            ok &= limbs_lt_mod<R>(e);
+            soa_st<8>(a.sig_e, n, i, e);
         }
-        uint32_t e[8];
-        soa_ld<8>(sg + 2 * NC, 1, 0, e);
-        ok &= limbs_lt_mod<R>(e);
-        soa_st<8>(a.sig_e, n, i, e);
         const uint32_t* rs = a.rnd + a.rnd_off[i] * 8;
         for (int k = 0; k < 5; k++) {
             uint32_t w[8];

@@ -340,6 +340,29 @@ class Engine:
                                                st.ctypes.data_as(_lib.c_i8p)), "bbs_sign_wire_batch")
         return [out[i * rec:(i + 1) * rec].tobytes() if st[i] == 1 else b"" for i in range(n)], st[:n]
 
+    def proof_gen_wire_batch(self, sig_octets, messages_raw, disclosed_idx, random_scalars, headers=None, phs=None):
+        """bbs_proof_gen_wire_batch: the reference's public proof_gen -- signature octets, raw messages, indexes and the
+        random scalars in, (proof octet strings, statuses) out."""
+        n = len(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
+        mb, mbo, mio = self._raw_msgs(messages_raw)
+        di, dio = self._indexes(disclosed_idx)
+        rs, ro = self._scalars(random_scalars)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        cap = sum(3 * self.fpb + 32 * (4 + len(m)) for m in messages_raw)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        oc = np.zeros(max(cap, 1), dtype=np.uint8)
+        oo = np.zeros(n + 1, dtype=np.uint64)
+        self._chk(self.lib.bbs_proof_gen_wire_batch(self.h, n, _u8(ob), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio), _u8(rs), _u64(ro),
+                                                    _u8(hb), _u64(ho), _u8(pb), _u64(po), _u8(oc), _u64(oo),
+                                                    st.ctypes.data_as(_lib.c_i8p)), "bbs_proof_gen_wire_batch")
+        out = [oc[int(oo[i]):int(oo[i + 1])].tobytes() for i in range(n)]
+        for i in bad:
+            st[i] = -42
+            out[i] = b""
+        return out, st[:n]
+
     def _wire_inputs(self, octets, disclosed_raw, disclosed_idx, headers, phs):
         """disclosed_raw[i]: the disclosed messages of item i as byte strings (hashed on the device)."""
         n = len(octets)

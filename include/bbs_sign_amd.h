@@ -322,6 +322,24 @@ int bbs_proof_gen_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* signatures
                                const uint8_t* headers, const uint64_t* hdr_off,
                                const uint8_t* ph, const uint64_t* ph_off,
                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
+/* The reference's PUBLIC proof_gen (src/proof_gen.rs:78-113) for a context's number of messages in one call: signature
+ * octet strings and the messages as RAW BYTES in (layout as bbs_proof_verify_wire_submit), proof octet strings out (as
+ * bbs_proof_gen_octets_*).  Statuses: what bbs_signature_from_octets gives when it fails, else msg_to_scalars' panic
+ * (BBS_ST_PANIC_DST_TOO_LONG), else core_proof_gen's. */
+int bbs_proof_gen_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                              const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                              const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                              const uint8_t* random_scalars, const uint64_t* rnd_off,
+                              const uint8_t* headers, const uint64_t* hdr_off,
+                              const uint8_t* ph, const uint64_t* ph_off,
+                              uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_job** job_out);
+int bbs_proof_gen_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* signature_octets,
+                             const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                             const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                             const uint8_t* random_scalars, const uint64_t* rnd_off,
+                             const uint8_t* headers, const uint64_t* hdr_off,
+                             const uint8_t* ph, const uint64_t* ph_off,
+                             uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
 /* asynchronous form, as bbs_core_sign_submit: bbs_job_wait(job) delivers `status` and the three outputs */
 int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
                               const uint8_t* messages, const uint64_t* msg_off,

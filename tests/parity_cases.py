@@ -1605,6 +1605,24 @@ def check_sign_verify_wire(curve, lib_path=None, n=10, L=4, seed=99):
         for i in (0, 1, 4):
             assert int(bbs.verify(suite, pk, bbs.Signature(sigs[i].a, sigs[i].e), vh[i], vraw[i])) == got[i], i
     assert eng.sign_wire_batch([])[0] == [] and list(eng.verify_wire_batch([], [])) == []
+    # public proof_gen on the wire: signature octets + raw messages in, proof octets out; then the public proof_verify
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 6]))) for _ in range(n)]
+    po = list(good)
+    po[3] = po[3][:c.fp_bytes] + (c.r + 4).to_bytes(32, "big")           # e >= r: malformed signature
+    po[4] = bbs.g1_compress(c, None) + po[4][c.fp_bytes:]               # A = identity
+    pocts, pst = eng.proof_gen_wire_batch(po, raw, disclosed, rnds, headers, phs)
+    assert [int(x) for x in pst] == [1, 1, 1, -40, -42] + [1] * (n - 5), list(pst)
+    cproofs, cst = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    for i in range(n):
+        assert pocts[i] == (api.proof_to_octets(curve, cproofs[i], lib_path) if pst[i] == 1 else b""), (curve, i)
+    if curve == "bls12_381":
+        w = bbs.proof_gen(suite, pk, bbs.Signature(sigs[0].a, sigs[0].e), headers[0], phs[0], raw[0], disclosed[0], rnds[0])
+        assert pocts[0] == api.proof_to_octets(curve, Proof(w.a_bar, w.b_bar, w.d, w.e_cap, w.r1_cap, w.r3_cap, list(w.commitments), w.challenge), lib_path)
+    okk = [i for i in range(n) if pst[i] == 1]
+    assert list(eng.proof_verify_wire_batch([pocts[i] for i in okk], [[raw[i][j] for j in disclosed[i]] for i in okk],
+                                            [disclosed[i] for i in okk], [headers[i] for i in okk], [phs[i] for i in okk])) == [1] * len(okk)
     eng.close()
     e3 = make_engine(curve, gens, b"y" * 235, lib_path, sk=sk)       # DST of msg_to_scalars longer than 255 bytes
     o3, st3 = e3.sign_wire_batch(raw[:2], headers[:2])
