@@ -250,6 +250,30 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     bls["proof_gen_to_octets_host_inclusive"] = host_loop(pg_oct_submit, all_true)
     assert all(int(o_[n]) == n * po_len for o_ in poo_out[:8])
 
+    # ---- the PUBLIC functions in one call each: raw 32-byte messages in (32 per item, hashed on the device), octet strings
+    # on both sides
+    raw_all = [[pc.expand_message(b"bbs-bench-msg" + pc.i2osp(b, 8) + pc.i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32) for j in range(L)]
+               for b in range(n)]
+    mb_w, mbo_w, mio_w = eng._raw_msgs(raw_all)
+    bls["verify_wire_raw_messages_host_inclusive"] = host_loop(
+        lambda: packed_submit(eng.lib.bbs_verify_wire_submit, "bbs_verify_wire_submit", u8(ob_s), u8(mb_w), u64(mbo_w), u64(mio_w), u8(hb_v), u64(ho_v)), all_true)
+
+    def sign_wire_submit():
+        o = so_out[turn[0] % 9]; turn[0] += 1
+        return packed_submit(eng.lib.bbs_sign_wire_submit, "bbs_sign_wire_submit", u8(mb_w), u64(mbo_w), u64(mio_w), u8(hb_v), u64(ho_v), u8(o))
+    bls["sign_wire_raw_messages_host_inclusive"] = host_loop(sign_wire_submit, all_true)
+    assert bytes(so_out[0][:eng.fpb + 32]) == sig_octs[0]
+    di_w, dio_w = eng._indexes(disclosed)
+    rs_w, ro_w = eng._scalars(rnds)
+    pb_w, po_w = _ragged_bytes([b""] * n)
+
+    def pg_wire_submit():
+        k = turn[0] % 9; turn[0] += 1
+        return packed_submit(eng.lib.bbs_proof_gen_wire_submit, "bbs_proof_gen_wire_submit", u8(ob_s), u8(mb_w), u64(mbo_w), u64(mio_w),
+                             u64(di_w), u64(dio_w), u8(rs_w), u64(ro_w), u8(hb_v), u64(ho_v), u8(pb_w), u64(po_w), u8(po_out[k]), u64(poo_out[k]))
+    bls["proof_gen_wire_raw_messages_host_inclusive"] = host_loop(pg_wire_submit, all_true)
+    assert bytes(po_out[0][:po_len]) == octs[0]
+
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
     sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)
     mb, db, rb = pc.bench_items(sb_, eb, n, L, R, 0)
