@@ -182,6 +182,56 @@ static int run_curve(int curve) {
     CHECK(bbs_core_proof_verify_batch(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph2, po, stC) == BBS_OK);
     CHECK(stC[0] == 0 && stC[1] == 1 && stC[2] == 1);     /* only item 0 carries a presentation header */
 
+    /* ---- the same round trip through the WIRE forms: raw messages and octet strings only -- what a binding needs when it
+     * does not want to convert field elements at all (the reference's public sign / verify / proof_gen / proof_verify) ---- */
+    {
+        uint8_t mbytes[256];
+        uint64_t mbo[3 * L + 1], mio[4] = {0, L, 2 * L, 3 * L};
+        size_t at = 0;
+        mbo[0] = 0;
+        for (int k = 0; k < 3 * L; k++) { memcpy(mbytes + at, raw[k], strlen(raw[k])); at += strlen(raw[k]); mbo[k + 1] = at; }
+        const size_t so_len = fpb + 32;
+        uint8_t so[3 * (48 + 32)];
+        int8_t sw[3];
+        CHECK(bbs_sign_wire_batch(ctx, 3, mbytes, mbo, mio, hdr_bytes, ho, so, sw) == BBS_OK);
+        CHECK(sw[0] == 1 && sw[1] == 1 && sw[2] == 1);
+        for (int i = 0; i < 3; i++) {                    /* the same signatures as the core call above, as octets */
+            uint8_t want[48 + 32];
+            CHECK(bbs_signature_to_octets(curve, sigs + (size_t)i * sig_rec, want) == BBS_OK);
+            CHECK(memcmp(want, so + (size_t)i * so_len, so_len) == 0);
+        }
+        CHECK(bbs_verify_wire_batch(vctx, 3, so, mbytes, mbo, mio, hdr_bytes, ho, sw) == BBS_OK);
+        CHECK(sw[0] == 1 && sw[1] == 1 && sw[2] == 1);
+        mbytes[0] ^= 1;                                  /* first message of item 0 altered */
+        CHECK(bbs_verify_wire_batch(vctx, 3, so, mbytes, mbo, mio, hdr_bytes, ho, sw) == BBS_OK);
+        CHECK(sw[0] == 0 && sw[1] == 1 && sw[2] == 1);
+        mbytes[0] ^= 1;
+        /* proof_gen: the first three items of the core call above (same disclosed sets, same random scalars) */
+        uint64_t dio_w[4] = {dio[0], dio[1], dio[2], dio[3]}, ro_w[4] = {ro[0], ro[1], ro[2], ro[3]};
+        uint64_t ho_w[4] = {ho4[0], ho4[1], ho4[2], ho4[3]}, po_w[4] = {po[0], po[1], po[2], po[3]};
+        uint8_t pocts[3 * (3 * 48 + 32 * (4 + L))];
+        uint64_t poff[4];
+        CHECK(bbs_proof_gen_wire_batch(vctx, 3, so, mbytes, mbo, mio, di, dio_w, rnd, ro_w, hdr4, ho_w, ph_bytes, po_w, pocts, poff, sw) == BBS_OK);
+        CHECK(sw[0] == 1 && sw[1] == 1 && sw[2] == 1);
+        for (int i = 0; i < 3; i++) {                    /* the same proofs, as octets */
+            uint8_t want[3 * 48 + 32 * (4 + L)];
+            const size_t nc = (size_t)(cmo[i + 1] - cmo[i]), wl = 3 * fpb + 32 * (4 + nc);
+            CHECK(bbs_proof_to_octets(curve, pf + (size_t)i * pf_rec, cm + 32 * cmo[i], nc, want) == BBS_OK);
+            CHECK(wl == poff[i + 1] - poff[i] && memcmp(want, pocts + poff[i], wl) == 0);
+        }
+        /* proof_verify: disclosed messages as raw bytes -- items disclose {0, 2}, {1}, {} */
+        uint8_t dmb[64];
+        uint64_t dmbo[4], dmio[4] = {0, 2, 3, 3};
+        const char* dsel[3] = {raw[0], raw[2], raw[L + 1]};
+        at = 0; dmbo[0] = 0;
+        for (int k = 0; k < 3; k++) { memcpy(dmb + at, dsel[k], strlen(dsel[k])); at += strlen(dsel[k]); dmbo[k + 1] = at; }
+        CHECK(bbs_proof_verify_wire_batch(vctx, 3, pocts, poff, dmb, dmbo, dmio, di, dio_w, hdr4, ho_w, ph_bytes, po_w, sw) == BBS_OK);
+        CHECK(sw[0] == 1 && sw[1] == 1 && sw[2] == 1);
+        pocts[poff[1] + 3 * fpb + 5] ^= 1;               /* e^ of item 1 altered */
+        CHECK(bbs_proof_verify_wire_batch(vctx, 3, pocts, poff, dmb, dmbo, dmio, di, dio_w, hdr4, ho_w, ph_bytes, po_w, sw) == BBS_OK);
+        CHECK(sw[0] == 1 && sw[1] == 0 && sw[2] == 1);
+    }
+
     bbs_ctx_destroy(vctx);                                                                                               /* step 18 */
     bbs_ctx_destroy(ctx);
     free(gens); free(pf);
