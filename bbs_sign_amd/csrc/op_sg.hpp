@@ -55,7 +55,8 @@ int sg_upload(Ctx<C>* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_of
     ms.offsets_only = raw;
     if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
     const size_t nm = raw ? (size_t)ms.total : 0;
-    RaggedIn mb{raw ? msg_byte_off : nullptr, msg_bytes, 1};
+    // (message t of the batch is entry msg_off[0] + t of msg_byte_off: item offsets need not start at zero)
+    RaggedIn mb{raw ? msg_byte_off + (n ? msg_off[0] : 0) : nullptr, msg_bytes, 1};
     if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
     if (int rc0 = stage_image(job.get(), n, nullptr, 0, {&ms, &hb}, raw ? &mb : nullptr, nm)) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();

@@ -208,7 +208,8 @@ int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* proof_o
 /* The reference's PUBLIC proof_verify (src/proof_verify.rs:19-61) for contexts of a fixed number of messages, in one
  * call: proof octet strings and the disclosed messages as RAW BYTES.  Message t of the batch is
  * msg_bytes[msg_byte_off[t] .. msg_byte_off[t + 1]) (t counts the disclosed messages of all items in order);
- * msg_item_off[i] .. msg_item_off[i + 1] are the messages of item i (n + 1 entries, in messages).  msg_to_scalars
+ * msg_item_off[i] .. msg_item_off[i + 1] are the messages of item i (n + 1 entries, in messages; as with every offset
+ * array of this header they need not start at zero: a window into larger arrays is passed by pointing into them).  msg_to_scalars
  * (interface_utilities.rs:76-88, dst = api_id || "MAP_MSG_TO_SCALAR_AS_HASH_") runs on the device in front of the checks;
  * statuses as bbs_proof_verify_octets_* on the hashed messages (BBS_ST_PANIC_DST_TOO_LONG for an item with disclosed
  * messages when that dst exceeds 255 bytes, as the reference's expand_message panics). */

@@ -17,6 +17,7 @@ import numpy as np
 
 from bbs_sign_amd import BbsError, Engine, Proof, Signature
 from bbs_sign_amd import _lib
+from bbs_sign_amd.engine import _ragged_bytes as _engine_ragged
 from oracle import bbs
 from oracle.hashing import expand_message, i2osp
 
@@ -1605,6 +1606,16 @@ def check_sign_verify_wire(curve, lib_path=None, n=10, L=4, seed=99):
         for i in (0, 1, 4):
             assert int(bbs.verify(suite, pk, bbs.Signature(sigs[i].a, sigs[i].e), vh[i], vraw[i])) == got[i], i
     assert eng.sign_wire_batch([])[0] == [] and list(eng.verify_wire_batch([], [])) == []
+    # item offsets that do not start at zero (a window into a larger list): items 2 .. 4 of the same arrays
+    mb_, mbo_, mio_ = eng._raw_msgs(raw)
+    ob_, _ = eng._sig_octets(good)
+    hb_, ho_ = _engine_ragged(headers)
+    st_w = np.full(3, -128, dtype=np.int8)
+    rec_o = c.fp_bytes + 32
+    rc = eng.lib.bbs_verify_wire_batch(eng.h, 3, ob_[2 * rec_o:].ctypes.data_as(_lib.c_u8p), mb_.ctypes.data_as(_lib.c_u8p),
+                                       mbo_.ctypes.data_as(_lib.c_u64p), mio_[2:].ctypes.data_as(_lib.c_u64p),
+                                       hb_.ctypes.data_as(_lib.c_u8p), ho_[2:].ctypes.data_as(_lib.c_u64p), st_w.ctypes.data_as(_lib.c_i8p))
+    assert rc == 0 and list(st_w) == [1, 1, 1], (rc, list(st_w))
     # public proof_gen on the wire: signature octets + raw messages in, proof octets out; then the public proof_verify
     disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
     rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
