@@ -18,6 +18,9 @@ octs = [api.proof_to_octets("bls12_381", p) for p in proofs]
 no, keep_o, args_o = eng._oct_inputs(octs, dm, disclosed, None, None)
 
 
+raw512 = [[bytes([b & 255, j, 7]) * (1 + (b + j) % 40) for j in range(L)] for b in range(512)]
+
+
 def snap():
     free, total = torch.cuda.mem_get_info()
     return (total - free) / 2**20, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
@@ -37,6 +40,11 @@ while time.time() - t0 < secs:
         j.wait(); assert (j.result == 1).all(); j.free()
     s2, st = eng.core_sign_batch(msgs[:512]); assert (st == 1).all()
     p2, st = eng.core_proof_gen_batch(sigs[:512], msgs[:512], disclosed[:512], rnds[:512]); assert (st == 1).all()
+    # the public one-call forms (raw messages hashed on the device, octet strings on both sides)
+    so, st = eng.sign_wire_batch(raw512); assert (st == 1).all()
+    assert (eng.verify_wire_batch(so, raw512) == 1).all()
+    po, st = eng.proof_gen_wire_batch(so, raw512, disclosed[:512], rnds[:512]); assert (st == 1).all()
+    assert (eng.proof_verify_wire_batch(po, [m[:R] for m in raw512], disclosed[:512]) == 1).all()
     rounds += 1
     if rounds in (2, 4) or rounds % 10 == 0:
         d, h = snap()
