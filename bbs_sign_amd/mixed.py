@@ -21,15 +21,34 @@ class PackedBatch:
         self.n, self.keep, self.args = eng._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
 
 
+MIN_BATCH = 512      # below this a job's fixed cost (launches, two copies) shows; a multiple of the 64-lane wavefront
+
+
+def batch_size_for(share: int, batch_max: int = 4096, inflight: int = 8, min_batch: int = MIN_BATCH) -> int:
+    """Batch size for one curve's share of a rank.  One 4096-item job fills only 40-60 % of the chip (410 + 640
+    wavefronts of uneven length on 1024 SIMDs): the rate comes from several jobs in flight.  Under strong
+    scaling the share shrinks with the number of ranks (65 536 items / 2 curves / 8 ranks = 4096 = ONE job per curve),
+    so the share is cut into at least `inflight` jobs per curve -- never below `min_batch` items, never above
+    `batch_max` -- and rounded up to whole wavefronts."""
+    if share <= 0:
+        return max(1, min(batch_max, min_batch))
+    size = -(-share // max(1, inflight))                 # ceil(share / inflight)
+    size = max(min_batch, min(batch_max, size))
+    return min(batch_max, -(-size // 64) * 64)
+
+
 def prepare_rank(engines: Dict[str, object], plan_for_rank: Dict[str, List[int]],
-                 fetch_items: Callable[[str, Sequence[int]], tuple], batch: int = 4096) -> List[PackedBatch]:
-    """Cut this rank's share into batches of at most `batch` items per curve.  fetch_items(curve, ids) returns
+                 fetch_items: Callable[[str, Sequence[int]], tuple], batch: int = 4096, inflight: int = 8,
+                 min_batch: int = MIN_BATCH) -> List[PackedBatch]:
+    """Cut this rank's share into batches per curve: at most `batch` items, and small enough that every curve's share
+    makes at least `inflight` jobs where the share allows it (batch_size_for).  fetch_items(curve, ids) returns
     (proofs, disclosed_msgs, disclosed_idx[, headers, phs]) for those global item ids."""
     out = []
     for curve in sorted(plan_for_rank):
         ids = plan_for_rank[curve]
-        for lo in range(0, len(ids), batch):
-            part = ids[lo:lo + batch]
+        size = batch_size_for(len(ids), batch, inflight, min(min_batch, batch))
+        for lo in range(0, len(ids), size):
+            part = ids[lo:lo + size]
             out.append(PackedBatch(engines[curve], curve, part, *fetch_items(curve, part)))
     return out
 
@@ -100,6 +119,6 @@ def proof_verify_mixed(engines, curve_of_item: Sequence[str], fetch_items, world
                        device="cpu", batch: int = 4096, inflight: int = 8) -> List[int]:
     """The whole path for one call: plan, pack, run, gather.  Every rank returns the merged statuses."""
     plan = shard_plan(curve_of_item, world)
-    batches = prepare_rank(engines, plan[rank], fetch_items, batch)
-    mine = run_rank(batches, inflight)
+    batches = prepare_rank(engines, plan[rank], fetch_items, batch, inflight)
+    mine = run_rank(batches, max(inflight, 1))
     return gather_statuses(plan, rank, mine, len(curve_of_item), dist, device)

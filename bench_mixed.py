@@ -47,11 +47,15 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
         return out_p, out_dm, out_di
 
     t_prep = time.perf_counter()
-    batches = mixed.prepare_rank(engines, plan[rank], fetch_items, batch)
+    min_batch = getattr(args, "min_batch", None) or mixed.MIN_BATCH
+    batches = mixed.prepare_rank(engines, plan[rank], fetch_items, batch, args.inflight, min_batch)
     t_prep = time.perf_counter() - t_prep
+    # jobs in flight: every curve's share was cut into >= --inflight jobs where it is large enough, and the two curves
+    # alternate, so up to 2 x --inflight jobs are outstanding (BN254 jobs are ~0.4 of a BLS12-381 job)
+    depth = max(args.inflight, min(len(batches), 2 * args.inflight))
 
     def step():
-        mine = mixed.run_rank(batches, args.inflight)
+        mine = mixed.run_rank(batches, depth)
         return mixed.gather_statuses(plan, rank, mine, total, dist, red_dev)
 
     for _ in range(max(1, min(args.warmup, 2))):
@@ -75,9 +79,11 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: %d proof_verify = %d BN254 + %d BLS12-381 (L=%d, R=%d), sharded by curve "
-                                   "then contiguously over %d GPU(s), %d-item batches from host buffers, one all_gather of int8 "
-                                   "statuses per step" % (total, total // 2, total // 2, L, R, world, batch),
-                       "batches_per_rank": len(batches), "batches_in_flight": args.inflight, "backend": args.backend if world > 1 else None,
+                                   "then contiguously over %d GPU(s), batches of at most %d items (cut so that each curve's share of a rank is >= %d "
+                                   "jobs) from host buffers, one all_gather of int8 statuses per step" % (total, total // 2, total // 2, L, R, world, batch, args.inflight),
+                       "batches_per_rank": len(batches), "batch_sizes_rank0": sorted({b.n for b in batches}, reverse=True),
+                       "items_per_rank": sum(b.n for b in batches), "batches_in_flight": depth,
+                       "backend": args.backend if world > 1 else None,
                        "fixed_base_window_bits": {"bls12_381": args.window_bits, "bn254": min(args.window_bits, 16)}},
             "checks": {"merged_statuses_exact_every_step": True, "corrupted": "every 16th global item"},
             "prepare_s_rank0": t_prep}))

@@ -665,6 +665,20 @@ def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2, window_bits
     assert (st == 1).all()
     st = eng.core_verify_batch(sigs, msgs)
     assert (st == 1).all()
+    # every 16th signature forged (src/verify.rs:88-92 -> Ok(false)): A + P1 (items 0 mod 32: fails in the pairing only),
+    # e + 1 (16 mod 32), and every 64th item additionally with one message changed
+    forged, fmsgs = list(sigs), [list(m) for m in msgs]
+    for i in range(0, n, 16):
+        forged[i] = Signature(c.g1_add(sigs[i].a, c.g1), sigs[i].e) if i % 32 == 0 else Signature(sigs[i].a, (sigs[i].e + 1) % c.r)
+        if i % 64 == 0:
+            fmsgs[i][L - 1] = (fmsgs[i][L - 1] + 1) % c.r
+    want_vf = [0 if i % 16 == 0 else 1 for i in range(n)]
+    st = eng.core_verify_batch(forged, fmsgs)
+    assert [int(x) for x in st] == want_vf
+    eng.set_batch_verification(True)                     # the opt-in mode decides the same (fallback over the whole batch)
+    st = eng.core_verify_batch(forged, fmsgs)
+    assert [int(x) for x in st] == want_vf
+    eng.set_batch_verification(False)
     proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
     assert (st == 1).all()
     dm = [m[:R] for m in msgs]
@@ -742,24 +756,32 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, c
     for i in range(0, n, 7):
         proofs[i].r1_cap = (proofs[i].r1_cap + 1) % c.r
     st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+    # core_verify (src/verify.rs:53-93) of every item, every 7th signature forged (A + P1 / e + 1 alternating)
+    vsigs = list(sigs)
+    for i in range(0, n, 7):
+        vsigs[i] = Signature(c.g1_add(sigs[i].a, c.g1), sigs[i].e) if i % 2 else Signature(sigs[i].a, (sigs[i].e + 1) % c.r)
+    vst = eng.core_verify_batch(vsigs, msgs)
 
     def one(i):
         s = c_port.core_sign(sk, gens, b"", msgs[i], api_id)
         good = bbs.Signature(sigs[i].a, sigs[i].e)
+        vf = c_port.core_verify(pk, bbs.Signature(vsigs[i].a, vsigs[i].e), gens, b"", msgs[i], api_id)
         p = c_port.core_proof_gen(pk, good, b"", gens, b"", msgs[i], disclosed[i], api_id, rnds[i])
         mine = bbs.Proof(proofs[i].a_bar, proofs[i].b_bar, proofs[i].d, proofs[i].e_cap, proofs[i].r1_cap, proofs[i].r3_cap,
                          proofs[i].commitments, proofs[i].challenge)
         v = c_port.core_proof_verify(pk, mine, gens, b"", b"", dm[i], disclosed[i], api_id)
         if i % 7 == 0:
             p.r1_cap = (p.r1_cap + 1) % c.r
-        return (s.a, s.e) == (sigs[i].a, sigs[i].e), p == mine, int(v) == int(st[i])
+        return (s.a, s.e) == (sigs[i].a, sigs[i].e), p == mine, int(v) == int(st[i]), int(vf) == int(vst[i])
 
     with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         res = list(ex.map(one, range(n)))
     assert all(r[0] for r in res), "sign mismatch"
     assert all(r[1] for r in res), "proof_gen mismatch"
     assert all(r[2] for r in res), "proof_verify mismatch"
+    assert all(r[3] for r in res), "verify mismatch"
     assert [int(x) for x in st] == [0 if i % 7 == 0 else 1 for i in range(n)]
+    assert [int(x) for x in vst] == [0 if i % 7 == 0 else 1 for i in range(n)]
     # the opt-in batch-verification mode returns the same booleans on the same (partly corrupted) batch
     eng.set_batch_verification(True)
     assert [int(x) for x in eng.core_proof_verify_batch(proofs, dm, disclosed)] == [int(x) for x in st]

@@ -141,3 +141,43 @@ def test_sign_verify_wire(curve):
     pc.check_sign_verify_wire(curve, None)
     pc.check_sign_verify_wire(curve, None, n=150, L=9, seed=100)
 
+
+
+@pytest.mark.parametrize("total", [65536, 8192])
+def test_mixed_list_configs4_one_gpu(total):
+    """BASELINE configs[4] through the real path on one GPU: bench.py --config mixed65536's own driver
+    (bench_mixed.run_mixed -> sharding.shard_plan -> mixed.prepare_rank -> packed batches in host buffers ->
+    bbs_core_proof_verify_submit with both curves in flight -> gather -> merge_status); every 16th global item is
+    corrupted and run_mixed compares the merged statuses of every step with that pattern.  8192 = one rank's share of the
+    list at 8 GPUs (the strong-scaling regime: the share is cut into 512-item jobs)."""
+    import argparse
+    import json
+    import torch
+    import bench_mixed
+    args = argparse.Namespace(batch=4096, inflight=8, window_bits=20, warmup=1, steps=2, backend="nccl")
+    lines = []
+    bench_mixed.run_mixed(args, pc, torch, None, 0, 0, 1, "cuda", torch.cuda.synchronize, total=total, emit=lines.append)
+    line = json.loads(lines[0])
+    assert line["checks"]["merged_statuses_exact_every_step"] is True and line["n_gpus"] == 1
+    assert line["config"]["items_per_rank"] == total
+    assert line["config"]["batches_per_rank"] >= 16           # >= 8 jobs per curve
+    assert max(line["config"]["batch_sizes_rank0"]) == (4096 if total == 65536 else 512)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare command (no torchrun, WORLD_SIZE unset): bench.py starts the two ranks itself
+    as a child process before touching the GPU.  Rehearsal of the N > 1 plumbing only: both ranks share this box's one
+    GPU and talk over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-ranks-on-device", "0",
+                        "--steps", "8", "--warmup", "2", "--batch", "1024", "--inflight", "2", "--window-bits", "16",
+                        "--no-extras", "--no-cpu-baseline", "--min-region-s", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 8 and line["checks"]["statuses_exact_every_step"] is True

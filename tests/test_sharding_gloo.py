@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU, world size 2 over gloo.
+"""The N > 1 path on CPU, world sizes 2 and 4 over gloo.
  * test_two_rank_gloo_shard_and_gather: partition + gather plumbing with a stand-in per-item result.
  * test_two_rank_engine_backed_mixed_list: bench.py --config mixed65536's own driver (bench_mixed.run_mixed) with each
    rank running the HOST TWIN engine (the same stage code compiled for x86, tests/hosttwin) on its shard of a small
@@ -81,14 +81,38 @@ def _engine_worker(rank, world, port, twin, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     args = argparse.Namespace(batch=5, inflight=3, window_bits=4, warmup=1, steps=2, backend="gloo")
     lines = []
-    bench_mixed.run_mixed(args, pc, torch, dist, rank, 0, world, "cpu", dist.barrier, total=36, lib_path=twin,
+    bench_mixed.run_mixed(args, pc, torch, dist, rank, 0, world, "cpu", dist.barrier, total=18 * world, lib_path=twin,
                           emit=lines.append, L=4, R=2)
     if rank == 0:
         q.put(json.loads(lines[0]))
     dist.destroy_process_group()
 
 
-def test_two_rank_engine_backed_mixed_list():
+def test_strong_scaling_plan_keeps_every_rank_busy():
+    """BASELINE configs[4] at 1/2/4/8 ranks: every rank's share of each curve is cut into at least 8 jobs (one
+    4096-item job per curve would be the single-batch regime, 0.6-0.8 M/s per GPU), none below 512 items."""
+    from bbs_sign_amd.mixed import batch_size_for
+    curves = ["bls12_381" if (i & 1) else "bn254" for i in range(65536)]
+    for world in (1, 2, 4, 8):
+        plan = shard_plan(curves, world)
+        for shard in plan:
+            jobs = 0
+            for c, ids in shard.items():
+                size = batch_size_for(len(ids), 4096, 8)
+                assert 512 <= size <= 4096 and size % 64 == 0
+                jobs_c = -(-len(ids) // size)
+                assert jobs_c >= 8, (world, c, len(ids), size)
+                jobs += jobs_c
+            assert jobs >= 16
+    assert batch_size_for(100, 4096, 8) == 512 and batch_size_for(0, 4096, 8) == 512
+    assert batch_size_for(9, 5, 3, 5) == 5               # test-sized lists: the cap wins
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_engine_backed_mixed_list(world):
     from bbs_sign_amd import build as b
     twin = b.build(twin=True, verbose=False)
     s = socket.socket()
@@ -97,7 +121,7 @@ def test_two_rank_engine_backed_mixed_list():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, twin, q)) for r in range(2)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, twin, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -115,5 +139,6 @@ def test_two_rank_engine_backed_mixed_list():
             p.terminate()
     assert line is not None, "a rank died: exit codes %r" % [p.exitcode for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["checks"]["merged_statuses_exact_every_step"] is True
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["checks"]["merged_statuses_exact_every_step"] is True
     assert line["config"]["batches_per_rank"] == 4          # 9 items per curve per rank in batches of 5
+    assert line["config"]["items_per_rank"] == 18
