@@ -71,21 +71,25 @@ def build(twin=False, force=False, jobs=None, verbose=True):
         flags = ["-O3", "--offload-arch=gfx950", "-fPIC"]
     # only the C ABI of include/bbs_sign_amd.h is exported (capi.hip raises the visibility of its extern "C" blocks)
     flags += ["-fvisibility=hidden", "-fvisibility-inlines-hidden", '-DBBS_SRC_HASH="%s"' % want]
-    stamp = os.path.join(objdir, "source_hash.txt")
-    fresh_objs = os.path.exists(stamp) and open(stamp).read() == want
+    # an object is reused only if ITS OWN stamp (written after it compiled) names this source hash and these flags: a build
+    # that failed half way leaves no object that claims a hash it was not built from
+    key = hashlib.sha256((want + "\0" + "\0".join(flags)).encode()).hexdigest()
     jobs = jobs or min(8, os.cpu_count() or 1)
 
     def one(tu):
         obj = os.path.join(objdir, os.path.basename(tu)[:-4] + ".o")
-        if not force and fresh_objs and os.path.exists(obj):
+        stamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
             return obj
+        if os.path.exists(stamp):
+            os.remove(stamp)
         _run(["hipcc"] + flags + ["-c", tu, "-o", obj])
+        with open(stamp, "w") as f:
+            f.write(key)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(one, tus))
-    with open(stamp, "w") as f:
-        f.write(want)
     link = ["hipcc", "-shared", "-fPIC"] + (["--offload-host-only"] if twin else ["--offload-arch=gfx950"]) + objs + ["-o", out]
     _run(link)
     assert built_hash(out) == want, "the library just built does not report the source hash it was built from"

@@ -626,6 +626,7 @@ static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_
     if (!rc && (o1 || o2 || o3)) rc = job->enqueue_result_fetch();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
+    job->results_wanted = o1 || o2 || o3;
     job->set_result_targets(o1, o2, o3);
     *job_out = job;
     return BBS_OK;

@@ -110,7 +110,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     if (!ms.measure(n) || !di.measure(n) || !rs.measure(n) || !hb.measure(n) || !pb.measure(n)) return BBS_E_ARG;
     const size_t nm = raw ? (size_t)ms.total : 0;
     // (message t of the batch is entry msg_off[0] + t of msg_byte_off: item offsets need not start at zero)
-    RaggedIn mb{raw ? msg_byte_off + (n ? msg_off[0] : 0) : nullptr, msg_bytes, 1};
+    RaggedIn mb{raw ? (nm ? msg_byte_off + msg_off[0] : zero_off1()) : nullptr, msg_bytes, 1};   // nm == 0: msg_byte_off is never indexed
     if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
     // Host side, one comparison per item (no field data is touched): the contract of this ABI on the number of random

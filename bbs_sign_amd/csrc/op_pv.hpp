@@ -52,7 +52,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     if (hb.total > 0xF0000000ull || pb.total > 0xF0000000ull) return BBS_E_ARG;
     const size_t nm = raw ? (size_t)dm.total : 0;                   // disclosed messages of the whole batch
     // (message t of the batch is entry dmsg_off[0] + t of msg_byte_off: item offsets need not start at zero)
-    RaggedIn mb{raw ? msg_byte_off + (n ? dmsg_off[0] : 0) : nullptr, msg_bytes, 1};
+    RaggedIn mb{raw ? (nm ? msg_byte_off + dmsg_off[0] : zero_off1()) : nullptr, msg_bytes, 1};   // nm == 0: msg_byte_off is never indexed
     if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
     // (the message section is ragged over MESSAGES, not items: stage_image places and fills it with nm as its count)
     if (int rc0 = stage_image(job.get(), n, wire ? nullptr : proofs_fixed, wire ? 0 : rec, {&cm, &dm, &di, &hb, &pb}, raw ? &mb : nullptr, nm)) return rc0;

@@ -42,7 +42,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     if (!ms.measure(n) || !hb.measure(n) || hb.total > 0xF0000000ull) return BBS_E_ARG;
     const size_t nm = raw ? (size_t)ms.total : 0;
     // (message t of the batch is entry msg_off[0] + t of msg_byte_off: item offsets need not start at zero)
-    RaggedIn mb{raw ? msg_byte_off + (n ? msg_off[0] : 0) : nullptr, msg_bytes, 1};
+    RaggedIn mb{raw ? (nm ? msg_byte_off + msg_off[0] : zero_off1()) : nullptr, msg_bytes, 1};   // nm == 0: msg_byte_off is never indexed
     if (raw && (!mb.measure(nm) || mb.total > 0xF0000000ull)) return BBS_E_ARG;
     if (int rc0 = stage_image(job.get(), n, sigs, rec, {&ms, &hb}, raw ? &mb : nullptr, nm)) return rc0;
     const uint8_t* dimg = job->d_raw.template as<uint8_t>();

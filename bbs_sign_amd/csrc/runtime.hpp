@@ -589,10 +589,18 @@ struct bbs_job {
     }
     bool timed = false;                          // set from bbs_ctx::stage_timing when the job is created
     std::unique_ptr<rt::EventList> tev;          // events of the LAST run (timed jobs)
+    bool results_wanted = false;                 // submit form of sign / proof_gen: the records follow the statuses
     int run() {
         if (use()) return BBS_E_HIP;
         if (timed) tev.reset(new rt::EventList(1 + 2 * stages.size()));
-        return run_recorded(timed ? tev.get() : nullptr);
+        int rc = run_recorded(timed ? tev.get() : nullptr);
+        // a submit-form job that is run AGAIN (bbs_job_run): what bbs_job_wait delivers must be this run's statuses and
+        // records, not the first run's -- the copies to page-locked memory are enqueued behind every run
+        if (!rc && deliver_to) {
+            rc = enqueue_status_fetch();
+            if (!rc && results_wanted) rc = enqueue_result_fetch();
+        }
+        return rc;
     }
     // stage durations of the last run of a timed job; call after wait()
     int stage_times(float* total_ms, float* kernel_ms, int cap, int* n_stages) {
@@ -717,6 +725,8 @@ struct JobBase : bbs_job {
 // staging image: the batch as the caller handed it over, one page-locked buffer, one asynchronous copy
 // =============================================================================================
 // Ragged input arrays of one batch inside the staging image: offsets rebased to 0, sections 16-byte aligned.
+// offsets of a ragged section without entries (a batch without messages): one zero that may be read at index 0
+inline const uint64_t* zero_off1() { static const uint64_t z[1] = {0}; return z; }
 struct RaggedIn {
     const uint64_t* off;      // n + 1 caller offsets, or nullptr (every item empty)
     const uint8_t* data;

@@ -267,8 +267,8 @@ where
 
     /// `proof_verify` (src/proof_verify.rs:19-61) for n proofs: the asynchronous form, so that a serving loop keeps
     /// several batches in flight -- `submit` returns at once, `PendingVerify::wait` yields the n results.
-    pub fn proof_verify_submit(&self, proofs: &[Proof<E, F>], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
-                               disclosed_indexes: &[&[usize]]) -> PendingVerify {
+    pub fn proof_verify_submit<'a>(&'a self, proofs: &[Proof<E, F>], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
+                               disclosed_indexes: &[&[usize]]) -> PendingVerify<'a> {
         let n = proofs.len();
         let (dm, dmo) = self.msg_to_scalars(disclosed_messages);
         let (mut fixed, mut cm, mut cmo, mut di, mut dio) = (Vec::new(), Vec::new(), vec![0u64], Vec::new(), vec![0u64]);
@@ -289,7 +289,7 @@ where
                                          dio.as_ptr(), hb.as_ptr(), ho.as_ptr(), pb.as_ptr(), po.as_ptr(), status.as_mut_ptr(), &mut job)   // step 15
         };
         assert_eq!(rc, 0, "bbs_core_proof_verify_submit: {rc}");
-        PendingVerify { job, status }                               // the input buffers may be dropped: the library staged them
+        PendingVerify { job, status, _issuer: std::marker::PhantomData }   // the input buffers may be dropped: the library staged them
     }
 
     /// Synchronous convenience: one batch, wait.
@@ -301,9 +301,10 @@ where
     pub fn messages_per_item(&self) -> usize { self.l }
 }
 
-/// A submitted proof_verify batch.
-pub struct PendingVerify { job: *mut BbsJob, status: Box<[i8]> }
-impl PendingVerify {
+/// A submitted proof_verify batch.  It borrows the issuer it was submitted to: the job's streams and buffers belong to that
+/// issuer's context, so the borrow checker refuses to drop the issuer (bbs_ctx_destroy) while a batch is outstanding.
+pub struct PendingVerify<'a> { job: *mut BbsJob, status: Box<[i8]>, _issuer: std::marker::PhantomData<&'a ()> }
+impl<'a> PendingVerify<'a> {
     pub fn wait(mut self) -> Vec<Result<bool, ProofGenError>> {
         let rc = unsafe { bbs_job_wait(self.job) };                                                // step 16
         unsafe { bbs_job_free(self.job) };                                                         // step 17
@@ -312,7 +313,7 @@ impl PendingVerify {
         self.status.iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
     }
 }
-impl Drop for PendingVerify {
+impl<'a> Drop for PendingVerify<'a> {
     fn drop(&mut self) { if !self.job.is_null() { unsafe { bbs_job_wait(self.job); bbs_job_free(self.job); } } }
 }
 

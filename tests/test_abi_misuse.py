@@ -87,3 +87,56 @@ def test_misuse_is_refused(twin, curve):
     assert lib.bbs_core_verify_batch(bare, n, _u8(sigs), _u8(msgs), _u64(good), none8, none64, i8) == E_STATE
     assert lib.bbs_core_sign_batch(bare, n, _u8(msgs), _u64(good), none8, none64, _u8(sigs), i8) == E_STATE
     lib.bbs_ctx_destroy(bare)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_wire_forms_without_messages_and_rebased_item_offsets(twin, curve):
+    """A wire-form batch in which no item has a message may pass msg_byte_off = NULL, and item offsets need not start at
+    zero: the library must not index the (absent) byte offsets with the caller's first item offset."""
+    suite = bbs.SUITES[curve]
+    n = 3
+    eng = pc.make_engine(curve, pc.gens_for(suite, 1), suite.api_id, twin, sk=11)        # L = 0
+    lib, h = eng.lib, eng.h
+    none8, none64 = ctypes.cast(None, _lib.c_u8p), ctypes.cast(None, _lib.c_u64p)
+    item_off = np.full(n + 1, 1 << 40, dtype=np.uint64)            # empty items, offsets far from zero
+    st = np.full(n, -128, dtype=np.int8)
+    so = np.zeros(n * (eng.fpb + 32), dtype=np.uint8)
+    rc = lib.bbs_sign_wire_batch(h, n, none8, none64, _u64(item_off), none8, none64, _u8(so), st.ctypes.data_as(_lib.c_i8p))
+    assert rc == 0 and (st == 1).all()
+    want = bbs.core_sign(suite, 11, pc.gens_for(suite, 1), b"", [], suite.api_id)
+    from bbs_sign_amd import api
+    assert bytes(so[:eng.fpb + 32]) == api.signature_to_octets(curve, pc.Signature(want.a, want.e))
+    st[:] = -128
+    rc = lib.bbs_verify_wire_batch(h, n, _u8(so), none8, none64, _u64(item_off), none8, none64, st.ctypes.data_as(_lib.c_i8p))
+    assert rc == 0 and (st == 1).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381"])
+def test_rerun_of_a_submitted_job_delivers_the_new_results(twin, curve):
+    """bbs_job_run on a submit-form job followed by bbs_job_wait hands over THAT run's statuses (here: the context's
+    public key changed in between, so every pairing product fails), not the first run's."""
+    suite = bbs.SUITES[curve]
+    L, R, n = 3, 1, 4
+    gens = pc.gens_for(suite, L + 1)
+    eng = pc.make_engine(curve, gens, suite.api_id, twin, sk=7)
+    rng = __import__("random").Random(5)
+    msgs = [[rng.randrange(suite.curve.r) for _ in range(L)] for _ in range(n)]
+    disclosed = [[1]] * n
+    rnds = [[rng.randrange(1, suite.curve.r) for _ in range(5 + L - R)] for _ in range(n)]
+    sigs, st = eng.core_sign_batch(msgs)
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    nn, keep, args = eng._pv_inputs(proofs, [[m[1]] for m in msgs], disclosed, None, None)
+    job = eng.submit_packed(nn, args)
+    job.wait()
+    assert (job.result == 1).all()
+    eng.set_public_key(bbs.sk_to_pk(suite, 8))
+    # (context constants reach the device with the next upload)
+    assert list(eng.core_proof_verify_batch(proofs[:1], [[msgs[0][1]]], disclosed[:1])) == [0]
+    job.result[:] = -99
+    job.run()
+    job.wait()
+    assert (job.result == 0).all(), list(job.result)
+    job.free()
+    eng.close()

@@ -5,13 +5,17 @@ set -e -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$ROOT/bbs_sign_amd/build/san}; mkdir -p $OUT
 pids=()
-[ -n "$SKIP_BUILD" ] && [ -f $OUT/libbbs_hosttwin_san_TESTONLY.so ] || for tu in $ROOT/bbs_sign_amd/csrc/*.hip; do
-  hipcc -O1 -g --offload-host-only -x hip -DBBS_HOST_TWIN -DBBS_CHECK_BOUNDS -fPIC -fsanitize=address,undefined \
-        -fno-omit-frame-pointer -fno-sanitize=vptr -c $tu -o $OUT/$(basename $tu .hip).o &
-  pids+=($!)
-done
-for p in "${pids[@]}"; do wait $p; done
-hipcc -shared -fPIC --offload-host-only -fsanitize=address,undefined -shared-libsan $OUT/*.o -o $OUT/libbbs_hosttwin_san_TESTONLY.so
+# SKIP_BUILD=1 with an instrumented library present: neither compile nor link (the objects may be gone)
+if [ -z "$SKIP_BUILD" ] || [ ! -f $OUT/libbbs_hosttwin_san_TESTONLY.so ]; then
+  for tu in $ROOT/bbs_sign_amd/csrc/*.hip; do
+    hipcc -O1 -g --offload-host-only -x hip -DBBS_HOST_TWIN -DBBS_CHECK_BOUNDS -fPIC -fsanitize=address,undefined \
+          -fno-omit-frame-pointer -fno-sanitize=vptr -c $tu -o $OUT/$(basename $tu .hip).o &
+    pids+=($!)
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  hipcc -shared -fPIC --offload-host-only -fsanitize=address,undefined -shared-libsan $OUT/*.o -o $OUT/libbbs_hosttwin_san_TESTONLY.so.tmp
+  mv $OUT/libbbs_hosttwin_san_TESTONLY.so.tmp $OUT/libbbs_hosttwin_san_TESTONLY.so
+fi
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cat > $OUT/run_san.py <<PY
 import sys
