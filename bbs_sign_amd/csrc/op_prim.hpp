@@ -19,7 +19,7 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
     gens_set = true;
     // fixed-base tables over [P1, Q1, H_1..H_L]
     const int nb = L + 2, W = (256 + win_bits - 1) / win_bits;
-    const size_t per_win = ((size_t)1 << win_bits) - 1;
+    const size_t per_win = (size_t)1 << (win_bits - 1);            // signed digits: |digit| = 1 .. 2^(c-1)
     std::vector<uint32_t> bases((size_t)nb * 2 * N);
     auto put = [&](size_t k, const G1Aff<C>& p) {
         for (int j = 0; j < N; j++) { bases[k * 2 * N + j] = p.x.v[j]; bases[k * 2 * N + N + j] = p.y.v[j]; }
@@ -37,6 +37,8 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
     if (rt::launch<TabEntry<C>>(stream, ta, (size_t)nb * W * per_win)) return BBS_E_HIP;
     if (rt::sync(stream)) return BBS_E_HIP;
     hc.L = L; hc.n_bases = nb; hc.win_bits = win_bits; hc.n_windows = W;
+    for (int j = 0; j < 8; j++) hc.fix_bias[j] = 0;
+    for (int w = 0; w + 1 < W; w++) { const int b = win_bits * w + win_bits - 1; hc.fix_bias[b >> 5] |= 1u << (b & 31); }
     rebuild_hash();
     return BBS_OK;
 }

@@ -60,8 +60,9 @@ struct CtxConsts {
     int L;                       // number of message generators
     int n_bases;                 // L + 2 : P1, Q1, H_1..H_L
     int win_bits;                // c
-    int n_windows;               // ceil(256 / c)
-    const uint32_t* tables;      // [base][window][digit-1][2N] affine Montgomery
+    int n_windows;               // W = ceil(256 / c)
+    uint32_t fix_bias[8];        // K = sum over w < W - 1 of 2^(c w + c - 1): signed-digit recoding of the fixed-base scalars
+    const uint32_t* tables;      // [base][window][|digit| - 1][2N] affine Montgomery, |digit| in 1 .. 2^(c-1)
     uint32_t frob[3][6][2][C::FpP::N];   // xi^(m (p^k - 1)/6), Montgomery (for the lane-sliced Fp12)
     MillerSchedule sched;
     LineTable<C> tab_pk;         // lines of W = pk
@@ -191,6 +192,37 @@ __host__ __device__ inline Fr<C> domain_from_header(const HashCtx& h, const uint
 // chunk f of NFIX handles t in [f*T/NFIX, (f+1)*T/NFIX).
 // (result through `out`, the accumulator a plain local: where this function is not inlined, a named return value is
 // the caller's memory and every addition of the loop would start with a scratch round trip -- DESIGN.md 5 rule 7b)
+// SIGNED digits (round 3): a table holds 2^(c-1) entries per (base, window) instead of 2^c - 1 -- half the memory, half the
+// build time, the same number of additions.  The scalar s < r < 2^255 is biased once, sb = s + K with
+// K = sum_{w < W-1} 2^(c w + c - 1) (no carry chain between windows: one 256-bit addition per scalar); window w < W - 1 then
+// contributes the digit  ((sb >> c w) mod 2^c) - 2^(c-1)  in [-2^(c-1), 2^(c-1) - 1], the top window  sb >> c (W - 1)  in
+// [0, 2^(c-1)] (it holds at most c - 1 bits of s plus the carry), and  sum_w digit_w 2^(c w) = sb - K = s.  A negative
+// digit adds the NEGATED table entry (y -> -y).
+template <class C>
+BBS_HD void fixed_bias_scalar(const CtxConsts<C>& cc, uint32_t* sc) {
+    uint64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cy += (uint64_t)sc[j] + cc.fix_bias[j]; sc[j] = (uint32_t)cy; cy >>= 32; }
+}
+// window w of a biased scalar: |digit| (0 = nothing to add) and its sign
+BBS_HD uint32_t fixed_digit(const uint32_t* sb, int w, int c, int W, bool& neg) {
+    const int bit = w * c;
+    const int li = bit >> 5, sh = bit & 31;
+    uint64_t two = sb[li];
+    if (li + 1 < 8) two |= (uint64_t)sb[li + 1] << 32;
+    const uint32_t half = 1u << (c - 1);
+    uint32_t raw = (uint32_t)(two >> sh);
+    if (w == W - 1) {
+        // top window: the 256 - c (W - 1) <= c remaining bits (nothing is loaded from beyond bit 256).  A canonical scalar
+        // gives raw <= 2^(c-1); clamped so that a non-canonical one could never index past the table
+        neg = false;
+        return raw > half ? half : raw;
+    }
+    raw &= (half << 1) - 1u;
+    neg = raw < half;
+    return neg ? half - raw : raw - half;
+}
+
 template <class C>
 __host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
                                                    int n_terms, int chunk, G1Jac<C>& out) {
@@ -198,25 +230,21 @@ __host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const
     const int W = cc.n_windows, c = cc.win_bits;
     const int T = n_terms * W;
     const int t0 = (int)(((long long)T * chunk) / NFIX), t1 = (int)(((long long)T * (chunk + 1)) / NFIX);
-    const size_t per_win = ((size_t)1 << c) - 1;
+    const size_t per_win = (size_t)1 << (c - 1);
     G1Jac<C> acc = g1j_inf<C>();
     int k_cur = -1;
     uint32_t sc[8];
     // table entry of term t (false: digit 0, nothing to add)
     auto fetch = [&](int t, G1Aff<C>& q) -> bool {
         const int k = t / W, w = t - k * W;
-        if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); k_cur = k; }
-        // digit = bits [w*c, w*c + c) of the scalar
-        const int bit = w * c;
-        const int li = bit >> 5, sh = bit & 31;
-        uint64_t two = sc[li];
-        if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
-        uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
-        if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
+        if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); fixed_bias_scalar<C>(cc, sc); k_cur = k; }
+        bool neg;
+        const uint32_t d = fixed_digit(sc, w, c, W, neg);
         if (d == 0) return false;
         const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
 #pragma unroll
         for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
+        q.y = fe_select<typename C::FpP>(neg, fe_neg<typename C::FpP>(q.y), q.y);
         return true;
     };
     // the entry of term t + 1 is requested before the addition of term t: the (random, HBM) table read of one
@@ -260,7 +288,7 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
     constexpr int N = P::N;
     const int W = cc.n_windows, c = cc.win_bits;
     const int T = n_terms * W;
-    const size_t per_win = ((size_t)1 << c) - 1;
+    const size_t per_win = (size_t)1 << (c - 1);
     auto ld = [&](const uint32_t* a, int slot) {
         G1Aff<C> q;
         const uint32_t* b = a + (size_t)slot * 2 * N * n + i;
@@ -277,16 +305,12 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
     // depends on them but the store behind them: four are in flight at a time (a load -> store chain per entry would pay
     // the full memory latency 442 times per item)
     {
-        auto entry = [&](int t) -> const uint32_t* {
+        auto entry = [&](int t, bool& neg) -> const uint32_t* {
             const int k = t / W, w = t - k * W;
             uint32_t sc[8];
             soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc);
-            const int bit = w * c;
-            const int li = bit >> 5, sh = bit & 31;
-            uint64_t two = sc[li];
-            if (li + 1 < 8) two |= (uint64_t)sc[li + 1] << 32;
-            uint32_t d = (uint32_t)(two >> sh) & (uint32_t)per_win;
-            if (bit + c > 256) d &= (1u << (256 - bit)) - 1u;
+            fixed_bias_scalar<C>(cc, sc);
+            const uint32_t d = fixed_digit(sc, w, c, W, neg);
             return d ? cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N) : nullptr;
         };
         constexpr int G = 4;
@@ -295,10 +319,12 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 q[g] = g1a_inf<C>();
-                const uint32_t* e = t0 + g < T ? entry(t0 + g) : nullptr;
+                bool neg = false;
+                const uint32_t* e = t0 + g < T ? entry(t0 + g, neg) : nullptr;
                 if (e) {
 #pragma unroll
                     for (int j = 0; j < N; j++) { q[g].x.v[j] = e[j]; q[g].y.v[j] = e[N + j]; }
+                    q[g].y = fe_select<P>(neg, fe_neg<P>(q[g].y), q[g].y);
                 }
             }
 #pragma unroll
@@ -768,7 +794,7 @@ struct TabArgs {
     int n_bases, win_bits, n_windows;
     const uint32_t* bases;    // [n_bases][2N] Montgomery affine (AoS)
     uint32_t* winbase;        // [n_bases][W][2N] : 2^(c*w) * G_k
-    uint32_t* tables;         // [n_bases][W][2^c - 1][2N]
+    uint32_t* tables;         // [n_bases][W][2^(c-1)][2N]
 };
 
 // lane per base: the W window bases by repeated doubling
@@ -793,7 +819,7 @@ template <class C>
 struct TabEntry {
     static __host__ __device__ void run(const TabArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
-        const size_t per_win = ((size_t)1 << a.win_bits) - 1;
+        const size_t per_win = (size_t)1 << (a.win_bits - 1);        // |digit| = 1 .. 2^(c-1) (signed digits)
         const size_t kw = t / per_win;
         const uint32_t d = (uint32_t)(t - kw * per_win) + 1;
         const uint32_t* bsrc = a.winbase + kw * 2 * N;

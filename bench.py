@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--total", type=int, default=65536, help="mixed65536 only: length of the list (8192 = one rank's share "
                     "of the 65 536-item list at 8 GPUs, to rehearse the strong-scaling regime on one GPU)")
     ap.add_argument("--min-batch", type=int, default=None, help="mixed65536 only: smallest job a rank's share is cut into")
+    ap.add_argument("--latency-mode", type=int, default=None, help="mixed65536 only, A/B: bbs_ctx_set_latency_mode on (1) / off (0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sign/verify/proof_gen/BN254 figures")
     ap.add_argument("--fixed-base-tree", type=int, default=None, help="A/B: bbs_ctx_set_fixed_base_tree on (1) / off (0); default = the library's")

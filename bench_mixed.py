@@ -27,6 +27,8 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
     engines, suites = {}, {}
     for curve, w in (("bls12_381", args.window_bits), ("bn254", min(args.window_bits, 16))):
         suites[curve], engines[curve], _, _ = pc.bench_engine(curve, L, lib_path, w, device=local_rank)
+        if getattr(args, "latency_mode", None) is not None:
+            engines[curve].set_latency_mode(bool(args.latency_mode))
     expect = [0 if i % 16 == 0 else 1 for i in range(total)]
 
     def fetch_items(curve, ids):
