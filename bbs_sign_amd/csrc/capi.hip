@@ -263,7 +263,8 @@ int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched) {
 }
 int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled) {
     if (!ctx) return BBS_E_ARG;
-    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->latency_mode = enabled != 0; else AS_BN(ctx)->latency_mode = enabled != 0;
+    if (enabled < 0 || enabled > 2) return BBS_E_ARG;
+    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->latency_mode = enabled; else AS_BN(ctx)->latency_mode = enabled;
     return BBS_OK;
 }
 int bbs_ctx_set_fixed_base_tree(bbs_ctx* ctx, int enabled) {

@@ -66,7 +66,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     a.n = n; a.L = L; a.Rmax = (int)Lw; a.cc = ctx->d_consts.template as<CtxConsts<C>>();
     // wire form: every point has passed the subgroup check of the decoder, the GLV split needs no vouching
     a.glv = (C::K::HAS_GLV && (C::K::GLV_ALWAYS || ctx->points_in_subgroup || wire)) ? 1 : 0;
-    a.nvar = ctx->latency_mode ? PV_NVAR_SPLIT : PV_NVAR;
+    a.nvar = job->latency_form ? PV_NVAR_SPLIT : PV_NVAR;
     uint32_t* pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * nn, rc);
     uint32_t* sc = job->template scratch<uint32_t>((size_t)4 * 8 * nn, rc);
     uint32_t* slots = job->template scratch<uint32_t>(Lw * 8 * nn, rc);

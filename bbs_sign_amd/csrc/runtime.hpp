@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -399,8 +400,13 @@ struct Ctx : bbs_ctx {
     // caller vouches that every G1 input is in the prime-order subgroup: variable-base multiplications of the
     // verification paths use the GLV split where the curve has it (g1.hpp); off by default
     bool points_in_subgroup = false;
-    // proof_verify: the three terms of T1 on three lanes instead of one joint chain (shorter critical lane, more work)
-    bool latency_mode = false;
+    // latency form of a job (bbs_ctx_set_latency_mode): proof_verify's T1 as three multiplications on three lanes instead
+    // of one joint chain, the two Miller loops of a pairing product on separate lane groups -- a shorter critical path for
+    // more work.  0 = never, 1 = always, 2 = AUTO (default): a job gets the latency form iff at most one other job of
+    // this context is alive when it is created, i.e. when it will have (most of) the chip to itself
+    int latency_mode = 2;
+    std::atomic<int> live_jobs{0};
+    bool latency_form_now() const { return latency_mode == 1 || (latency_mode == 2 && live_jobs.load() <= 2); }
     bool fix_tree = false;           // bbs_ctx_set_fixed_base_tree: the fixed-base sums as trees of affine additions
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
@@ -634,8 +640,14 @@ struct JobBase : bbs_job {
     rt::Stream main{}, aux{};
     rt::Event ev_fork{}, ev_join{};
     bool main_ready = false, aux_ready = false;
-    explicit JobBase(Ctx<C>* c) : ctx(c) { main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); timed = c->stage_timing; }
+    bool latency_form = false;       // decided when the job is created (Ctx::latency_form_now)
+    explicit JobBase(Ctx<C>* c) : ctx(c) {
+        main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); timed = c->stage_timing;
+        ctx->live_jobs.fetch_add(1);
+        latency_form = ctx->latency_form_now();
+    }
     ~JobBase() override {
+        ctx->live_jobs.fetch_sub(1);
         (void)ctx->use();            // streams and buffers go back to this device's pools
         if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
         if (main_ready) { rt::sync(main); rt::stream_destroy(main); }
@@ -811,6 +823,12 @@ void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller
     j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
     j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
 #else
+    if (j->latency_form) {
+        // the two Miller loops of every item on separate wavefronts, then product + final exponentiation (stages.hpp)
+        j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMillerHalf<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 128); }, aux, 0});
+        j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinalDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
+        return;
+    }
     j->stages.push_back({nm_dist, [j, pargs, aux]() { return rt::launch<PairDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
 #endif
 }

@@ -198,9 +198,12 @@ class Engine:
         """bbs_ctx_set_fixed_base_tree: fixed-base sums as one tree of affine additions per item (jobs created afterwards)."""
         self._chk(self.lib.bbs_ctx_set_fixed_base_tree(self.h, 1 if enabled else 0), "bbs_ctx_set_fixed_base_tree")
 
-    def set_latency_mode(self, enabled: bool):
-        """bbs_ctx_set_latency_mode: proof_verify's T1 as three multiplications on three lanes (one batch at a time)."""
-        self._chk(self.lib.bbs_ctx_set_latency_mode(self.h, 1 if enabled else 0), "bbs_ctx_set_latency_mode")
+    def set_latency_mode(self, enabled):
+        """bbs_ctx_set_latency_mode: the latency form of a job (T1 as three multiplications on three lanes, the two Miller
+        loops of a pairing product on separate lane groups).  False / 0 = never, True / 1 = always, "auto" / 2 = the
+        library's default: a job gets it when at most one other job of the context is alive."""
+        mode = 2 if enabled in ("auto", 2) else (1 if enabled else 0)
+        self._chk(self.lib.bbs_ctx_set_latency_mode(self.h, mode), "bbs_ctx_set_latency_mode")
 
     def set_batch_verification(self, enabled: bool, seed: Optional[bytes] = None):
         """Opt-in random-linear-combination batch verification for core_proof_verify (include/bbs_sign_amd.h);

@@ -21,15 +21,19 @@ class PackedBatch:
         self.n, self.keep, self.args = eng._pv_inputs(proofs, disclosed_msgs, disclosed_idx, headers, phs)
 
 
-MIN_BATCH = 512      # below this a job's fixed cost (launches, two copies) shows; a multiple of the 64-lane wavefront
+MIN_BATCH = 4096     # measured (tools/mixed_share_sweep.sh, profiles/r03_b_mixed_share_sweep.log): bigger jobs win
 
 
 def batch_size_for(share: int, batch_max: int = 4096, inflight: int = 8, min_batch: int = MIN_BATCH) -> int:
-    """Batch size for one curve's share of a rank.  One 4096-item job fills only 40-60 % of the chip (410 + 640
-    wavefronts of uneven length on 1024 SIMDs): the rate comes from several jobs in flight.  Under strong
-    scaling the share shrinks with the number of ranks (65 536 items / 2 curves / 8 ranks = 4096 = ONE job per curve),
-    so the share is cut into at least `inflight` jobs per curve -- never below `min_batch` items, never above
-    `batch_max` -- and rounded up to whole wavefronts."""
+    """Batch size for one curve's share of a rank: ceil(share / inflight), clamped to [min_batch, batch_max] and rounded
+    up to whole wavefronts.  Under strong scaling the share shrinks with the number of ranks (65 536 items / 2 curves /
+    8 ranks = 4096 = ONE job per curve).  Cutting such a share into many small jobs so that "enough" are in flight is
+    the wrong cure -- measured on one MI355X with a rank's share of the list at 8 GPUs (8192 items): 2 jobs of 4096 ->
+    8.2 ms per step, 4 x 2048 -> 8.9 ms, 8 x 1024 -> 12.4 ms, 16 x 512 -> 17.4 ms: a job's critical path (~6 ms) does not
+    shrink with its size, every job costs the submitting thread ~0.4 ms, and 2 streams x 16 jobs exceed the hardware
+    queues.  What shortens a step with few jobs is the LATENCY FORM of a job (bbs_ctx_set_latency_mode, automatic when
+    at most two jobs of a context are alive).  min_batch therefore defaults to batch_max's 4096; the knob stays for
+    A/B runs (bench.py --min-batch)."""
     if share <= 0:
         return max(1, min(batch_max, min_batch))
     size = -(-share // max(1, inflight))                 # ceil(share / inflight)
@@ -40,9 +44,9 @@ def batch_size_for(share: int, batch_max: int = 4096, inflight: int = 8, min_bat
 def prepare_rank(engines: Dict[str, object], plan_for_rank: Dict[str, List[int]],
                  fetch_items: Callable[[str, Sequence[int]], tuple], batch: int = 4096, inflight: int = 8,
                  min_batch: int = MIN_BATCH) -> List[PackedBatch]:
-    """Cut this rank's share into batches per curve: at most `batch` items, and small enough that every curve's share
-    makes at least `inflight` jobs where the share allows it (batch_size_for).  fetch_items(curve, ids) returns
-    (proofs, disclosed_msgs, disclosed_idx[, headers, phs]) for those global item ids."""
+    """Cut this rank's share into batches per curve (batch_size_for: at most `batch` items, by default as few jobs as
+    that allows).  fetch_items(curve, ids) returns (proofs, disclosed_msgs, disclosed_idx[, headers, phs]) for those
+    global item ids."""
     out = []
     for curve in sorted(plan_for_rank):
         ids = plan_for_rank[curve]
@@ -84,7 +88,7 @@ def run_rank(batches: List[PackedBatch], inflight: int = 8) -> Dict[str, np.ndar
     return out
 
 
-def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> List[int]:
+def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> np.ndarray:
     """One all_gather of int8 statuses (each rank's share in plan order, padded to the largest share), then
     sharding.merge_status.  dist=None: single process."""
     world = len(plan)
@@ -116,7 +120,7 @@ def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, 
 
 
 def proof_verify_mixed(engines, curve_of_item: Sequence[str], fetch_items, world: int = 1, rank: int = 0, dist=None,
-                       device="cpu", batch: int = 4096, inflight: int = 8) -> List[int]:
+                       device="cpu", batch: int = 4096, inflight: int = 8) -> np.ndarray:
     """The whole path for one call: plan, pack, run, gather.  Every rank returns the merged statuses."""
     plan = shard_plan(curve_of_item, world)
     batches = prepare_rank(engines, plan[rank], fetch_items, batch, inflight)

@@ -29,16 +29,32 @@ def shard_plan(curve_of_item: Sequence[str], world: int) -> List[Dict[str, List[
     return plan
 
 
-def merge_status(plan: List[Dict[str, List[int]]], per_rank_status: List[Dict[str, Sequence[int]]], n_items: int) -> List[int]:
-    """Inverse of shard_plan for the gathered per-rank status lists."""
-    out = [None] * n_items
+_INDEX_CACHE = {}
+
+
+def merge_status(plan: List[Dict[str, List[int]]], per_rank_status: List[Dict[str, Sequence[int]]], n_items: int):
+    """Inverse of shard_plan for the gathered per-rank status lists -> numpy int8 array of n_items statuses.  Vectorised
+    (one fancy-index store per rank and curve): every rank merges the WHOLE list after every step, and a Python loop over
+    65 536 items costs more than the GPU spends verifying a rank's share of them at 8 GPUs."""
+    import numpy as np
+    key = id(plan)
+    cached = _INDEX_CACHE.get(key)
+    if cached is None or cached[0] is not plan:            # the id lists as arrays, once per plan
+        if len(_INDEX_CACHE) > 8:
+            _INDEX_CACHE.clear()
+        cached = (plan, [{c: np.asarray(ids, dtype=np.int64) for c, ids in shard.items()} for shard in plan])
+        _INDEX_CACHE[key] = cached
+    index = cached[1]
+    out = np.full(n_items, -128, dtype=np.int8)           # -128 = the library's "undecided": never a result
+    seen = np.zeros(n_items, dtype=bool)
     for r, shard in enumerate(plan):
         for c, ids in shard.items():
-            st = per_rank_status[r][c]
+            st = np.asarray(per_rank_status[r][c], dtype=np.int8)
             if len(st) != len(ids):
                 raise ValueError("rank %d returned %d statuses for %d items" % (r, len(st), len(ids)))
-            for i, s in zip(ids, st):
-                out[i] = int(s)
-    if any(s is None for s in out):
+            if len(ids):
+                out[index[r][c]] = st
+                seen[index[r][c]] = True
+    if not seen.all():
         raise ValueError("items without a status")
     return out

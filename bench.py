@@ -138,6 +138,7 @@ def submit_loop(eng, slots, steps, inflight, first_step=0, collect_times=False):
 def resident_rate(eng, slots_data, n, steps, inflight):
     """Batches already resident in HBM (uploaded, validated, unpacked): kernels only.  -> (proof_verify/s, stage ms)"""
     from bbs_sign_amd import Job
+    eng.set_latency_mode(False)                  # every resident job in the throughput form (AUTO would give the first two the other)
     jobs = [eng.core_proof_verify_upload(*d) for d in slots_data[:inflight]]
     for j in jobs:
         j.run()
@@ -145,10 +146,20 @@ def resident_rate(eng, slots_data, n, steps, inflight):
         j.wait()
     Job.run_many_timed(jobs, len(jobs))
     ms, st = Job.run_many_timed(jobs, steps)
-    one_ms, one_st = jobs[0].run_timed(3, per_stage=True)
     for j in jobs:
         j.free()
-    return n * steps / (ms * 1e-3), {k: v / steps for k, v in st.items()}, one_ms / 3, {k: v / 3 for k, v in one_st.items()}
+    # one batch at a time, in both forms of a job (the library's AUTO picks the latency form for a job that is alone)
+    single = {}
+    for form, mode in (("throughput_form", False), ("latency_form", True)):
+        eng.set_latency_mode(mode)
+        j = eng.core_proof_verify_upload(*slots_data[0])
+        j.run(); j.wait()
+        one_ms, one_st = j.run_timed(3, per_stage=True)
+        assert (j.status() == 1).all()
+        j.free()
+        single[form] = {"ms": one_ms / 3, "proof_verify_per_s": n / (one_ms / 3 * 1e-3), "stage_ms": {k: v / 3 for k, v in one_st.items()}}
+    eng.set_latency_mode("auto")
+    return n * steps / (ms * 1e-3), {k: v / steps for k, v in st.items()}, single
 
 
 def main():
@@ -261,8 +272,8 @@ def main():
 
     # ---- untimed legs ------------------------------------------------------------------------------------------
     slots_data = [(proofs, dm, disclosed)]
-    res_rate, res_stage, single_ms, single_stage = resident_rate(eng, slots_data * n_slots, n, max(32, args.steps // 2), n_slots) \
-        if rank == 0 else (None, None, None, None)
+    res_rate, res_stage, single = resident_rate(eng, slots_data * n_slots, n, max(32, args.steps // 2), n_slots) \
+        if rank == 0 else (None, None, None)
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         from bench_extras import other_ops
@@ -303,7 +314,8 @@ def main():
                          "stage_ms_per_step": res_stage,
                          "note": "the same kernels on batches already uploaded / validated / unpacked in HBM, %d in "
                                  "flight; never the headline" % n_slots},
-            "single_batch": {"ms": single_ms, "proof_verify_per_s": n / (single_ms * 1e-3), "stage_ms": single_stage},
+            "single_batch": dict(single["latency_form"], form="latency form = what the library's AUTO mode gives a job that is alone "
+                                 "on its context (bbs_ctx_set_latency_mode)", throughput_form=single["throughput_form"]),
         }
         if dt < 1.0:
             out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): filling and draining the %d in-flight slots is "

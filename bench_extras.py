@@ -29,7 +29,9 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
             j.free()
         return size * steps / (ms * 1e-3)
 
-    out = {"unit": "items/s; single = one 4096-item resident batch at a time, *_8_in_flight = eight resident batches"}
+    eng.set_latency_mode(False)        # every leg below states its form: throughput unless it says otherwise
+    out = {"unit": "items/s; single = one 4096-item resident batch at a time, *_8_in_flight = eight resident batches; jobs in "
+                   "the throughput form unless a leg says otherwise"}
     bls = {"sign": rate(eng.core_sign_upload(msgs)), "verify": rate(eng.core_verify_upload(sigs, msgs)),
            "proof_gen": rate(eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds)),
            "sign_8_in_flight": rate_k(lambda: eng.core_sign_upload(msgs)),
@@ -56,6 +58,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     cmp_w = {}
     for w in sorted({16, 20} - {args.window_bits}):
         s2, e2, _, _ = pc.bench_engine("bls12_381", L, None, w, device=device)
+        e2.set_latency_mode(False)
         slots2, _ = make_slots(pc, s2, e2, n, L, R, max(1, args.inflight), first_item=0)
         bad, _, _ = submit_loop(e2, slots2, len(slots2), len(slots2))
         assert bad == 0
@@ -276,6 +279,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
 
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
     sb_, eb, _, _ = pc.bench_engine("bn254", L, None, 16, device=device)
+    eb.set_latency_mode(False)
     mb, db, rb = pc.bench_items(sb_, eb, n, L, R, 0)
     sb, st = eb.core_sign_batch(mb)
     assert (st == 1).all()
@@ -309,10 +313,12 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     msweep = {}
     for Lm in (1, 2, 4, 8, 16, 64, 128):
         sm_, em, _, _ = pc.bench_engine("bn254", Lm, None, 16, device=device)
+        em.set_latency_mode(False)
         mm, _, _ = pc.bench_items(sm_, em, n, Lm, min(R, Lm), 0)
         sg, st = em.core_sign_batch(mm)
         assert (st == 1).all()
         msweep["msgs=%d" % Lm] = {"sign": rate(em.core_sign_upload(mm)), "verify": rate(em.core_verify_upload(sg, mm))}
         em.close()
     out["bn254"]["message_count_sweep"] = msweep
+    eng.set_latency_mode("auto")
     return out

@@ -108,11 +108,16 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
  * Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched);
 
-/* Latency mode for core_proof_verify (off by default).  T1 = Bbar*c + Abar*e^ + D*r1^ (src/proof_verify.rs:163-164) is by
- * default ONE joint windowed chain on one lane per item -- the least work, and the longest lane of a batch.  With
- * enabled = 1 the three multiplications run on three lanes and are summed afterwards: the same group element, a
- * critical lane about one third shorter, about 10 % more instructions per batch.  For callers that verify one batch
- * at a time; with several batches in flight the default is faster.  Takes effect for jobs uploaded afterwards. */
+/* Latency form of a job.  A batch can be laid out for the least WORK (the throughput form: T1 = Bbar*c + Abar*e^ + D*r1^,
+ * src/proof_verify.rs:163-164, as ONE joint windowed chain on one lane per item; both Miller loops of an item's pairing
+ * product on one six-lane group with shared squarings) or for the shortest CRITICAL PATH (the latency form: the three
+ * multiplications on three lanes, summed afterwards; the two Miller loops on separate wavefronts, multiplied before the
+ * final exponentiation).  Same group elements and booleans; the latency form is ~25 % shorter for a batch that has the
+ * chip to itself and costs ~15 % more instructions, so it loses once several batches are in flight.
+ *   enabled = 0: never; 1: always; 2: AUTO (the default) -- a job gets the latency form iff at most one other job of this
+ *   context is alive when it is created (upload / submit), i.e. a serving loop that keeps many batches in flight runs in
+ *   the throughput form, a caller that verifies one batch at a time gets the short path without asking.
+ * Takes effect for jobs created afterwards. */
 int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled);
 /* Fixed-base sums (the generators' multiples: B of sign / verify / proof_gen, the fixed part of T2 of proof_verify) as
  * ONE tree of affine additions per item with one shared inversion per level, instead of eight chains of mixed Jacobian

@@ -149,7 +149,7 @@ def test_mixed_list_configs4_one_gpu(total):
     (bench_mixed.run_mixed -> sharding.shard_plan -> mixed.prepare_rank -> packed batches in host buffers ->
     bbs_core_proof_verify_submit with both curves in flight -> gather -> merge_status); every 16th global item is
     corrupted and run_mixed compares the merged statuses of every step with that pattern.  8192 = one rank's share of the
-    list at 8 GPUs (the strong-scaling regime: the share is cut into 512-item jobs)."""
+    list at 8 GPUs (the strong-scaling regime: one job per curve, which the library runs in its latency form)."""
     import argparse
     import json
     import torch
@@ -160,8 +160,8 @@ def test_mixed_list_configs4_one_gpu(total):
     line = json.loads(lines[0])
     assert line["checks"]["merged_statuses_exact_every_step"] is True and line["n_gpus"] == 1
     assert line["config"]["items_per_rank"] == total
-    assert line["config"]["batches_per_rank"] >= 16           # >= 8 jobs per curve
-    assert max(line["config"]["batch_sizes_rank0"]) == (4096 if total == 65536 else 512)
+    assert line["config"]["batches_per_rank"] == total // 4096
+    assert line["config"]["batch_sizes_rank0"] == [4096]
 
 
 def test_bench_starts_its_own_ranks():
@@ -181,3 +181,61 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 8 and line["checks"]["statuses_exact_every_step"] is True
+
+
+# ---- the latency form of a job (T1 on three lanes, the two Miller loops on separate wavefronts): the same cases ----------
+LATENCY = pytest.mark.job_form(True)
+
+
+@LATENCY
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_latency_form_random_batch_and_errors(curve):
+    pc.check_random_batch(curve, None, n=70, L=3, seed=2)
+    pc.check_error_semantics(curve, None)
+    pc.check_verify_octets(curve, None)
+    pc.check_proof_verify_octets(curve, None)
+
+
+@LATENCY
+@pytest.mark.parametrize("curve,window_bits", [("bls12_381", 20), ("bn254", 16)])
+def test_latency_form_full_batch_4096(curve, window_bits):
+    pc.check_big_batch(curve, None, n=4096, L=32, R=8, window_bits=window_bits)
+
+
+@LATENCY
+def test_latency_form_every_item_against_c_oracle():
+    pc.check_batch_vs_c_oracle(None, n=512, window_bits=16, curve="bls12_381")
+
+
+@pytest.mark.job_form(None)
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_auto_form(curve):
+    """The library's default: a job that is alone on its context is laid out in the latency form (pairing as two stages),
+    the third and later live jobs in the throughput form (one fused pairing stage); the statuses are the same."""
+    import ctypes
+    suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload(curve, 130, 6, 2, None, 8)
+    sigs, st = eng.core_sign_batch(msgs)
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    proofs[5].r1_cap = (proofs[5].r1_cap + 1) % suite.curve.r
+    dm = [m[:2] for m in msgs]
+    jobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(4)]
+    eng.lib.bbs_job_stage_name.restype = ctypes.c_char_p
+
+    def names(j):
+        out, k = [], 0
+        while True:
+            nm = eng.lib.bbs_job_stage_name(j.h, k)
+            if not nm:
+                return out
+            out.append(nm.decode()); k += 1
+    assert "pair_final_exp" in names(jobs[0]) and "pair_final_exp" in names(jobs[1])
+    assert "pairing_6lane" in names(jobs[2]) and "pairing_6lane" in names(jobs[3])
+    for j in jobs:
+        j.run()
+    want = [0 if i == 5 else 1 for i in range(130)]
+    for j in jobs:
+        j.wait()
+        assert [int(x) for x in j.status()] == want
+        j.free()
+    eng.close()

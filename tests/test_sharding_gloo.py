@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_items, q):
     passed = torch.tensor([sum(sum(v) for v in mine.values())], dtype=torch.int64)
     dist.all_reduce(passed, op=dist.ReduceOp.SUM)
     if rank == 0:
-        q.put((merge_status(plan, gathered, n_items) == truth, int(passed.item()) == sum(truth)))
+        q.put((merge_status(plan, gathered, n_items).tolist() == truth, int(passed.item()) == sum(truth)))
     dist.destroy_process_group()
 
 
@@ -88,23 +88,22 @@ def _engine_worker(rank, world, port, twin, q):
     dist.destroy_process_group()
 
 
-def test_strong_scaling_plan_keeps_every_rank_busy():
-    """BASELINE configs[4] at 1/2/4/8 ranks: every rank's share of each curve is cut into at least 8 jobs (one
-    4096-item job per curve would be the single-batch regime, 0.6-0.8 M/s per GPU), none below 512 items."""
+def test_strong_scaling_plan():
+    """BASELINE configs[4] at 1/2/4/8 ranks: every rank gets the same number of items of each curve, cut into the fewest
+    jobs of at most 4096 items (measured: smaller jobs are slower, bbs_sign_amd/mixed.py batch_size_for); the knob that
+    cuts a share into `inflight` jobs still works."""
     from bbs_sign_amd.mixed import batch_size_for
     curves = ["bls12_381" if (i & 1) else "bn254" for i in range(65536)]
     for world in (1, 2, 4, 8):
         plan = shard_plan(curves, world)
         for shard in plan:
-            jobs = 0
             for c, ids in shard.items():
+                assert len(ids) == 32768 // world
                 size = batch_size_for(len(ids), 4096, 8)
-                assert 512 <= size <= 4096 and size % 64 == 0
-                jobs_c = -(-len(ids) // size)
-                assert jobs_c >= 8, (world, c, len(ids), size)
-                jobs += jobs_c
-            assert jobs >= 16
-    assert batch_size_for(100, 4096, 8) == 512 and batch_size_for(0, 4096, 8) == 512
+                assert size == 4096
+                assert -(-len(ids) // size) == max(1, 8 // world)
+    assert batch_size_for(4096, 4096, 8, 512) == 512 and batch_size_for(16384, 4096, 8, 512) == 2048
+    assert batch_size_for(100, 4096, 8, 512) == 512 and batch_size_for(0, 4096, 8) == 4096
     assert batch_size_for(9, 5, 3, 5) == 5               # test-sized lists: the cap wins
 
 
