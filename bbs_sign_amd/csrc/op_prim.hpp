@@ -136,24 +136,41 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
         ok &= pack_fe<R>(S, 0, i, scal + i * 32);
         if (!ok) st0[i] = BBS_ST_NONCANONICAL;
     }
-    const size_t n_pad = (n + 3) & ~(size_t)3, T = (size_t)NW * PIP_NB;
-    DevBuf dP, dS, dSt, dPm, dDig, dList, dB, dSeg, dW, dOut;
-    if (dP.alloc(P.bytes()) || dS.alloc(S.bytes()) || dSt.alloc(n + 4) || dPm.alloc((size_t)2 * N * n * 4 + 4) ||
-        dDig.alloc((size_t)NW * n_pad + 4) || dList.alloc((size_t)NW * n * 4 + 4) || dB.alloc((size_t)3 * N * T * 4) ||
-        dSeg.alloc((size_t)3 * N * NW * (PIP_NB / PIP_SEG) * 4) || dW.alloc((size_t)3 * N * NW * 4) || dOut.alloc((size_t)2 * N * 4))
+    const size_t n_pad = (n + 3) & ~(size_t)3;
+    DevBuf dP, dS, dSt, dPm, dDig, dW, dOut;
+    if (dP.alloc(P.bytes()) || dS.alloc(S.bytes()) || dSt.alloc(n + 4) || dPm.alloc((size_t)2 * N * n * 4 + 16) ||
+        dDig.alloc((size_t)NW * n_pad + 4) || dW.alloc((size_t)3 * N * NW * 4) || dOut.alloc((size_t)2 * N * 4))
         return BBS_E_NOMEM;
     if (rt::h2d(dP.p, P.soa().data(), P.bytes(), ctx->stream) || rt::h2d(dS.p, S.soa().data(), S.bytes(), ctx->stream) ||
         rt::h2d(dSt.p, st0.data(), n, ctx->stream) || rt::dmemset(dDig.p, 0, (size_t)NW * n_pad, ctx->stream)) return BBS_E_HIP;
     PipPrep<C> prep{dP.as<uint32_t>(), dPm.as<uint32_t>(), dSt.as<int8_t>(), n};
     PipDigitArgs da{n, n_pad, dS.as<uint32_t>(), dSt.as<int8_t>(), dDig.as<uint8_t>()};
     PipArgs<C> a{};
-    a.n = n; a.n_pad = n_pad; a.M = 1; a.NW = NW; a.pts0 = dPm.as<uint32_t>(); a.pts1 = a.pts0; a.dig = dDig.as<uint8_t>();
-    a.list = dList.as<uint32_t>(); a.buckets = dB.as<uint32_t>(); a.segs = dSeg.as<uint32_t>(); a.wins = dW.as<uint32_t>();
-    a.out = dOut.as<uint32_t>();
-    if (rt::launch<PipPrep<C>>(ctx->stream, prep, n) || rt::launch<PipDigits>(ctx->stream, da, n) ||
-        rt::launch<PipBuckets<C>>(ctx->stream, a, T) || rt::launch<PipSegments<C>>(ctx->stream, a, (size_t)NW * (PIP_NB / PIP_SEG)) ||
+    a.n = n; a.n_pad = n_pad; a.M = 1; a.NW = NW; a.ppts = dPm.as<uint32_t>(); a.dig = dDig.as<uint8_t>();
+    a.wins = dW.as<uint32_t>(); a.out = dOut.as<uint32_t>();
+    if (rt::launch<PipPrep<C>>(ctx->stream, prep, n) || rt::launch<PipDigits>(ctx->stream, da, n)) return BBS_E_HIP;
+#ifdef BBS_HOST_TWIN
+    const size_t T = (size_t)NW * PIP_NB;
+    DevBuf dList, dB, dSeg;
+    if (dList.alloc((size_t)NW * n * 4 + 4) || dB.alloc((size_t)3 * N * T * 4) || dSeg.alloc((size_t)3 * N * NW * (PIP_NB / PIP_SEG) * 4)) return BBS_E_NOMEM;
+    a.list = dList.as<uint32_t>(); a.buckets = dB.as<uint32_t>(); a.segs = dSeg.as<uint32_t>();
+    if (rt::launch<PipBuckets<C>>(ctx->stream, a, T) || rt::launch<PipSegments<C>>(ctx->stream, a, (size_t)NW * (PIP_NB / PIP_SEG)) ||
         rt::launch<PipWindows<C>>(ctx->stream, a, (size_t)NW) || rt::launch<PipFinal<C>>(ctx->stream, a, 1) || rt::sync(ctx->stream))
         return BBS_E_HIP;
+#else
+    // the workgroup-cooperative kernel (pippenger.hpp): one workgroup per (window, tile of 4096 items), then the tiles'
+    // window sums shifted by 2^(8 w) and added
+    PipCoopArgs<C> co{};
+    co.n = n; co.n_pad = n_pad; co.M = 1; co.NW = NW; co.n_tiles = (int)((std::max<size_t>(n, 1) + PIP_TILE - 1) / PIP_TILE);
+    co.ppts = dPm.as<uint32_t>(); co.dig = dDig.as<uint8_t>();
+    DevBuf dTile;
+    if (dTile.alloc((size_t)3 * N * NW * co.n_tiles * 4)) return BBS_E_NOMEM;
+    co.tile_sums = dTile.as<uint32_t>();
+    PipTileSumArgs<C> ts{1, NW, n ? co.n_tiles : 0, 1, co.tile_sums, nullptr, a.wins};
+    if (rt::launch_pip_windows<C>(ctx->stream, co) || rt::launch<PipTileSums<C>>(ctx->stream, ts, (size_t)NW) ||
+        rt::launch<PipFinal<C>>(ctx->stream, a, 1) || rt::sync(ctx->stream))
+        return BBS_E_HIP;
+#endif
     std::vector<uint32_t> w((size_t)2 * N);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
     if (!statuses_final(status, n)) return BBS_E_STATE;

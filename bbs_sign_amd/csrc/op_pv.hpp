@@ -133,23 +133,26 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
-    j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
     if (!ctx->batch_verify) {
         // every item its own pairing product, on the job's second stream concurrently with the MSM / challenge
-        // stages: it needs only the proof's own points (canonical, converted in the kernel) and the
-        // host-validated flag
+        // stages: it needs only the proof's own points (canonical, converted in the kernel) and the flag the ingest stage
+        // left.  First in the list: the second stream forks where its first stage stands, i.e. before pv_scalars.
         add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
+        j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
-        // batch verification (pippenger.hpp): one combined pairing check over the items whose challenge matched;
-        // if it fails, the per-item kernel decides (its lanes return at once when the combined check passed)
-        pa.gate_arr = a.status; pa.gate = ST_PAIRING;                            // fallback: items still pending
+        // batch verification (pippenger.hpp): the combined pairing checks over the structurally valid items run on the
+        // second stream beside the MSM / challenge stages (they too need only the proof's own points); if one fails, the
+        // per-item kernel decides the items still pending (its lanes return at once otherwise)
+        if ((rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
+                                           job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1))) return rc;
+        j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
-        // a_bar, b_bar in Montgomery form, stored by PvMsmPart
-        if ((rc = add_batch_verification<C>(j, &j->bv, ctx, n, a.cc, a.status, a.aff, a.aff + (size_t)2 * N * n, 1, &j->pa))) return rc;
+        pa.gate_arr = a.status; pa.gate = ST_PAIRING;                            // fallback: items still pending
+        add_batch_decision<C>(j, &j->bv, a.status, &j->pa, 1);
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }});
     }
     *out = job.release();

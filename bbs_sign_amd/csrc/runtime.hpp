@@ -810,20 +810,37 @@ inline uint32_t* hash_raw_messages(J* job, Ctx<C>* ctx, const RaggedIn& mb, size
 // =============================================================================================
 template <class C>
 struct BvState {
-    PipArgs<C> pip{};
+    RlcPrepArgs<C> prep{};
+    PipArgs<C> pip{};            // host twin: the lane-per-bucket stages
+    PipCoopArgs<C> coop{};       // device: the workgroup-cooperative kernel
+    PipTileSumArgs<C> tsum{};
     RlcArgs rlc{};
     PairArgs<C> pa_sum{};
 };
 
-// one pairing product check as stages on the job's main (aux = 0) or second stream
+#if !defined(BBS_HOST_TWIN)
+namespace rt {
+template <class C>
+inline int launch_pip_windows(Stream& s, const PipCoopArgs<C>& a) {
+    const size_t units = (size_t)a.M * a.NW * a.n_tiles;
+    if (!units || !a.n) return 0;
+    hipLaunchKernelGGL((k_pip_window<C>), dim3((unsigned)units), dim3(PIP_WG), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+}  // namespace rt
+#endif
+
+// one pairing product check as stages on the job's main (aux = 0) or second stream.  split: the two Miller loops of an
+// item on separate wavefronts and the final exponentiation as its own stage (the job's latency form; always for the
+// sixteen combined checks of batch verification, which are the narrow tail of their job)
 template <class C, class J>
-void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist) {
-    (void)nm_miller; (void)nm_final; (void)nm_dist;
+void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist, bool force_split = false) {
+    (void)nm_miller; (void)nm_final; (void)nm_dist; (void)force_split;
 #ifdef BBS_HOST_TWIN
     j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
     j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
 #else
-    if (j->latency_form) {
+    if (j->latency_form || force_split) {
         // the two Miller loops of every item on separate wavefronts, then product + final exponentiation (stages.hpp)
         j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMillerHalf<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 128); }, aux, 0});
         j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinalDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
@@ -833,26 +850,23 @@ void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller
 #endif
 }
 
-// Stages of the combined check over the items whose status is 2: coefficients, bucket-method sums of the two point
-// sets (Montgomery affine, [2N][n] each) per 8-bit window, 16 pairing products e(sum_w pts0, pk) e(+-sum_w pts1, BP2)
-// side by side, and -- only for what is still pending afterwards -- the per-item kernel `fallback` (gate: status == 2).
+// Batch verification (pippenger.hpp), in two parts so that a job can place them on different streams:
+//   add_batch_combination : RlcPrep (coefficients, the two point sets item-major), the bucket-method sums of both sets per
+//                           8-bit window, and the 16 pairing products  e(sum_w pts0, pk) e(+-sum_w pts1, BP2)  side by side
+//                           -- on the job's second stream (aux = 1: proof_verify, whose points are inputs) or on the main one;
+//   add_batch_decision    : (main stream; joins the second) if all 16 products are 1, every item still at ST_PAIRING becomes
+//                           Ok(true); otherwise the per-item kernel `fallback` (gate: status == ST_PAIRING) decides them.
 template <class C, class J>
-int add_batch_verification(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const CtxConsts<C>* cc, int8_t* status,
-                           const uint32_t* pts0, const uint32_t* pts1, int negate_b, PairArgs<C>* fallback) {
+int add_batch_combination(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const CtxConsts<C>* cc, const uint32_t* pa, const uint32_t* pb,
+                          int canonical, const int8_t* gate_arr, int gate, int negate_b, int aux) {
     constexpr int N = C::FpP::N;
     constexpr int NW = 16, M = 2;
-    const size_t n_pad = (n + 3) & ~(size_t)3;
+    const size_t n_pad = (n + 3) & ~(size_t)3, nn = std::max<size_t>(n, 1);
     int rc = BBS_OK;
-    PipArgs<C>& pp = bv->pip;
-    RlcArgs& rl = bv->rlc;
-    pp.n = n; pp.n_pad = n_pad; pp.M = M; pp.NW = NW; pp.pts0 = pts0; pp.pts1 = pts1;
+    RlcPrepArgs<C>& pr = bv->prep;
     uint8_t* dig = j->template scratch<uint8_t>((size_t)NW * n_pad + 4, rc);
-    pp.dig = dig;
-    pp.list = j->template scratch<uint32_t>((size_t)M * NW * std::max<size_t>(n, 1), rc);
-    pp.buckets = j->template scratch<uint32_t>((size_t)3 * N * M * NW * PIP_NB, rc);
-    pp.segs = j->template scratch<uint32_t>((size_t)3 * N * M * NW * (PIP_NB / PIP_SEG), rc);
-    pp.wins = j->template scratch<uint32_t>((size_t)3 * N * M * NW, rc);
-    pp.out = j->template scratch<uint32_t>((size_t)M * 2 * N * NW, rc);          // [M][2N][NW]: NW affine sums per set
+    uint32_t* ppts = j->template scratch<uint32_t>((size_t)M * nn * 2 * N, rc);
+    uint32_t* out = j->template scratch<uint32_t>((size_t)M * 2 * N * NW, rc);          // [M][2N][NW]: NW affine sums per set
     // [0 .. NW) gates of the NW combined checks (all 1), [NW .. 2 NW) their results
     std::vector<int8_t> fl(2 * NW, 0);
     for (int k = 0; k < NW; k++) fl[k] = 1;
@@ -860,17 +874,43 @@ int add_batch_verification(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const Ct
     uint32_t* fm_sum = j->template scratch<uint32_t>((size_t)2 * 12 * N * NW, rc);
     if (rc) return rc;
     if (rt::dmemset(dig, 0, (size_t)NW * n_pad, j->stream())) return BBS_E_HIP;
-    rl.n = n; rl.n_pad = n_pad; rl.status = status; rl.dig = dig; rl.batch_ok = flags + NW; rl.n_checks = NW;
-    ctx->next_rlc_seed(rl.seed);
+    j->zero_on_reset.push_back({flags + NW, (size_t)NW});          // a combined check that never ran reads as failed
+    pr.n = n; pr.n_pad = n_pad; pr.pa = pa; pr.pb = pb; pr.canonical = canonical; pr.gate_arr = gate_arr; pr.gate = gate;
+    pr.dig = dig; pr.ppts = ppts;
+    ctx->next_rlc_seed(pr.seed);
+    bv->rlc.batch_ok = flags + NW; bv->rlc.n_checks = NW;
     PairArgs<C>& ps = bv->pa_sum;
-    ps.n = NW; ps.cc = cc; ps.pa = pp.out; ps.pb = pp.out + (size_t)2 * N * NW; ps.negate_b = negate_b; ps.canonical = 0;
+    ps.n = NW; ps.cc = cc; ps.pa = out; ps.pb = out + (size_t)2 * N * NW; ps.negate_b = negate_b; ps.canonical = 0;
     ps.gate_arr = flags; ps.gate = 1; ps.out = flags + NW; ps.fmiller = fm_sum;
-    j->stages.push_back({"rlc_scalars", [j, bv]() { return rt::launch<RlcScalars>(j->stream(), bv->rlc, j->n); }});
-    j->stages.push_back({"pip_buckets", [j, bv]() { return rt::launch<PipBuckets<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * PIP_NB); }});
-    j->stages.push_back({"pip_segments", [j, bv]() { return rt::launch<PipSegments<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * (PIP_NB / PIP_SEG)); }});
-    j->stages.push_back({"pip_window_sums", [j, bv]() { return rt::launch<PipWindowSums<C>>(j->stream(), bv->pip, (size_t)bv->pip.M * bv->pip.NW); }});
-    add_pairing_stages<C>(j, &bv->pa_sum, 0, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane");
-    j->stages.push_back({"rlc_apply", [j, bv]() { return rt::launch<RlcApply>(j->stream(), bv->rlc, j->n); }});
-    add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");
+    auto strm = [j, aux]() -> rt::Stream& { return aux ? j->stream_aux() : j->stream(); };
+    j->stages.push_back({"rlc_prep", [j, bv, strm]() { return rt::launch<RlcPrep<C>>(strm(), bv->prep, j->n); }, aux, 0});
+#ifdef BBS_HOST_TWIN
+    PipArgs<C>& pp = bv->pip;
+    pp.n = n; pp.n_pad = n_pad; pp.M = M; pp.NW = NW; pp.ppts = ppts; pp.dig = dig; pp.out = out;
+    pp.list = j->template scratch<uint32_t>((size_t)M * NW * nn, rc);
+    pp.buckets = j->template scratch<uint32_t>((size_t)3 * N * M * NW * PIP_NB, rc);
+    pp.segs = j->template scratch<uint32_t>((size_t)3 * N * M * NW * (PIP_NB / PIP_SEG), rc);
+    pp.wins = j->template scratch<uint32_t>((size_t)3 * N * M * NW, rc);
+    if (rc) return rc;
+    j->stages.push_back({"pip_buckets", [bv, strm]() { return rt::launch<PipBuckets<C>>(strm(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * PIP_NB); }, aux, 0});
+    j->stages.push_back({"pip_segments", [bv, strm]() { return rt::launch<PipSegments<C>>(strm(), bv->pip, (size_t)bv->pip.M * bv->pip.NW * (PIP_NB / PIP_SEG)); }, aux, 0});
+    j->stages.push_back({"pip_window_sums", [bv, strm]() { return rt::launch<PipWindowSums<C>>(strm(), bv->pip, (size_t)bv->pip.M * bv->pip.NW); }, aux, 0});
+#else
+    PipCoopArgs<C>& co = bv->coop;
+    co.n = n; co.n_pad = n_pad; co.M = M; co.NW = NW; co.n_tiles = (int)((nn + PIP_TILE - 1) / PIP_TILE); co.ppts = ppts; co.dig = dig;
+    co.tile_sums = j->template scratch<uint32_t>((size_t)3 * N * M * NW * co.n_tiles, rc);
+    if (rc) return rc;
+    PipTileSumArgs<C>& ts = bv->tsum;
+    ts.M = M; ts.NW = NW; ts.n_tiles = n ? co.n_tiles : 0; ts.shift = 0; ts.tile_sums = co.tile_sums; ts.out = out; ts.wins = nullptr;
+    j->stages.push_back({"pip_windows", [bv, strm]() { return rt::launch_pip_windows<C>(strm(), bv->coop); }, aux, 0});
+    j->stages.push_back({"pip_tile_sums", [bv, strm]() { return rt::launch<PipTileSums<C>>(strm(), bv->tsum, (size_t)bv->tsum.M * bv->tsum.NW); }, aux, 0});
+#endif
+    add_pairing_stages<C>(j, &bv->pa_sum, aux, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane", true);
     return BBS_OK;
+}
+template <class C, class J>
+void add_batch_decision(J* j, BvState<C>* bv, int8_t* status, PairArgs<C>* fallback, int joins_aux) {
+    bv->rlc.n = j->n; bv->rlc.status = status;
+    j->stages.push_back({"rlc_apply", [j, bv]() { return rt::launch<RlcApply>(j->stream(), bv->rlc, j->n); }, 0, joins_aux});
+    add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");
 }
