@@ -166,6 +166,7 @@ int msm_pippenger(Ctx<C>* ctx, size_t n, const uint8_t* pts, const uint8_t* scal
     DevBuf dTile;
     if (dTile.alloc((size_t)3 * N * NW * co.n_tiles * 4)) return BBS_E_NOMEM;
     co.tile_sums = dTile.as<uint32_t>();
+    co.out_aff = nullptr;
     PipTileSumArgs<C> ts{1, NW, n ? co.n_tiles : 0, 1, co.tile_sums, nullptr, a.wins};
     if (rt::launch_pip_windows<C>(ctx->stream, co) || rt::launch<PipTileSums<C>>(ctx->stream, ts, (size_t)NW) ||
         rt::launch<PipFinal<C>>(ctx->stream, a, 1) || rt::sync(ctx->stream))
@@ -320,7 +321,7 @@ int pairing_batch(Ctx<C>* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, i
     int rc = ctx->sync_consts();
     if (rc) return rc;
     PairPrep<C> pp{dA.as<uint32_t>(), dB.as<uint32_t>(), dAm.as<uint32_t>(), dBm.as<uint32_t>(), dSt.as<int8_t>(), n};
-    PairArgs<C> a;
+    PairArgs<C> a{};
     a.n = n; a.cc = ctx->d_consts.template as<CtxConsts<C>>(); a.pa = dAm.as<uint32_t>(); a.pb = dBm.as<uint32_t>();
     a.negate_b = 0; a.canonical = 0; a.gate_arr = dSt.as<int8_t>(); a.gate = ST_PAIRING; a.out = dSt.as<int8_t>(); a.fmiller = dF.as<uint32_t>();
 #ifdef BBS_HOST_TWIN

@@ -133,27 +133,45 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
+    // the fixed-base lanes compute their own scalars and PvChallenge the domain (no PvScalars launch), except with the
+    // experimental tree of affine additions, whose level-0 gather reads the scalar array
+    a.scal_fly = ctx->fix_tree ? 0 : 1;
+    a.bv_dig = nullptr; a.bv_ppts = nullptr; a.bv_n_pad = 0;
+    auto msm_chain = [j, &a]() {
+        if (!a.scal_fly) j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
+        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
+    };
     if (!ctx->batch_verify) {
         // every item its own pairing product, on the job's second stream concurrently with the MSM / challenge
         // stages: it needs only the proof's own points (canonical, converted in the kernel) and the flag the ingest stage
-        // left.  First in the list: the second stream forks where its first stage stands, i.e. before pv_scalars.
+        // left.  First in the list: the second stream forks where its first stage stands, i.e. before the MSM chain.
         add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
-        j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
-        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
+        msm_chain();
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
-        // batch verification (pippenger.hpp): the combined pairing checks over the structurally valid items run on the
-        // second stream beside the MSM / challenge stages (they too need only the proof's own points); if one fails, the
-        // per-item kernel decides the items still pending (its lanes return at once otherwise)
-        if ((rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
-                                           job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1))) return rc;
-        j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
-        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
-        j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
-        pa.gate_arr = a.status; pa.gate = ST_PAIRING;                            // fallback: items still pending
-        add_batch_decision<C>(j, &j->bv, a.status, &j->pa, 1);
-        j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }});
+        // batch verification (pippenger.hpp): combined pairing checks instead of n products; if one fails, the per-item
+        // kernel decides the items still pending (its lanes write Ok(true) and return at once otherwise).
+        //  * latency form: the combination runs on the job's second stream BESIDE the MSM / challenge stages, over the
+        //    structurally valid items (it needs only the proof's own points) -- the shortest path for a job that is alone;
+        //  * throughput form: the combination FOLLOWS the challenge stage on the one stream, over the items whose challenge
+        //    matched, and the challenge stage itself prepares it (PvChallengeBv).  Six launches per job, one hardware queue:
+        //    small kernels queue behind the long wavefronts of other jobs, so every launch saved is latency saved.
+        const int aux = job->latency_form ? 1 : 0;
+        if (aux && (rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
+                                                  job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1, true))) return rc;
+        msm_chain();
+        if (aux) {
+            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
+        } else {
+            // (a_bar, b_bar in Montgomery form were stored by PvMsmPart; the challenge stage writes digits and points)
+            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallengeBv<C>>(j->stream(), j->a, j->n); }});
+            if ((rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.aff, a.aff + (size_t)2 * N * n, 0, a.status, ST_PAIRING, 1, 0, false))) return rc;
+            a.bv_dig = j->bv.prep.dig; a.bv_ppts = j->bv.prep.ppts; a.bv_n_pad = j->bv.prep.n_pad;
+            std::memcpy(a.bv_seed, j->bv.prep.seed, sizeof(a.bv_seed));
+        }
+        pa.gate_arr = a.status; pa.gate = ST_PAIRING; pa.out = a.status;          // fallback: the items still pending, verdict in place
+        add_batch_decision<C>(j, &j->bv, &j->pa, aux);
     }
     *out = job.release();
     return BBS_OK;

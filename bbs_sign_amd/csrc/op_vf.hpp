@@ -100,7 +100,7 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
         // e(A, W) e(e A - B, BP2) == 1 for all pending items at once: A and e A - B are in a.aff (Montgomery)
         // (the second point is computed by vf_combine, so here the combination follows the MSM chain on the main stream)
         if ((rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.aff, a.aff + (size_t)2 * N * n, 0, a.status, ST_PAIRING, 0, 0))) return rc;
-        add_batch_decision<C>(j, &j->bv, a.status, &j->pa, 0);
+        add_batch_decision<C>(j, &j->bv, &j->pa, 0);
     }
     *out = job.release();
     return BBS_OK;

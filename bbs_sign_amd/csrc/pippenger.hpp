@@ -12,7 +12,8 @@
 //     probability 2^-128 (cofactor components of a point never reach GT: the final exponentiation removes them).
 //     A batch that fails is re-checked item by item with the exact kernel, so the booleans are the reference's.
 //
-// Stages (all lane-per-work-unit functors like the rest of the engine; window c = 8 bits, digits in HBM as bytes):
+// Host-twin stages (lane-per-work-unit functors; window c = 8 bits, digits in HBM as bytes) -- the device runs the
+// workgroup-cooperative kernel k_pip_window further down instead of the first three:
 //   PipBuckets : lane per (point set, window, bucket b): scans the window's n digits (every lane of a wavefront
 //                reads the same words -> one broadcast load per 4 items), claims its slice of the window's index
 //                list (offset = number of smaller non-zero digits), fills it, then sums its points with mixed
@@ -175,6 +176,7 @@ struct PipCoopArgs {
     const uint32_t* ppts;     // [M][n][2N] Montgomery affine, ITEM-major (one point = 2N consecutive words), (0,0) = identity
     const uint8_t* dig;       // [NW][n_pad]
     uint32_t* tile_sums;      // [3N][M*NW*n_tiles] Jacobian (SoA over the work units)
+    uint32_t* out_aff;        // n_tiles == 1 only, or null: the window sum normalised straight into [M][2N][NW] (no PipTileSums launch)
 };
 
 #if !defined(BBS_HOST_TWIN)
@@ -313,7 +315,8 @@ __global__ void __launch_bounds__(PIP_WG) k_pip_window(PipCoopArgs<C> a) {
     // 5. thread 0: the tile's window sum
     if (b == 0) {
         for (int k = 1; k < 4; k++) acc = g1j_add<C>(acc, g1j_from_lds<C>(s_pt[k]));
-        g1j_store<C>(a.tile_sums, (size_t)a.M * a.NW * a.n_tiles, unit, acc);
+        if (a.out_aff && a.n_tiles == 1) g1a_store_mont<C>(a.out_aff + (size_t)m * 2 * N * a.NW, (size_t)a.NW, (size_t)w, g1j_to_aff<C>(acc));
+        else g1j_store<C>(a.tile_sums, (size_t)a.M * a.NW * a.n_tiles, unit, acc);
     }
 }
 #endif
@@ -346,13 +349,6 @@ struct PipTileSums {
 };
 
 // ---- batch verification glue ------------------------------------------------------------------
-struct RlcArgs {
-    size_t n;
-    int8_t* status;           // ST_PAIRING = every check before the pairing passed
-    const int8_t* batch_ok;   // [n_checks] results of the combined pairing checks
-    int n_checks;
-};
-
 // lane per item, in front of the bucket stage: the item's two points in Montgomery form, item-major, and its sixteen
 // digit bytes  rho_i = first 128 bits of SHA-256(seed || I2OSP(i, 8)).  An item takes part iff gate_arr[i] == gate and
 // (canonical inputs) both points are on the curve; otherwise its digits are 0 and it contributes nothing.
@@ -404,16 +400,6 @@ struct RlcPrep {
         for (int w = 0; w < 16; w++) a.dig[(size_t)w * a.n_pad + i] = (uint8_t)(h[w >> 2] >> (8 * (w & 3)));
         g1a_store_mont<C>(a.ppts + i * 2 * N, 1, 0, p);
         g1a_store_mont<C>(a.ppts + (a.n + i) * 2 * N, 1, 0, q);
-    }
-};
-
-// all combined checks passed: every pending item's pairing product is 1
-struct RlcApply {
-    static __host__ __device__ void run(const RlcArgs& a, size_t i) {
-        if (a.status[i] != ST_PAIRING) return;
-        int ok = 1;
-        for (int k = 0; k < a.n_checks; k++) ok &= (a.batch_ok[k] == 1);
-        if (ok) a.status[i] = 1;
     }
 };
 

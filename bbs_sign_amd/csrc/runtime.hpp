@@ -814,7 +814,8 @@ struct BvState {
     PipArgs<C> pip{};            // host twin: the lane-per-bucket stages
     PipCoopArgs<C> coop{};       // device: the workgroup-cooperative kernel
     PipTileSumArgs<C> tsum{};
-    RlcArgs rlc{};
+    const int8_t* batch_ok = nullptr;      // [n_checks] verdicts of the combined checks
+    int n_checks = 0;
     PairArgs<C> pa_sum{};
 };
 
@@ -834,8 +835,11 @@ inline int launch_pip_windows(Stream& s, const PipCoopArgs<C>& a) {
 // item on separate wavefronts and the final exponentiation as its own stage (the job's latency form; always for the
 // sixteen combined checks of batch verification, which are the narrow tail of their job)
 template <class C, class J>
-void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist, bool force_split = false) {
+void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist, bool force_split = false,
+                        int join_first = 0) {       // join_first: the (main-stream) first stage waits for the second stream
     (void)nm_miller; (void)nm_final; (void)nm_dist; (void)force_split;
+    const size_t first = j->stages.size();
+    struct JoinFirst { J* j; size_t first; int join; ~JoinFirst() { if (join && j->stages.size() > first) j->stages[first].join = 1; } } jf{j, first, join_first};
 #ifdef BBS_HOST_TWIN
     j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
     j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
@@ -854,11 +858,11 @@ void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller
 //   add_batch_combination : RlcPrep (coefficients, the two point sets item-major), the bucket-method sums of both sets per
 //                           8-bit window, and the 16 pairing products  e(sum_w pts0, pk) e(+-sum_w pts1, BP2)  side by side
 //                           -- on the job's second stream (aux = 1: proof_verify, whose points are inputs) or on the main one;
-//   add_batch_decision    : (main stream; joins the second) if all 16 products are 1, every item still at ST_PAIRING becomes
-//                           Ok(true); otherwise the per-item kernel `fallback` (gate: status == ST_PAIRING) decides them.
+//   add_batch_decision    : (main stream; joins the second) the per-item kernel `fallback` (gate: status == ST_PAIRING) with the
+//                           16 verdicts: all 1 -> its lanes write Ok(true) and return, otherwise they compute the item's own product.
 template <class C, class J>
 int add_batch_combination(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const CtxConsts<C>* cc, const uint32_t* pa, const uint32_t* pb,
-                          int canonical, const int8_t* gate_arr, int gate, int negate_b, int aux) {
+                          int canonical, const int8_t* gate_arr, int gate, int negate_b, int aux, bool with_prep = true) {
     constexpr int N = C::FpP::N;
     constexpr int NW = 16, M = 2;
     const size_t n_pad = (n + 3) & ~(size_t)3, nn = std::max<size_t>(n, 1);
@@ -878,12 +882,13 @@ int add_batch_combination(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const Ctx
     pr.n = n; pr.n_pad = n_pad; pr.pa = pa; pr.pb = pb; pr.canonical = canonical; pr.gate_arr = gate_arr; pr.gate = gate;
     pr.dig = dig; pr.ppts = ppts;
     ctx->next_rlc_seed(pr.seed);
-    bv->rlc.batch_ok = flags + NW; bv->rlc.n_checks = NW;
+    bv->batch_ok = flags + NW; bv->n_checks = NW;
     PairArgs<C>& ps = bv->pa_sum;
     ps.n = NW; ps.cc = cc; ps.pa = out; ps.pb = out + (size_t)2 * N * NW; ps.negate_b = negate_b; ps.canonical = 0;
     ps.gate_arr = flags; ps.gate = 1; ps.out = flags + NW; ps.fmiller = fm_sum;
     auto strm = [j, aux]() -> rt::Stream& { return aux ? j->stream_aux() : j->stream(); };
-    j->stages.push_back({"rlc_prep", [j, bv, strm]() { return rt::launch<RlcPrep<C>>(strm(), bv->prep, j->n); }, aux, 0});
+    // with_prep = false: the caller's own stage writes the digits and the item-major points (proof_verify's PvChallengeBv)
+    if (with_prep) j->stages.push_back({"rlc_prep", [j, bv, strm]() { return rt::launch<RlcPrep<C>>(strm(), bv->prep, j->n); }, aux, 0});
 #ifdef BBS_HOST_TWIN
     PipArgs<C>& pp = bv->pip;
     pp.n = n; pp.n_pad = n_pad; pp.M = M; pp.NW = NW; pp.ppts = ppts; pp.dig = dig; pp.out = out;
@@ -902,15 +907,17 @@ int add_batch_combination(J* j, BvState<C>* bv, Ctx<C>* ctx, size_t n, const Ctx
     if (rc) return rc;
     PipTileSumArgs<C>& ts = bv->tsum;
     ts.M = M; ts.NW = NW; ts.n_tiles = n ? co.n_tiles : 0; ts.shift = 0; ts.tile_sums = co.tile_sums; ts.out = out; ts.wins = nullptr;
+    co.out_aff = (n && co.n_tiles == 1) ? out : nullptr;      // one tile: the kernel's thread 0 normalises the window sum itself
     j->stages.push_back({"pip_windows", [bv, strm]() { return rt::launch_pip_windows<C>(strm(), bv->coop); }, aux, 0});
-    j->stages.push_back({"pip_tile_sums", [bv, strm]() { return rt::launch<PipTileSums<C>>(strm(), bv->tsum, (size_t)bv->tsum.M * bv->tsum.NW); }, aux, 0});
+    if (!co.out_aff)
+        j->stages.push_back({"pip_tile_sums", [bv, strm]() { return rt::launch<PipTileSums<C>>(strm(), bv->tsum, (size_t)bv->tsum.M * bv->tsum.NW); }, aux, 0});
 #endif
     add_pairing_stages<C>(j, &bv->pa_sum, aux, "rlc_pair_miller", "rlc_pair_final_exp", "rlc_pairing_6lane", true);
     return BBS_OK;
 }
 template <class C, class J>
-void add_batch_decision(J* j, BvState<C>* bv, int8_t* status, PairArgs<C>* fallback, int joins_aux) {
-    bv->rlc.n = j->n; bv->rlc.status = status;
-    j->stages.push_back({"rlc_apply", [j, bv]() { return rt::launch<RlcApply>(j->stream(), bv->rlc, j->n); }, 0, joins_aux});
-    add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane");
+void add_batch_decision(J* j, BvState<C>* bv, PairArgs<C>* fallback, int joins_aux) {
+    // no kernel of its own: the per-item kernel's lanes read the 16 verdicts first -- all passed: write Ok(true) and leave
+    fallback->batch_ok = bv->batch_ok; fallback->n_checks = bv->n_checks;
+    add_pairing_stages<C>(j, fallback, 0, "fallback_pair_miller", "fallback_pair_final_exp", "fallback_pairing_6lane", false, joins_aux);
 }

@@ -223,9 +223,14 @@ BBS_HD uint32_t fixed_digit(const uint32_t* sb, int w, int c, int W, bool& neg) 
     return neg ? half - raw : raw - half;
 }
 
-template <class C>
-__host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
-                                                   int n_terms, int chunk, G1Jac<C>& out) {
+// scalar_of(k, sc): the canonical scalar of base k into sc[8] -- from an array the *Scalars stage filled (FixScalLoad), or
+// computed on the spot (proof_verify: PvScalOnTheFly)
+struct FixScalLoad {
+    const uint32_t* fscal; size_t n, i;
+    BBS_HD void operator()(int k, uint32_t* sc) const { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); }
+};
+template <class C, class SF>
+__host__ __device__ inline void fixed_msm_chunk_sf(const CtxConsts<C>& cc, const SF& scalar_of, int n_terms, int chunk, G1Jac<C>& out) {
     constexpr int N = C::FpP::N;
     const int W = cc.n_windows, c = cc.win_bits;
     const int T = n_terms * W;
@@ -237,7 +242,7 @@ __host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const
     // table entry of term t (false: digit 0, nothing to add)
     auto fetch = [&](int t, G1Aff<C>& q) -> bool {
         const int k = t / W, w = t - k * W;
-        if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); fixed_bias_scalar<C>(cc, sc); k_cur = k; }
+        if (k != k_cur) { scalar_of(k, sc); fixed_bias_scalar<C>(cc, sc); k_cur = k; }
         bool neg;
         const uint32_t d = fixed_digit(sc, w, c, W, neg);
         if (d == 0) return false;
@@ -258,6 +263,11 @@ __host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const
         if (h) acc = g1j_add_aff<C>(acc, q);
     }
     out = acc;
+}
+template <class C>
+__host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
+                                                   int n_terms, int chunk, G1Jac<C>& out) {
+    fixed_msm_chunk_sf<C, FixScalLoad>(cc, FixScalLoad{fscal, n, i}, n_terms, chunk, out);
 }
 template <class C>
 BBS_HD G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i, int n_terms, int chunk) {
@@ -430,6 +440,9 @@ struct PvArgs {
     const CtxConsts<C>* cc;
     int glv;                  // inputs vouched to be in G1: GLV split for the variable-base terms (BLS12-381)
     int nvar;                 // PV_NVAR (throughput: T1 as one joint chain) or PV_NVAR_SPLIT (latency: bbs_ctx_set_latency_mode)
+    int scal_fly;             // 1: no PvScalars stage -- the fixed-base lanes compute their scalars themselves, PvChallenge the domain
+    // batch verification, throughput form: PvChallenge also prepares the combination (RlcPrep of pippenger.hpp) -- null otherwise
+    uint8_t* bv_dig; uint32_t* bv_ppts; size_t bv_n_pad; uint32_t bv_seed[8];
     // inputs (canonical limbs, SoA)
     const uint32_t* pts;      // [3][2NC][n] a_bar, b_bar, d (canonical words)
     const uint32_t* sc;       // [4][8][n]   e_cap, r1_cap, r3_cap, challenge
@@ -569,6 +582,28 @@ struct PvScalars {
     }
 };
 
+template <class C>
+struct PvScalOnTheFly {
+    const PvArgs<C>* a; size_t i;
+    __host__ __device__ void operator()(int k, uint32_t* sc) const {
+        using R = typename C::FrP;
+        const size_t n = a->n;
+        const Fr<C> c_canon = fr_load_canon<C>(a->sc + (size_t)3 * 8 * n, n, i);
+        Fr<C> s = c_canon;
+        if (k == 1) {
+            const Fr<C> dom = domain_from_header<C>(a->cc->hash, a->hdr_bytes + a->hdr_off[i], a->hdr_len[i]);
+            s = fe_mul<R>(dom, c_canon);                           // (dom R) c / R = dom c, canonical
+        } else if (k >= 2) {
+            const int j = k - 2;
+            s = fr_load_canon<C>(a->slots + (size_t)j * 8 * n, n, i);
+            const uint32_t m = a->dmask[(size_t)(j >> 5) * n + i];
+            if ((m >> (j & 31)) & 1u) s = fe_mul<R>(fr_to_mont<C>(c_canon), s);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) sc[w] = s.v[w];
+    }
+};
+
 // stage 2 (lane per (part, item)): MSM parts
 template <class C>
 struct PvMsmPart {
@@ -618,6 +653,13 @@ struct PvMsmPart {
             G1Jac<C> r = g1j_inf<C>();
             if (part == a.nvar) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.L + 2, a.fixwk, r);
             g1j_store<C>(out, n, i, r);
+        } else if (a.scal_fly) {
+            // the scalars of the bases this chunk touches, computed here (what PvScalars would have stored): c for P1,
+            // domain * c for Q1, c * m_i for a disclosed message's generator, the commitment m^_j otherwise
+            // (src/proof_verify.rs:165-182 with Bv * c distributed)
+            G1Jac<C> r;
+            fixed_msm_chunk_sf<C>(*a.cc, PvScalOnTheFly<C>{&a, i}, a.L + 2, part - a.nvar, r);
+            g1j_store<C>(out, n, i, r);
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - a.nvar));
         }
@@ -654,7 +696,8 @@ struct PvChallenge {
         sha256_g1_compressed<C>(s, T1);
         sha256_g1_compressed<C>(s, T2);
         Fr<C> dom;
-        soa_ld<8>(a.dom, n, i, dom.v);
+        if (a.scal_fly) dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
+        else soa_ld<8>(a.dom, n, i, dom.v);
         sha256_fr_be<C>(s, dom);
         sha256_u64be(s, a.ph_len[i]);
         sha256_bytes(s, a.ph_bytes + a.ph_off[i], a.ph_len[i]);
@@ -665,6 +708,31 @@ struct PvChallenge {
         // proof_verify.rs:108-110: mismatch -> Ok(false) before any pairing
         a.status[i] = fe_eq<typename C::FrP>(chal, c) ? ST_PAIRING : (int8_t)0;
     }
+    // batch verification, throughput form: every lane -- also those that left run() early -- then prepares its item's part
+    // of the combination (digits of rho_i, the two points item-major); see RlcPrep in pippenger.hpp
+    static __host__ __device__ void run_with_bv_prep(const PvArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        run(a, i);
+        const size_t n = a.n;
+        uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        G1Aff<C> p = g1a_inf<C>(), q = g1a_inf<C>();
+        if (a.status[i] == ST_PAIRING) {
+            p = g1a_load_mont<C>(a.aff, n, i);
+            q = g1a_load_mont<C>(a.aff + (size_t)2 * N * n, n, i);
+            Sha256 s;
+            sha256_init(s);
+            for (int k = 0; k < 8; k++) sha256_word(s, a.bv_seed[k]);
+            sha256_u64be(s, (uint64_t)i);
+            sha256_final(s, h);
+        }
+        for (int w = 0; w < 16; w++) a.bv_dig[(size_t)w * a.bv_n_pad + i] = (uint8_t)(h[w >> 2] >> (8 * (w & 3)));
+        g1a_store_mont<C>(a.bv_ppts + i * 2 * N, 1, 0, p);
+        g1a_store_mont<C>(a.bv_ppts + (n + i) * 2 * N, 1, 0, q);
+    }
+};
+template <class C>
+struct PvChallengeBv {
+    static __host__ __device__ void run(const PvArgs<C>& a, size_t i) { PvChallenge<C>::run_with_bv_prep(a, i); }
 };
 
 // generic pairing stages: e(Pa, pk) * e(Pb, BP2) == 1 for items whose status is 2
@@ -680,7 +748,18 @@ struct PairArgs {
     int gate;
     int8_t* out;              // result 1 / 0 per item (may alias the status array)
     uint32_t* fmiller;        // [2][12N][n]
+    // batch verification: this launch is the per-item FALLBACK behind the combined checks -- if all n_checks of them passed
+    // (batch_ok[k] == 1), every gated item's product is 1 (error 2^-128) and the lane only writes that; null otherwise
+    const int8_t* batch_ok;
+    int n_checks;
 };
+template <class C>
+BBS_HD bool pair_batch_passed(const PairArgs<C>& a) {
+    if (!a.batch_ok) return false;
+    int ok = 1;
+    for (int k = 0; k < a.n_checks; k++) ok &= (a.batch_ok[k] == 1);
+    return ok != 0;
+}
 
 template <class C>
 BBS_HD G1Aff<C> pair_load_point(const PairArgs<C>& a, const uint32_t* base, size_t i) {
@@ -736,6 +815,7 @@ struct PairMiller {
         const int pair = (int)(t / n);
         const size_t i = t - (size_t)pair * n;
         if (a.gate_arr[i] != a.gate) return;
+        if (pair_batch_passed<C>(a)) return;
         G1Aff<C> P = pair_load_point<C>(a, pair == 0 ? a.pa : a.pb, i);
         if (pair == 1 && a.negate_b) P = g1a_neg<C>(P);
         const LineTable<C>* tab = pair == 0 ? &a.cc->tab_pk : &a.cc->tab_bp2;
@@ -761,6 +841,7 @@ struct PairFinal {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
         if (a.gate_arr[i] != a.gate) return;
+        if (pair_batch_passed<C>(a)) { a.out[i] = 1; return; }
         Fp12<C> f = f12_mul<C>(f12_load<C>(a.fmiller, n, i), f12_load<C>(a.fmiller + (size_t)12 * N * n, n, i));
         a.out[i] = f12_is_one<C>(final_exponentiation<C>(f)) ? 1 : 0;
     }
@@ -1634,6 +1715,7 @@ struct PairDist {
         if (i >= a.n) return;
         if (a.gate_arr[i] != a.gate) return;
         Lane6 L{grp * GRP, lane - grp * GRP};
+        if (pair_batch_passed<C>(a)) { if (L.m == 0) a.out[i] = 1; return; }
         G1Aff<C> Pa = pair_load_point<C>(a, a.pa, i);
         G1Aff<C> Pb = pair_load_point<C>(a, a.pb, i);
         if (a.negate_b) Pb = g1a_neg<C>(Pb);
@@ -1686,6 +1768,7 @@ struct PairMillerHalf {
         const size_t i = (wave >> 1) * GRP_PER_WAVE + grp;
         if (i >= a.n) return;
         if (a.gate_arr[i] != a.gate) return;
+        if (pair_batch_passed<C>(a)) return;                   // PairFinalDist writes the verdict
         Lane6 L{grp * GRP, lane - grp * GRP};
         G1Aff<C> P = pair_load_point<C>(a, pair ? a.pb : a.pa, i);
         if (pair && a.negate_b) P = g1a_neg<C>(P);
@@ -1719,6 +1802,7 @@ struct PairFinalDist {
         if (i >= a.n) return;
         if (a.gate_arr[i] != a.gate) return;
         Lane6 L{grp * GRP, lane - grp * GRP};
+        if (pair_batch_passed<C>(a)) { if (L.m == 0) a.out[i] = 1; return; }
         Fp2<C> g0, g1;
         const uint32_t* p0 = a.fmiller + (size_t)L.m * 2 * N * a.n + i;
         const uint32_t* p1 = a.fmiller + ((size_t)GRP + L.m) * 2 * N * a.n + i;
