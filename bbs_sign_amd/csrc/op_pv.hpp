@@ -133,12 +133,11 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     pa.fmiller = a.fmiller;
     job->fin.n = n; job->fin.status = a.status; job->fin.pair_ok = pair_ok;
     PvJob<C>* j = job.get();
-    // the fixed-base lanes compute their own scalars and PvChallenge the domain (no PvScalars launch), except with the
-    // experimental tree of affine additions, whose level-0 gather reads the scalar array
-    a.scal_fly = ctx->fix_tree ? 0 : 1;
+    // (measured: letting the fixed-base lanes compute their own scalars and dropping the pv_scalars launch costs more than
+    // the launch -- the hash and the Fr products land in the register-critical MSM kernel: 5.14 -> 5.33 ms, scratch 2.7 -> 3.1 KB)
     a.bv_dig = nullptr; a.bv_ppts = nullptr; a.bv_n_pad = 0;
-    auto msm_chain = [j, &a]() {
-        if (!a.scal_fly) j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
+    auto msm_chain = [j]() {
+        j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
     };
     if (!ctx->batch_verify) {

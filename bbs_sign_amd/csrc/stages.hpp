@@ -223,14 +223,9 @@ BBS_HD uint32_t fixed_digit(const uint32_t* sb, int w, int c, int W, bool& neg) 
     return neg ? half - raw : raw - half;
 }
 
-// scalar_of(k, sc): the canonical scalar of base k into sc[8] -- from an array the *Scalars stage filled (FixScalLoad), or
-// computed on the spot (proof_verify: PvScalOnTheFly)
-struct FixScalLoad {
-    const uint32_t* fscal; size_t n, i;
-    BBS_HD void operator()(int k, uint32_t* sc) const { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); }
-};
-template <class C, class SF>
-__host__ __device__ inline void fixed_msm_chunk_sf(const CtxConsts<C>& cc, const SF& scalar_of, int n_terms, int chunk, G1Jac<C>& out) {
+template <class C>
+__host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
+                                                   int n_terms, int chunk, G1Jac<C>& out) {
     constexpr int N = C::FpP::N;
     const int W = cc.n_windows, c = cc.win_bits;
     const int T = n_terms * W;
@@ -242,7 +237,7 @@ __host__ __device__ inline void fixed_msm_chunk_sf(const CtxConsts<C>& cc, const
     // table entry of term t (false: digit 0, nothing to add)
     auto fetch = [&](int t, G1Aff<C>& q) -> bool {
         const int k = t / W, w = t - k * W;
-        if (k != k_cur) { scalar_of(k, sc); fixed_bias_scalar<C>(cc, sc); k_cur = k; }
+        if (k != k_cur) { soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc); fixed_bias_scalar<C>(cc, sc); k_cur = k; }
         bool neg;
         const uint32_t d = fixed_digit(sc, w, c, W, neg);
         if (d == 0) return false;
@@ -263,11 +258,6 @@ __host__ __device__ inline void fixed_msm_chunk_sf(const CtxConsts<C>& cc, const
         if (h) acc = g1j_add_aff<C>(acc, q);
     }
     out = acc;
-}
-template <class C>
-__host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i,
-                                                   int n_terms, int chunk, G1Jac<C>& out) {
-    fixed_msm_chunk_sf<C, FixScalLoad>(cc, FixScalLoad{fscal, n, i}, n_terms, chunk, out);
 }
 template <class C>
 BBS_HD G1Jac<C> fixed_msm_chunk(const CtxConsts<C>& cc, const uint32_t* fscal, size_t n, size_t i, int n_terms, int chunk) {
@@ -440,7 +430,6 @@ struct PvArgs {
     const CtxConsts<C>* cc;
     int glv;                  // inputs vouched to be in G1: GLV split for the variable-base terms (BLS12-381)
     int nvar;                 // PV_NVAR (throughput: T1 as one joint chain) or PV_NVAR_SPLIT (latency: bbs_ctx_set_latency_mode)
-    int scal_fly;             // 1: no PvScalars stage -- the fixed-base lanes compute their scalars themselves, PvChallenge the domain
     // batch verification, throughput form: PvChallenge also prepares the combination (RlcPrep of pippenger.hpp) -- null otherwise
     uint8_t* bv_dig; uint32_t* bv_ppts; size_t bv_n_pad; uint32_t bv_seed[8];
     // inputs (canonical limbs, SoA)
@@ -582,28 +571,6 @@ struct PvScalars {
     }
 };
 
-template <class C>
-struct PvScalOnTheFly {
-    const PvArgs<C>* a; size_t i;
-    __host__ __device__ void operator()(int k, uint32_t* sc) const {
-        using R = typename C::FrP;
-        const size_t n = a->n;
-        const Fr<C> c_canon = fr_load_canon<C>(a->sc + (size_t)3 * 8 * n, n, i);
-        Fr<C> s = c_canon;
-        if (k == 1) {
-            const Fr<C> dom = domain_from_header<C>(a->cc->hash, a->hdr_bytes + a->hdr_off[i], a->hdr_len[i]);
-            s = fe_mul<R>(dom, c_canon);                           // (dom R) c / R = dom c, canonical
-        } else if (k >= 2) {
-            const int j = k - 2;
-            s = fr_load_canon<C>(a->slots + (size_t)j * 8 * n, n, i);
-            const uint32_t m = a->dmask[(size_t)(j >> 5) * n + i];
-            if ((m >> (j & 31)) & 1u) s = fe_mul<R>(fr_to_mont<C>(c_canon), s);
-        }
-#pragma unroll
-        for (int w = 0; w < 8; w++) sc[w] = s.v[w];
-    }
-};
-
 // stage 2 (lane per (part, item)): MSM parts
 template <class C>
 struct PvMsmPart {
@@ -653,13 +620,6 @@ struct PvMsmPart {
             G1Jac<C> r = g1j_inf<C>();
             if (part == a.nvar) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.L + 2, a.fixwk, r);
             g1j_store<C>(out, n, i, r);
-        } else if (a.scal_fly) {
-            // the scalars of the bases this chunk touches, computed here (what PvScalars would have stored): c for P1,
-            // domain * c for Q1, c * m_i for a disclosed message's generator, the commitment m^_j otherwise
-            // (src/proof_verify.rs:165-182 with Bv * c distributed)
-            G1Jac<C> r;
-            fixed_msm_chunk_sf<C>(*a.cc, PvScalOnTheFly<C>{&a, i}, a.L + 2, part - a.nvar, r);
-            g1j_store<C>(out, n, i, r);
         } else {
             g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - a.nvar));
         }
@@ -696,8 +656,7 @@ struct PvChallenge {
         sha256_g1_compressed<C>(s, T1);
         sha256_g1_compressed<C>(s, T2);
         Fr<C> dom;
-        if (a.scal_fly) dom = domain_from_header<C>(a.cc->hash, a.hdr_bytes + a.hdr_off[i], a.hdr_len[i]);
-        else soa_ld<8>(a.dom, n, i, dom.v);
+        soa_ld<8>(a.dom, n, i, dom.v);
         sha256_fr_be<C>(s, dom);
         sha256_u64be(s, a.ph_len[i]);
         sha256_bytes(s, a.ph_bytes + a.ph_off[i], a.ph_len[i]);
