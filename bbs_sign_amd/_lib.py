@@ -22,6 +22,19 @@ ci = ctypes.c_int
 # name -> (restype, argtypes); every symbol include/bbs_sign_amd.h declares
 SIGNATURES = {
     "bbs_fp_bytes": (sz, [ci]),
+    "bbs_issuer_create": (ci, [ci, ci, c_u8p, sz, ctypes.POINTER(vp)]),
+    "bbs_issuer_destroy": (None, [vp]),
+    "bbs_issuer_set_public_key": (ci, [vp, c_u8p, ci]),
+    "bbs_issuer_set_secret_key": (ci, [vp, c_u8p]),
+    "bbs_issuer_set_limits": (ci, [vp, sz, ci]),
+    "bbs_issuer_set_modes": (ci, [vp, ci, ci, ci]),
+    "bbs_issuer_context": (ci, [vp, sz, ctypes.POINTER(vp)]),
+    "bbs_issuer_context_count": (sz, [vp]),
+    "bbs_issuer_proof_verify": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
+    "bbs_issuer_verify": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_i8p]),
+    "bbs_issuer_sign": (ci, [vp, sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p]),
+    "bbs_issuer_proof_gen": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                  c_u8p, c_u64p, c_i8p]),
     "bbs_version": (ctypes.c_char_p, []),
     "bbs_source_hash": (ctypes.c_char_p, []),
     "bbs_runtime_hw_queues": (ci, []),

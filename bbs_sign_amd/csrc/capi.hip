@@ -2,6 +2,7 @@
 #include "ops_decl.hpp"
 #include "host_h2c.hpp"
 #include "host_codec.hpp"
+#include "issuer.hpp"
 
 // Many independent batches are kept in flight, one HIP stream pair each.  The HIP runtime maps the streams of a
 // process onto 4 hardware queues unless told otherwise, and a long narrow kernel then blocks the streams sharing
@@ -248,8 +249,9 @@ int bbs_ctx_create(int curve, int device_id, bbs_ctx** out) {
 void bbs_ctx_destroy(bbs_ctx* ctx) { delete ctx; }
 
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
-    if (!ctx || bits < 4 || bits > 22) return BBS_E_ARG;
-    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->win_bits = bits; else AS_BN(ctx)->win_bits = bits;
+    if (!ctx || (bits != 0 && (bits < 4 || bits > 22))) return BBS_E_ARG;      // 0: chosen from the free device memory at set_generators
+    if (ctx->curve == BBS_CURVE_BLS12_381) { AS_BLS(ctx)->win_bits_requested = bits; if (bits) AS_BLS(ctx)->win_bits = bits; }
+    else { AS_BN(ctx)->win_bits_requested = bits; if (bits) AS_BN(ctx)->win_bits = bits; }
     return BBS_OK;
 }
 int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32) {
@@ -992,6 +994,238 @@ int bbs_selftest_f2dot2(int curve, size_t n_terms, const uint8_t* a, const uint8
     if (curve == BBS_CURVE_BLS12_381) return selftest_f2dot2<BlsCurve>(n_terms, a, b, weights, out);
     if (curve == BBS_CURVE_BN254) return selftest_f2dot2<BnCurve>(n_terms, a, b, weights, out);
     return BBS_E_ARG;
+}
+
+// ---- bbs_issuer: items of any message count in one call (issuer.hpp) --------------------------------------------------
+int bbs_issuer_create(int curve, int device_id, const uint8_t* api_id, size_t api_id_len, bbs_issuer** out) {
+    if (!out || (curve != BBS_CURVE_BLS12_381 && curve != BBS_CURVE_BN254) || (api_id_len && !api_id)) return BBS_E_ARG;
+    if (device_id < 0 || device_id >= bbs_device_count()) return BBS_E_NO_DEVICE;
+    auto* is = new bbs_issuer();
+    is->curve = curve; is->device = device_id;
+    is->api_id.assign(api_id, api_id + api_id_len);
+    *out = is;
+    return BBS_OK;
+}
+void bbs_issuer_destroy(bbs_issuer* is) { delete is; }
+int bbs_issuer_set_public_key(bbs_issuer* is, const uint8_t* pk_affine, int is_identity) {
+    if (!is || (!is_identity && !pk_affine)) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(is->mu);
+    const size_t fpb = bbs_fp_bytes(is->curve);
+    is->pk.assign(4 * fpb, 0);
+    if (!is_identity) std::memcpy(is->pk.data(), pk_affine, 4 * fpb);
+    is->pk_inf = is_identity ? 1 : 0;
+    for (auto& kv : is->by_count) if (int rc = bbs_ctx_set_public_key(kv.second, is->pk.data(), is->pk_inf)) return rc;
+    is->pk_set = true; is->sk_set = false;
+    return BBS_OK;
+}
+int bbs_issuer_set_secret_key(bbs_issuer* is, const uint8_t* sk32) {
+    if (!is || !sk32) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(is->mu);
+    for (auto& kv : is->by_count) if (int rc = bbs_ctx_set_secret_key(kv.second, sk32)) return rc;
+    std::memcpy(is->sk, sk32, 32);
+    is->sk_set = true; is->pk_set = true;
+    return BBS_OK;
+}
+int bbs_issuer_set_limits(bbs_issuer* is, size_t max_messages, int window_bits) {
+    if (!is || (window_bits != 0 && (window_bits < 4 || window_bits > 22))) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(is->mu);
+    is->max_messages = max_messages; is->window_bits = window_bits;
+    return BBS_OK;
+}
+int bbs_issuer_set_modes(bbs_issuer* is, int latency_mode, int batch_verification, int points_in_subgroup) {
+    if (!is || latency_mode < 0 || latency_mode > 2) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(is->mu);
+    is->latency_mode = latency_mode; is->batch_verify = batch_verification != 0; is->in_subgroup = points_in_subgroup != 0;
+    for (auto& kv : is->by_count) {
+        int rc = bbs_ctx_set_latency_mode(kv.second, latency_mode);
+        if (!rc) rc = bbs_ctx_set_batch_verification(kv.second, is->batch_verify, nullptr);
+        if (!rc) rc = bbs_ctx_set_points_in_subgroup(kv.second, is->in_subgroup);
+        if (rc) return rc;
+    }
+    return BBS_OK;
+}
+int bbs_issuer_context(bbs_issuer* is, size_t message_count, bbs_ctx** out) {
+    if (!is || !out) return BBS_E_ARG;
+    return is->context(message_count, out);
+}
+size_t bbs_issuer_context_count(bbs_issuer* is) {
+    if (!is) return 0;
+    std::lock_guard<std::mutex> g(is->mu);
+    return is->by_count.size();
+}
+
+using issuer_detail::Group;
+using issuer_detail::Ragged;
+// items -> groups by message count; items whose count exceeds the issuer's limit get `too_many` and join no group
+static void issuer_group(bbs_issuer* is, size_t n, const std::vector<uint64_t>& count, const std::vector<int8_t>& pre, int8_t* status,
+                         std::map<size_t, Group>& groups) {
+    for (size_t i = 0; i < n; i++) {
+        if (pre[i] != 1) { status[i] = pre[i]; continue; }
+        if (count[i] > is->max_messages) { status[i] = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }
+        Group& g = groups[(size_t)count[i]];
+        g.L = (size_t)count[i];
+        g.items.push_back(i);
+    }
+}
+
+// the reference's PUBLIC proof_verify (src/proof_verify.rs:19-61), every item with the generators of ITS OWN length
+// L_i = U_i + R_i (:40-43): U_i from the length of the proof's octet string, R_i = number of disclosed indexes
+int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const uint64_t* oct_off, const uint8_t* msg_bytes,
+                            const uint64_t* msg_byte_off, const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio,
+                            const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
+    if (!is || !status || (n && (!oct_off || !msg_item_off || !dio))) return BBS_E_ARG;
+    if (!is->pk_set) return BBS_E_STATE;
+    const Ragged ro{oct, oct_off, 1}, rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rh{h, ho, 1}, rp{ph, pho, 1};
+    if (!ro.sane(n) || !rdi.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
+    const size_t fpb = bbs_fp_bytes(is->curve);
+    std::vector<uint64_t> count(n, 0);
+    std::vector<int8_t> pre(n, 1);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t len = ro.count(i), floor_ = 3 * fpb + 4 * 32;
+        // shape of the octet string (what bbs_proof_from_octets checks first): 3 points, 4 + U scalars
+        if (len < floor_ || (len - floor_) % 32) { pre[i] = BBS_ST_INVALID_ENCODING; continue; }
+        count[i] = (len - floor_) / 32 + rdi.count(i);
+    }
+    std::map<size_t, Group> groups;
+    issuer_group(is, n, count, pre, status, groups);
+    int rc = BBS_OK;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        bbs_ctx* c = nullptr;
+        if ((rc = is->context(g.L, &c))) break;
+        g.oct.gather(ro, g.items); g.di.gather(rdi, g.items); g.hdr.gather(rh, g.items); g.ph.gather(rp, g.items);
+        g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
+        g.status.assign(g.items.size(), ST_PENDING);
+        rc = bbs_proof_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.oct.off.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(),
+                                          g.msgs.item_off.data(), reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(),
+                                          g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.status.data(), &g.job);
+        if (rc) break;
+    }
+    if (rc) { issuer_detail::free_jobs(groups); return rc; }
+    if ((rc = issuer_detail::wait_all(groups))) return rc;
+    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
+    return BBS_OK;
+}
+
+// the reference's PUBLIC verify (src/verify.rs:18-50): generators by the item's number of messages (:30-35)
+int bbs_issuer_verify(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                      const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    if (!is || !status || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
+    if (!is->pk_set) return BBS_E_STATE;
+    const Ragged rh{h, ho, 1};
+    if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
+    const size_t so = bbs_fp_bytes(is->curve) + 32;
+    std::vector<uint64_t> count(n);
+    for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
+    std::map<size_t, Group> groups;
+    issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
+    int rc = BBS_OK;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        bbs_ctx* c = nullptr;
+        if ((rc = is->context(g.L, &c))) break;
+        g.oct.data.resize(g.items.size() * so + 8);
+        for (size_t k = 0; k < g.items.size(); k++) std::memcpy(g.oct.data.data() + k * so, sig_octets + g.items[k] * so, so);
+        g.hdr.gather(rh, g.items);
+        g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
+        g.status.assign(g.items.size(), ST_PENDING);
+        rc = bbs_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
+                                    g.hdr.data.data(), g.hdr.off.data(), g.status.data(), &g.job);
+        if (rc) break;
+    }
+    if (rc) { issuer_detail::free_jobs(groups); return rc; }
+    if ((rc = issuer_detail::wait_all(groups))) return rc;
+    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
+    return BBS_OK;
+}
+
+// the reference's PUBLIC sign (src/sign.rs:32-60): generators by the item's number of messages (:44-49); signature octet
+// strings (fp_bytes + 32 each, zeros where status != 1) in the caller's order
+int bbs_issuer_sign(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                    const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status) {
+    if (!is || !status || (n && (!sig_octets_out || !msg_item_off))) return BBS_E_ARG;
+    if (!is->sk_set) return BBS_E_STATE;
+    const Ragged rh{h, ho, 1};
+    if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
+    const size_t so = bbs_fp_bytes(is->curve) + 32;
+    std::vector<uint64_t> count(n);
+    for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
+    std::map<size_t, Group> groups;
+    issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
+    std::memset(sig_octets_out, 0, n * so);
+    int rc = BBS_OK;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        bbs_ctx* c = nullptr;
+        if ((rc = is->context(g.L, &c))) break;
+        g.hdr.gather(rh, g.items);
+        g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
+        g.status.assign(g.items.size(), ST_PENDING);
+        g.out.assign(g.items.size() * so + 8, 0);
+        rc = bbs_sign_wire_submit(c, g.items.size(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(), g.hdr.data.data(),
+                                  g.hdr.off.data(), g.out.data(), g.status.data(), &g.job);
+        if (rc) break;
+    }
+    if (rc) { issuer_detail::free_jobs(groups); return rc; }
+    if ((rc = issuer_detail::wait_all(groups))) return rc;
+    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) {
+        status[kv.second.items[k]] = kv.second.status[k];
+        std::memcpy(sig_octets_out + kv.second.items[k] * so, kv.second.out.data() + k * so, so);
+    }
+    return BBS_OK;
+}
+
+// the reference's PUBLIC proof_gen (src/proof_gen.rs:78-113): generators by the item's number of messages (:91-96); proof
+// octet strings packed in the caller's order (oct_off_out: n + 1 byte offsets; a failed item is empty).  octets_out needs
+// sum_i (3 * fp_bytes + 32 * (4 + messages_i)) bytes.
+int bbs_issuer_proof_gen(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                         const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                         const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                         uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
+    if (!is || !status || !oct_off_out || (n && (!sig_octets || !octets_out || !msg_item_off || !dio || !rno))) return BBS_E_ARG;
+    if (!is->pk_set) return BBS_E_STATE;
+    const Ragged rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rr{rnd, rno, 32}, rh{h, ho, 1}, rp{ph, pho, 1};
+    if (!rdi.sane(n) || !rr.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
+    const size_t fpb = bbs_fp_bytes(is->curve), so = fpb + 32;
+    std::vector<uint64_t> count(n);
+    for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
+    std::map<size_t, Group> groups;
+    issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
+    int rc = BBS_OK;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        bbs_ctx* c = nullptr;
+        if ((rc = is->context(g.L, &c))) break;
+        g.oct.data.resize(g.items.size() * so + 8);
+        for (size_t k = 0; k < g.items.size(); k++) std::memcpy(g.oct.data.data() + k * so, sig_octets + g.items[k] * so, so);
+        g.di.gather(rdi, g.items); g.rnd.gather(rr, g.items); g.hdr.gather(rh, g.items); g.ph.gather(rp, g.items);
+        g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
+        g.status.assign(g.items.size(), ST_PENDING);
+        g.out.assign(g.items.size() * (3 * fpb + 32 * (4 + g.L)) + 8, 0);
+        g.out_off.assign(g.items.size() + 1, 0);
+        rc = bbs_proof_gen_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
+                                       reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(), g.rnd.data.data(), g.rnd.off.data(),
+                                       g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.out.data(), g.out_off.data(),
+                                       g.status.data(), &g.job);
+        if (rc) break;
+    }
+    if (rc) { issuer_detail::free_jobs(groups); return rc; }
+    if ((rc = issuer_detail::wait_all(groups))) return rc;
+    // scatter: lengths in the caller's order, then the bytes
+    std::vector<uint64_t> len(n, 0);
+    std::vector<const uint8_t*> src(n, nullptr);
+    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) {
+        const size_t i = kv.second.items[k];
+        status[i] = kv.second.status[k];
+        len[i] = kv.second.out_off[k + 1] - kv.second.out_off[k];
+        src[i] = kv.second.out.data() + kv.second.out_off[k];
+    }
+    oct_off_out[0] = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (len[i]) std::memcpy(octets_out + oct_off_out[i], src[i], (size_t)len[i]);
+        oct_off_out[i + 1] = oct_off_out[i] + len[i];
+    }
+    return BBS_OK;
 }
 
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {

@@ -51,6 +51,7 @@ inline int d2h_async(void* h, const void* d, size_t b, Stream&) { if (b) std::me
 inline int hmalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? 0 : -1; }
 inline void hfree(void* p, size_t) { std::free(p); }
 inline int sync(Stream&) { return 0; }
+inline size_t mem_free_bytes() { return (size_t)64 << 20; }      // test build: the automatic window width comes out as 8
 struct Event { };
 inline int event_create(Event*) { return 0; }
 inline void event_destroy(Event&) {}
@@ -171,6 +172,7 @@ inline void hfree(void* p, size_t b) {
     (void)hipHostFree(p);
 }
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+inline size_t mem_free_bytes() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? f : 0; }
 using Event = hipEvent_t;
 inline int stream_create(Stream* s) {
     Pools& P = Pools::get();
@@ -383,7 +385,8 @@ struct Ctx : bbs_ctx {
     static constexpr int FPB = 4 * C::FpP::NC;   // bytes of a canonical field element
     int device = 0;
     rt::Stream stream{};
-    int win_bits = 8;
+    int win_bits = 8;                // width of the tables that are built
+    int win_bits_requested = 8;      // bbs_ctx_set_window_bits: 0 = choose at set_generators from the free device memory
     // host state
     bool gens_set = false, pk_set = false, sk_set = false, dst_too_long = false;
     int L = 0;

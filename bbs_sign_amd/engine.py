@@ -845,3 +845,126 @@ class Job:
             self.free()
         except Exception:
             pass
+
+
+class Issuer:
+    """bbs_issuer: the reference's four PUBLIC functions over batches whose items differ in their number of messages
+    (generators chosen by the item's own length: src/sign.rs:44-49, verify.rs:30-35, proof_gen.rs:91-96,
+    proof_verify.rs:40-43).  Octet strings and raw messages in and out; statuses as numpy int8."""
+
+    def __init__(self, curve, api_id: bytes, device: int = 0, lib_path: Optional[str] = None, max_messages: Optional[int] = None,
+                 window_bits: Optional[int] = None):
+        self.lib = _lib.load_library(lib_path)
+        self.curve = CURVE_IDS[curve] if isinstance(curve, str) else int(curve)
+        self.fpb = int(self.lib.bbs_fp_bytes(self.curve))
+        h = ctypes.c_void_p()
+        aid = _bytes_arr(api_id)
+        Engine._chk(self.lib.bbs_issuer_create(self.curve, device, _u8(aid), len(api_id), ctypes.byref(h)), "bbs_issuer_create")
+        self.h = h
+        if max_messages is not None or window_bits is not None:
+            Engine._chk(self.lib.bbs_issuer_set_limits(self.h, 1024 if max_messages is None else max_messages, window_bits or 0),
+                        "bbs_issuer_set_limits")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bbs_issuer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fp(self, v: int) -> bytes:
+        return int(v).to_bytes(self.fpb, "little")
+
+    def set_public_key(self, pk):
+        if pk is None:
+            Engine._chk(self.lib.bbs_issuer_set_public_key(self.h, None, 1), "bbs_issuer_set_public_key")
+            return
+        (x0, x1), (y0, y1) = pk
+        buf = _bytes_arr(self._fp(x0) + self._fp(x1) + self._fp(y0) + self._fp(y1))
+        Engine._chk(self.lib.bbs_issuer_set_public_key(self.h, _u8(buf), 0), "bbs_issuer_set_public_key")
+
+    def set_secret_key(self, sk: int):
+        buf = _bytes_arr(int(sk).to_bytes(32, "little"))
+        Engine._chk(self.lib.bbs_issuer_set_secret_key(self.h, _u8(buf)), "bbs_issuer_set_secret_key")
+
+    def set_modes(self, latency_mode=2, batch_verification=False, points_in_subgroup=False):
+        Engine._chk(self.lib.bbs_issuer_set_modes(self.h, 2 if latency_mode in ("auto", 2) else (1 if latency_mode else 0),
+                                                  1 if batch_verification else 0, 1 if points_in_subgroup else 0), "bbs_issuer_set_modes")
+
+    def context_count(self) -> int:
+        return int(self.lib.bbs_issuer_context_count(self.h))
+
+    def warm(self, message_count: int):
+        c = ctypes.c_void_p()
+        Engine._chk(self.lib.bbs_issuer_context(self.h, message_count, ctypes.byref(c)), "bbs_issuer_context")
+
+    def _sig_octets(self, octets):
+        want = self.fpb + 32
+        bad = [i for i, o in enumerate(octets) if len(o) != want]
+        flat = b"".join(o if len(o) == want else bytes(want) for o in octets)
+        return (_bytes_arr(flat) if octets else np.zeros(1, dtype=np.uint8)), bad
+
+    def proof_verify(self, proof_octets, disclosed_raw, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+        n = len(proof_octets)
+        ob, oo = _ragged_bytes(proof_octets)
+        mb, mbo, mio = Engine._raw_msgs(disclosed_raw)
+        di, dio = Engine._indexes(disclosed_idx)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        Engine._chk(self.lib.bbs_issuer_proof_verify(self.h, n, _u8(ob), _u64(oo), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio),
+                                                     _u8(hb), _u64(ho), _u8(pb), _u64(po), st.ctypes.data_as(_lib.c_i8p)), "bbs_issuer_proof_verify")
+        return st[:n]
+
+    def verify(self, sig_octets, messages_raw, headers=None) -> np.ndarray:
+        n = len(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
+        mb, mbo, mio = Engine._raw_msgs(messages_raw)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        Engine._chk(self.lib.bbs_issuer_verify(self.h, n, _u8(ob), _u8(mb), _u64(mbo), _u64(mio), _u8(hb), _u64(ho),
+                                               st.ctypes.data_as(_lib.c_i8p)), "bbs_issuer_verify")
+        for i in bad:
+            st[i] = -42
+        return st[:n]
+
+    def sign(self, messages_raw, headers=None):
+        """-> (signature octet strings, b"" where status != 1; statuses)"""
+        n = len(messages_raw)
+        mb, mbo, mio = Engine._raw_msgs(messages_raw)
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        so = self.fpb + 32
+        out = np.zeros(max(n, 1) * so, dtype=np.uint8)
+        Engine._chk(self.lib.bbs_issuer_sign(self.h, n, _u8(mb), _u64(mbo), _u64(mio), _u8(hb), _u64(ho), _u8(out),
+                                             st.ctypes.data_as(_lib.c_i8p)), "bbs_issuer_sign")
+        return [bytes(out[i * so:(i + 1) * so]) if st[i] == 1 else b"" for i in range(n)], st[:n]
+
+    def proof_gen(self, sig_octets, messages_raw, disclosed_idx, random_scalars, headers=None, phs=None):
+        """-> (proof octet strings, b"" where status != 1; statuses).  random_scalars[i]: 5 + U_i integers."""
+        n = len(sig_octets)
+        ob, bad = self._sig_octets(sig_octets)
+        mb, mbo, mio = Engine._raw_msgs(messages_raw)
+        di, dio = Engine._indexes(disclosed_idx)
+        ro = np.zeros(n + 1, dtype=np.uint64)
+        chunks = []
+        for i, row in enumerate(random_scalars):
+            ro[i + 1] = ro[i] + len(row)
+            chunks.extend(int(s).to_bytes(32, "little") for s in row)
+        rs = _bytes_arr(b"".join(chunks))
+        hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
+        pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        cap = sum(3 * self.fpb + 32 * (4 + len(m)) for m in messages_raw) + 8
+        out = np.zeros(cap, dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        Engine._chk(self.lib.bbs_issuer_proof_gen(self.h, n, _u8(ob), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio), _u8(rs), _u64(ro),
+                                                  _u8(hb), _u64(ho), _u8(pb), _u64(po), _u8(out), _u64(off), st.ctypes.data_as(_lib.c_i8p)),
+                    "bbs_issuer_proof_gen")
+        for i in bad:
+            st[i] = -42
+        return [bytes(out[int(off[i]):int(off[i + 1])]) if st[i] == 1 else b"" for i in range(n)], st[:n]

@@ -93,8 +93,10 @@ int bbs_device_count(void);
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);
 void bbs_ctx_destroy(bbs_ctx* ctx);
 
-/* window width (bits) of the fixed-base tables, 4..22; takes effect at the next
- * bbs_ctx_set_generators.  Table bytes = (count+1) * ceil(256/w) * (2^w - 1) * 2 * fp_bytes. */
+/* window width (bits) of the fixed-base tables, 4..22, or 0 = chosen at bbs_ctx_set_generators from the memory free on
+ * the device (the widest of 20 / 16 / 12 / 8 whose tables fit an eighth of it); takes effect at the next
+ * bbs_ctx_set_generators.  Digits are SIGNED: table bytes = (count+1) * ceil(256/w) * 2^(w-1) * 2 * limb bytes of an Fp
+ * element (56 on BLS12-381, 40 on BN254) -- 26 GB at w = 20 for 32 messages, 4 GB at 16, 29 MB at 8 (the default). */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
 /* Subgroup vouching (off by default).  The reference's point types (ark-ec `Affine`, built by `deserialize_compressed`
@@ -406,6 +408,62 @@ int bbs_g1_msm_pippenger(bbs_ctx* ctx, size_t n, const uint8_t* points_affine, c
 /* status[i] = ( e(Pa[i], pk) * e(Pb[i], BP2) == 1 ) */
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_affine,
                                       const uint8_t* pb_affine, int8_t* status);
+
+/* ------------------------------------------------------------------------------------------
+ * bbs_issuer: the reference's four PUBLIC functions over batches whose items differ in their number of messages.
+ *
+ * The reference chooses the generators by the item's own length on every call: create_generators(messages.len() + 1) in
+ * sign / verify / proof_gen (src/sign.rs:44-49, src/verify.rs:30-35, src/proof_gen.rs:91-96) and
+ * create_generators(proof.commitments.len() + disclosed_indexes.len() + 1) in proof_verify (src/proof_verify.rs:40-43).
+ * A bbs_ctx holds the tables of one generator set; a bbs_issuer holds one context per message count it has seen (created
+ * on first use: generators by hash-to-curve on the host, window and line tables on the device, window width by
+ * bbs_ctx_set_window_bits(ctx, 0) unless bbs_issuer_set_limits says otherwise) and routes the items of a call: grouped by
+ * message count, every group through the context's one-call wire form (bbs_*_wire_submit), all groups in flight together,
+ * results scattered back into the caller's order.  Arguments as the bbs_*_wire_* functions of the same name.
+ *
+ * Statuses: exactly those of the wire form under the item's own context -- so BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH
+ * cannot occur (as in the reference's public functions), EXCEPT for an item with more than max_messages messages (default
+ * 1024; bbs_issuer_set_limits), which gets that code and is not computed: a table set per length is device memory an
+ * untrusted caller must not be able to allocate without bound.  A proof octet string of the wrong shape is
+ * BBS_ST_INVALID_ENCODING (its length does not define a message count).
+ * Thread-compatible: calls on one issuer from several threads are allowed (context creation is locked; jobs are
+ * independent).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bbs_issuer bbs_issuer;
+int bbs_issuer_create(int curve, int device_id, const uint8_t* api_id, size_t api_id_len, bbs_issuer** out);
+void bbs_issuer_destroy(bbs_issuer* issuer);
+int bbs_issuer_set_public_key(bbs_issuer* issuer, const uint8_t* pk_affine, int is_identity);
+int bbs_issuer_set_secret_key(bbs_issuer* issuer, const uint8_t* sk32);          /* also sets pk = sk * BP2 */
+/* max_messages: longest item served; window_bits: 0 = by free device memory, else 4..22 -- for contexts created afterwards */
+int bbs_issuer_set_limits(bbs_issuer* issuer, size_t max_messages, int window_bits);
+/* bbs_ctx_set_latency_mode / _set_batch_verification (seed from the operating system) / _set_points_in_subgroup on every
+ * context of the issuer, present and future */
+int bbs_issuer_set_modes(bbs_issuer* issuer, int latency_mode, int batch_verification, int points_in_subgroup);
+/* the context serving items of `message_count` messages (created if needed), e.g. to warm it up before traffic arrives */
+int bbs_issuer_context(bbs_issuer* issuer, size_t message_count, bbs_ctx** out);
+size_t bbs_issuer_context_count(bbs_issuer* issuer);
+/* proof_verify (src/proof_verify.rs:19-61); message count of item i = (its proof's commitments) + (its disclosed indexes) */
+int bbs_issuer_proof_verify(bbs_issuer* issuer, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                            const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                            const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                            const uint8_t* headers, const uint64_t* hdr_off,
+                            const uint8_t* ph, const uint64_t* ph_off, int8_t* status);
+/* verify (src/verify.rs:18-50), sign (src/sign.rs:32-60), proof_gen (src/proof_gen.rs:78-113); message count of item i =
+ * its number of messages.  sign: fp_bytes + 32 octets per item (zeros where status != 1).  proof_gen: octet strings packed
+ * in the caller's order, oct_off_out n + 1 byte offsets, octets_out needs sum_i (3 fp_bytes + 32 (4 + messages_i)) bytes. */
+int bbs_issuer_verify(bbs_issuer* issuer, size_t n, const uint8_t* signature_octets,
+                      const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                      const uint8_t* headers, const uint64_t* hdr_off, int8_t* status);
+int bbs_issuer_sign(bbs_issuer* issuer, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                    const uint64_t* msg_item_off, const uint8_t* headers, const uint64_t* hdr_off,
+                    uint8_t* signature_octets_out, int8_t* status);
+int bbs_issuer_proof_gen(bbs_issuer* issuer, size_t n, const uint8_t* signature_octets,
+                         const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                         const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                         const uint8_t* random_scalars, const uint64_t* rnd_off,
+                         const uint8_t* headers, const uint64_t* hdr_off,
+                         const uint8_t* ph, const uint64_t* ph_off,
+                         uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side setup helpers: once per ciphersuite / key, no GPU involved.

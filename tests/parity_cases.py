@@ -1695,3 +1695,97 @@ def check_sign_verify_wire(curve, lib_path=None, n=10, L=4, seed=99):
         assert list(e2.verify_wire_batch(o, [[m1 + b"x"]], [hdr])) == [0]
         e2.close()
 
+
+
+def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1, 5, 3, 2, 5, 1, 7, 3), oracle_items=(0, 1, 3, 5)):
+    """bbs_issuer_*: ONE call over items whose numbers of messages differ -- every item gets the generators of its own
+    length, as the reference's public functions do (create_generators(messages.len() + 1): src/sign.rs:44-49,
+    src/verify.rs:30-35, src/proof_gen.rs:91-96; commitments + disclosed indexes + 1: src/proof_verify.rs:40-43).
+    Signatures and proofs byte for byte against the oracle's PUBLIC sign / proof_gen, booleans against its public verify /
+    proof_verify (a subset: pairings in pure Python are slow), incl. forged items, a malformed proof string and an item
+    longer than the issuer's limit."""
+    from bbs_sign_amd import Issuer, api
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    n = len(lengths)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    iss = Issuer(curve, suite.api_id, lib_path=lib_path, max_messages=6, window_bits=4 if lib_path else 8)
+    iss.set_secret_key(sk)
+    raw = [[bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 32, 70]))) for _ in range(L)] for L in lengths]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9, 66]))) for _ in range(n)]
+    too_long = [i for i, L in enumerate(lengths) if L > 6]
+    assert too_long, "the case needs an item above the issuer's limit"
+    # ---- sign
+    octs, st = iss.sign(raw, headers)
+    assert [int(x) for x in st] == [-1 if i in too_long else 1 for i in range(n)], list(st)
+    sigs = []
+    for i in range(n):
+        if i in too_long:
+            assert octs[i] == b""
+            sigs.append(None)
+            continue
+        w = bbs.sign(suite, sk, raw[i], headers[i])
+        sigs.append(w)
+        assert octs[i] == api.signature_to_octets(curve, Signature(w.a, w.e), lib_path), (curve, "sign", i)
+    assert iss.context_count() == len({L for L in lengths if L <= 6})
+    # ---- verify: forged message / header / e, one malformed string
+    vo = [o if o else bytes(c.fp_bytes + 32) for o in octs]
+    vraw = [list(m) for m in raw]
+    vh = list(headers)
+    vraw[3][0] = vraw[3][0] + b"!"
+    vh[4] = vh[4] + b"x"
+    vo[5] = vo[5][:-1] + bytes([vo[5][-1] ^ 1])
+    vo[6] = vo[6][:-3]
+    got = [int(x) for x in iss.verify(vo, vraw, vh)]
+    want = [1] * n
+    want[3] = want[4] = want[5] = 0
+    want[6] = -42
+    for i in too_long:
+        want[i] = -1
+    assert got == want, (got, want)
+    for i in (0, 1, 3, 4):                                                 # (items whose signature string is untouched)
+        assert int(bbs.verify(suite, pk, sigs[i], vh[i], vraw[i])) == got[i], (curve, "verify", i)
+    # ---- proof_gen
+    ok = [i for i in range(n) if i not in too_long]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) if L else [] for L in lengths]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for L, d in zip(lengths, disclosed)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 7]))) for _ in range(n)]
+    so = [o if o else bytes(c.fp_bytes + 32) for o in octs]
+    poct, st = iss.proof_gen(so, raw, disclosed, rnds, headers, phs)
+    assert [int(x) for x in st] == [-1 if i in too_long else 1 for i in range(n)], list(st)
+    proofs = {}
+    for i in ok:
+        w = bbs.proof_gen(suite, pk, sigs[i], headers[i], phs[i], raw[i], disclosed[i], rnds[i])
+        proofs[i] = w
+        assert poct[i] == api.proof_to_octets(curve, Proof(w.a_bar, w.b_bar, w.d, w.e_cap, w.r1_cap, w.r3_cap, list(w.commitments), w.challenge), lib_path), (curve, "proof_gen", i)
+    # ---- proof_verify: the message count of an item comes from its own octet string and index list
+    dm = [[raw[i][j] for j in disclosed[i]] for i in range(n)]
+    vp = [p if p else bytes(3 * c.fp_bytes + 128) for p in poct]
+    vdm = [list(m) for m in dm]
+    vph = list(phs)
+    vph[0] = vph[0] + b"?"                                                 # forged presentation header -> Ok(false)
+    i_msg = next(i for i in ok if disclosed[i] and i not in (0,))
+    vdm[i_msg][0] = vdm[i_msg][0] + b"~"                                   # forged disclosed message -> Ok(false)
+    i_cut = next(i for i in ok if i not in (0, i_msg))
+    vp[i_cut] = vp[i_cut][:-5]                                             # malformed: no message count can be read
+    long_i = too_long[0]
+    vp[long_i] = bytes(3 * c.fp_bytes + 32 * (4 + 7))                      # 7 commitments: above the limit
+    vdisc = list(disclosed)
+    vdisc[long_i] = []
+    vdm[long_i] = []
+    got = [int(x) for x in iss.proof_verify(vp, vdm, vdisc, headers, vph)]
+    want = [1] * n
+    want[0] = 0
+    want[i_msg] = 0
+    want[i_cut] = -42
+    want[long_i] = -1
+    assert got == want, (got, want)
+    for i in oracle_items:
+        if i in (i_cut, long_i):
+            continue
+        assert int(bbs.proof_verify(suite, pk, proofs[i], headers[i], vph[i], vdm[i], disclosed[i])) == got[i], (curve, "proof_verify", i)
+    # empty calls
+    assert list(iss.proof_verify([], [], [])) == [] and list(iss.verify([], [])) == []
+    iss.close()

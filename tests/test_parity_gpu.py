@@ -241,3 +241,9 @@ def test_auto_form(curve):
         assert [int(x) for x in j.status()] == want
         j.free()
     eng.close()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_mixed_lengths(curve):
+    pc.check_issuer_mixed_lengths(curve, None)
+    pc.check_issuer_mixed_lengths(curve, None, seed=137, lengths=(6, 6, 2, 4, 4, 9, 0, 1, 6, 2, 3, 3, 5), oracle_items=(0, 2))

@@ -124,3 +124,8 @@ def test_proof_verify_wire(twin, curve):
 def test_sign_verify_wire(twin, curve):
     pc.check_sign_verify_wire(curve, twin)
 
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_mixed_lengths(twin, curve):
+    pc.check_issuer_mixed_lengths(curve, twin)
