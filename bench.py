@@ -334,15 +334,27 @@ def main():
             traffic = None
             if dom in kc:
                 traffic = (2 * kc[dom]["FETCH_SIZE_KiB"] + kc[dom]["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0)
+            alg_bytes = ALG_BYTES_PER_PROOF_VERIFY * n
+            excl_ms = (single["throughput_form"]["stage_ms"].get(dom) if single else None)
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "algorithmic bytes/unit = %d (SURVEY 8d) x %d units per launch; launch duration = HIP events "
-                        "around the kernel on its own stream, averaged over the timed region (%d batches in flight, so "
-                        "it is the wall duration of a kernel co-scheduled with the others; exclusive duration: "
-                        "single_batch.stage_ms); traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch from %s; the path is "
-                        "bound by integer VALU issue, not HBM (valu_issue, DESIGN.md)" % (
-                            ALG_BYTES_PER_PROOF_VERIFY, n, n_slots, counters_file)}
+                "frac_uses": "duration_ms_co_scheduled",
+                "duration_ms_co_scheduled": dom_ms,
+                "duration_ms_exclusive": excl_ms,
+                "frac_exclusive": (alg_bytes / (excl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if excl_ms else None,
+                "frac_per_step": alg_bytes / (dt / args.steps / world) / 1e9 / HBM_PEAK_GBS,
+                "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                "target_40_percent_of_hbm": "NOT MET and not attainable: 1361 algorithmic bytes against ~2.9e5 wavefront "
+                                            "instructions per proof (SURVEY 7/8d); the binding resource is integer VALU issue (valu_issue)",
+                "note": "algorithmic bytes/unit = %d (SURVEY 8d) x %d units per launch; `frac` divides them by the launch duration "
+                        "measured with HIP events around the kernel on its own stream, averaged over the timed region, i.e. the "
+                        "wall duration of a kernel CO-SCHEDULED with the kernels of the other %d batches in flight (longer than "
+                        "ms_per_step); duration_ms_exclusive = the same kernel with the chip to itself (single_batch, throughput "
+                        "form) and frac_exclusive the fraction priced with it; frac_per_step prices the whole step.  traffic = "
+                        "2 x FETCH_SIZE + WRITE_SIZE per launch from %s (the x2 is the guide's gfx950 correction for streaming "
+                        "reads; the MSM kernel's 112-byte table gathers are probably over-corrected by it)" % (
+                            ALG_BYTES_PER_PROOF_VERIFY, n, n_slots - 1, counters_file)}
             out["stage_ms_per_step"] = per_step
             out["gpu_ms_per_job_events"] = job_ms / args.steps
             if counters:
@@ -356,6 +368,7 @@ def main():
                 avail = 1024 * clk * 1e9 * (dt / args.steps) / world
                 out["valu_issue"] = {
                     "frac": tot_cyc / avail, "issue_cycles_per_step": tot_cyc, "simd_cycles_available_per_step": avail,
+                    "frac_of_4cycle_peak": tot_inst * 4.0 / avail,
                     "frac_if_8_waves_per_simd_issue_costs": tot_cyc8 / avail,
                     "valu_wave_insts_per_step": tot_inst, "achieved_ginstr_s": tot_inst * args.steps * world / dt / 1e9 / world,
                     "clock_ghz_under_load": clk, "source": counters_file,
@@ -364,10 +377,13 @@ def main():
                             "profiles/ (tools/valu_model.py).  frac = share of the SIMD cycles the step needs just to ISSUE "
                             "its vector instructions one wavefront per SIMD; frac_if_8_waves_per_simd_issue_costs prices the "
                             "same instructions at the cheaper issue costs eight co-resident wavefronts would see (the "
-                            "kernels need 400 of 512 registers, so they run one per SIMD)"}
+                            "kernels need 400 of 512 registers, so they run one per SIMD); frac_of_4cycle_peak prices every "
+                            "instruction at the hard floor of a wave64 instruction on a 16-lane SIMD (4 cycles)"}
                 out["kernels"] = [{"kernel": k, "ms_per_launch": per_step.get(k), "valu_wave_insts": v["valu_insts"] * (n / 4096.0),
                                    "cycles_per_inst": v["cycles_per_inst"],
-                                   "hbm_bytes": (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0)}
+                                   "hbm_bytes": (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0),
+                                   "hbm_traffic_over_algorithmic": (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 / (ALG_BYTES_PER_PROOF_VERIFY * 4096.0),
+                                   "own_isa_histogram": v.get("own_isa_histogram")}
                                   for k, v in kc.items()]
         if extras is not None:
             out["other_ops"] = extras

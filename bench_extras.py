@@ -320,5 +320,48 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         msweep["msgs=%d" % Lm] = {"sign": rate(em.core_sign_upload(mm)), "verify": rate(em.core_verify_upload(sg, mm))}
         em.close()
     out["bn254"]["message_count_sweep"] = msweep
+
+    # ---- the reference's message-SIZE sweeps (benches/sign.rs:18, verify.rs:21, proof_gen.rs:22: ONE message of 32 ... 4096
+    # bytes, BN254) through the public functions in one call each: raw message bytes in host buffers, hashed on the device
+    # (msg_to_scalars), octet strings on both sides, 8 batches of 4096 in flight, one submitting thread
+    bsweep = {}
+    sb1, e1, _, _ = pc.bench_engine("bn254", 1, None, 16, device=device)
+    e1.set_latency_mode(False)
+    hb1, ho1 = _ragged_bytes([b""] * n)
+    so1 = [np.zeros(n * (e1.fpb + 32), dtype=np.uint8) for _ in range(9)]
+    di1, dio1 = e1._indexes([[0]] * n)
+    rs1, ro1 = e1._scalars([[7 + b, 11 + b, 13 + b, 17 + b, 19 + b] for b in range(n)])
+    po1 = [np.zeros(n * (3 * e1.fpb + 32 * 5), dtype=np.uint8) for _ in range(9)]
+    poo1 = [np.zeros(n + 1, dtype=np.uint64) for _ in range(9)]
+
+    def packed1(fn, name, *a):
+        st_ = np.full(n, -128, dtype=np.int8)
+        jh = _ct.c_void_p()
+        e1._chk(fn(e1.h, n, *a, st_.ctypes.data_as(_l.c_i8p), _ct.byref(jh)), name)
+        j = Job(e1, jh, n)
+        j.result = st_
+        return j
+    for size in (32, 128, 512, 2048, 4096):
+        raw1 = [[pc.expand_message(b"bbs-bench-bytes" + pc.i2osp(b, 8), b"BBS_BENCH_MSG_DST_", 32) * (size // 32)] for b in range(n)]
+        mb1, mbo1, mio1 = e1._raw_msgs(raw1)
+
+        def sign1():
+            o = so1[turn[0] % 9]; turn[0] += 1
+            return packed1(e1.lib.bbs_sign_wire_submit, "bbs_sign_wire_submit", u8(mb1), u64(mbo1), u64(mio1), u8(hb1), u64(ho1), u8(o))
+        r_sign = host_loop(sign1, all_true, steps=32)
+        sig1 = so1[(turn[0] - 1) % 9].copy()
+
+        def pg1():
+            k = turn[0] % 9; turn[0] += 1
+            return packed1(e1.lib.bbs_proof_gen_wire_submit, "bbs_proof_gen_wire_submit", u8(sig1), u8(mb1), u64(mbo1), u64(mio1), u64(di1), u64(dio1),
+                           u8(rs1), u64(ro1), u8(hb1), u64(ho1), u8(hb1), u64(ho1), u8(po1[k]), u64(poo1[k]))
+        bsweep["bytes=%d" % size] = {
+            "sign": r_sign,
+            "verify": host_loop(lambda: packed1(e1.lib.bbs_verify_wire_submit, "bbs_verify_wire_submit", u8(sig1), u8(mb1), u64(mbo1), u64(mio1),
+                                                u8(hb1), u64(ho1)), all_true, steps=32),
+            "proof_gen": host_loop(pg1, all_true, steps=32),
+            "message_megabytes_per_s_at_sign_rate": r_sign * size / 1e6}
+    e1.close()
+    out["bn254"]["single_message_bytes_sweep_wire_host_inclusive"] = bsweep
     eng.set_latency_mode("auto")
     return out

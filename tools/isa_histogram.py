@@ -79,8 +79,9 @@ def demangle(names):
 
 def main():
     lib, out = sys.argv[1], sys.argv[2]
-    pats = sys.argv[3:] or [r"k_stage<bbs::PairDist<bbs::BlsCurve>", r"k_stage<bbs::PvMsmPart<bbs::BlsCurve>", r"k_stage<bbs::PvFixPart<bbs::BlsCurve>",
-                            r"k_stage<bbs::PvVarPart<bbs::BlsCurve>"]
+    pats = sys.argv[3:] or [r"k_stage<bbs::PairDist<bbs::BlsCurve>", r"k_stage<bbs::PvMsmPart<bbs::BlsCurve>", r"k_stage<bbs::PvChallenge<bbs::BlsCurve>",
+                            r"k_stage<bbs::PvScalars<bbs::BlsCurve>", r"k_stage<bbs::PvFinish,", r"k_stage<bbs::PairMillerHalf<bbs::BlsCurve>",
+                            r"k_stage<bbs::PairFinalDist<bbs::BlsCurve>", r"k_stage<bbs::PvIngest<bbs::BlsCurve>"]
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         for co in extract_code_objects(os.path.abspath(lib), tmp):
@@ -91,9 +92,17 @@ def main():
                 continue
             for k in kernels:
                 kname = re.sub(r"void rt::k_stage<bbs::(\w+)<bbs::(\w+)>.*", r"\1<\2>", dm[k])
+                kname = re.sub(r"void rt::k_stage<bbs::(\w+),.*", r"\1", kname)          # non-template stages (PvFinish)
                 curve = "BlsCurve" if "BlsCurve" in dm[k] else "BnCurve"
-                group = [k] + [s for s in syms if s != k and not dm.get(s, s).startswith("void rt::k_stage") and curve in dm.get(s, s)
-                               and ("Pair" in kname) == any(t in dm.get(s, s) for t in ("d_mul", "d_inv", "d_final", "d_frob", "d_pow", "d_gather"))]
+                # the device functions a kernel can reach, by name: the lane-sliced Fp12 routines for the pairing kernels, the
+                # hash routines only for the stages that hash, everything else of the curve (field / group arithmetic) otherwise
+                pair_fn = lambda d: any(t in d for t in ("d_mul", "d_inv", "d_final", "d_frob", "d_pow", "d_gather"))
+                hash_fn = lambda d: "sha256" in d or "xmd" in d
+                hashes = any(t in kname for t in ("PvChallenge", "PvScalars"))
+                leaf = any(t in kname for t in ("PvFinish", "PvIngest", "PairMillerHalf"))
+                group = [k] + [s for s in syms if s != k and not leaf and not dm.get(s, s).startswith("void rt::k_stage")
+                               and (curve in dm.get(s, s) or (hashes and hash_fn(dm.get(s, s))))
+                               and ("Pair" in kname) == pair_fn(dm.get(s, s)) and (hashes or not hash_fn(dm.get(s, s)))]
                 for s in group:
                     insts = syms[s]
                     if not insts:

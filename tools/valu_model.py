@@ -18,7 +18,8 @@ import json
 import sys
 
 STAGE_OF = {"PairDist<BlsCurve>": "pairing_6lane", "PvMsmPart<BlsCurve>": "pv_msm_parts", "PvChallenge<BlsCurve>": "pv_challenge",
-            "PvScalars<BlsCurve>": "pv_scalars", "PvFinish": "pv_finish"}
+            "PvScalars<BlsCurve>": "pv_scalars", "PvFinish": "pv_finish", "PairMillerHalf<BlsCurve>": "pair_miller",
+            "PairFinalDist<BlsCurve>": "pair_final_exp"}
 SIMPLE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32",
           "v_mov_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32", "v_not_b32", "v_max_i32", "v_min_i32", "v_max_u32",
           "v_min_u32", "v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32", "v_mul_i32_i24", "v_mul_u32_u24", "v_bfrev_b32"}
@@ -79,7 +80,8 @@ def main():
         c = pmc[k]
         waves_per_simd = 1            # every proof_verify kernel runs one wavefront per SIMD (registers): DESIGN.md 5
         cost = class_costs(ub, waves_per_simd)
-        h = hist.get(k) or hist.get("PvMsmPart<BlsCurve>")      # small kernels: the MSM kernel's mix (same field arithmetic)
+        own = bool(hist.get(k))
+        h = hist.get(k) or hist.get("PvMsmPart<BlsCurve>")      # no histogram of its own (older profile sets): the MSM kernel's mix
         tot = sum(h.values())
         share = collections.Counter()
         for op, n in h.items():
@@ -88,9 +90,11 @@ def main():
             cw = class_costs(ub, w)
             return sum(share[cl] * cw[cl] for cl in share)
         cpi = cpi_at(waves_per_simd)
-        clk = c.get("GRBM_GUI_ACTIVE", 0) / 8.0 / (c.get("duration_ns", 0) or 1) if c.get("duration_ns") else None
+        # clock = GRBM_GUI_ACTIVE / 8 / duration: only meaningful for a kernel that runs long enough for the counter window to
+        # be the kernel (a 10 us kernel reads 9 GHz)
+        clk = c.get("GRBM_GUI_ACTIVE", 0) / 8.0 / c["duration_ns"] if c.get("duration_ns", 0) > 500000 else None
         kernels[stage] = {"kernel": k, "valu_insts": c["SQ_INSTS_VALU"], "FETCH_SIZE_KiB": c.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": c.get("WRITE_SIZE", 0.0),
-                          "waves": c.get("SQ_WAVES"), "waves_per_simd": waves_per_simd, "cycles_per_inst": cpi,
+                          "waves": c.get("SQ_WAVES"), "waves_per_simd": waves_per_simd, "cycles_per_inst": cpi, "own_isa_histogram": own,
                           "cycles_per_inst_if_waves_per_simd": {str(w): round(cpi_at(w), 3) for w in (1, 2, 4, 8)},
                           "opcode_class_share": {cl: round(share[cl], 4) for cl in ("mad", "vop3", "simple", "carry")},
                           "class_cost_cycles": {cl: round(cost[cl], 3) for cl in cost},
