@@ -144,7 +144,11 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         // every item its own pairing product, on the job's second stream concurrently with the MSM / challenge
         // stages: it needs only the proof's own points (canonical, converted in the kernel) and the flag the ingest stage
         // left.  First in the list: the second stream forks where its first stage stands, i.e. before the MSM chain.
-        add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane");
+        // One fused kernel in BOTH forms: the split of the two Miller loops (820 + 410 wavefronts) pays where the pairing
+        // follows the MSM chain (verify: 7.4 -> 6.9 ms), but beside the 768 wavefronts of this operation's latency-form MSM
+        // chain it oversubscribes the 1024 SIMDs and the queued wavefronts cost more than the split saves (measured
+        // 5.1 ms split vs 4.4 ms fused, profiles/r03_j_latency_form_split.log)
+        add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane", false, 0, false);
         msm_chain();
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});

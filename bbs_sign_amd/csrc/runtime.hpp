@@ -839,15 +839,16 @@ inline int launch_pip_windows(Stream& s, const PipCoopArgs<C>& a) {
 // sixteen combined checks of batch verification, which are the narrow tail of their job)
 template <class C, class J>
 void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller, const char* nm_final, const char* nm_dist, bool force_split = false,
-                        int join_first = 0) {       // join_first: the (main-stream) first stage waits for the second stream
-    (void)nm_miller; (void)nm_final; (void)nm_dist; (void)force_split;
+                        int join_first = 0,         // join_first: the (main-stream) first stage waits for the second stream
+                        bool allow_split = true) {  // false: one fused kernel also in the latency form (see op_pv.hpp)
+    (void)nm_miller; (void)nm_final; (void)nm_dist; (void)force_split; (void)allow_split;
     const size_t first = j->stages.size();
     struct JoinFirst { J* j; size_t first; int join; ~JoinFirst() { if (join && j->stages.size() > first) j->stages[first].join = 1; } } jf{j, first, join_first};
 #ifdef BBS_HOST_TWIN
     j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMiller<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n * 2); }, aux, 0});
     j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinal<C>>(aux ? j->stream_aux() : j->stream(), *pargs, pargs->n); }, aux, 0});
 #else
-    if (j->latency_form || force_split) {
+    if ((j->latency_form && allow_split) || force_split) {
         // the two Miller loops of every item on separate wavefronts, then product + final exponentiation (stages.hpp)
         j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMillerHalf<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 128); }, aux, 0});
         j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinalDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});

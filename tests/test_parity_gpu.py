@@ -212,8 +212,9 @@ def test_latency_form_every_item_against_c_oracle():
 @pytest.mark.job_form(None)
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_auto_form(curve):
-    """The library's default: a job that is alone on its context is laid out in the latency form (pairing as two stages),
-    the third and later live jobs in the throughput form (one fused pairing stage); the statuses are the same."""
+    """The library's default: a job with at most one other live job on its context is laid out in the latency form (verify:
+    the pairing as two stages), the third and later live jobs in the throughput form (one fused pairing stage); the
+    statuses are the same.  (proof_verify keeps the fused pairing kernel in both forms; its forms differ in the MSM parts.)"""
     import ctypes
     suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload(curve, 130, 6, 2, None, 8)
     sigs, st = eng.core_sign_batch(msgs)
@@ -221,7 +222,9 @@ def test_auto_form(curve):
     assert (st == 1).all()
     proofs[5].r1_cap = (proofs[5].r1_cap + 1) % suite.curve.r
     dm = [m[:2] for m in msgs]
-    jobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(4)]
+    vsigs = list(sigs)
+    vsigs[5] = pc.Signature(sigs[5].a, (sigs[5].e + 1) % suite.curve.r)
+    jobs = [eng.core_verify_upload(vsigs, msgs) for _ in range(4)]
     eng.lib.bbs_job_stage_name.restype = ctypes.c_char_p
 
     def names(j):
@@ -233,10 +236,18 @@ def test_auto_form(curve):
             out.append(nm.decode()); k += 1
     assert "pair_final_exp" in names(jobs[0]) and "pair_final_exp" in names(jobs[1])
     assert "pairing_6lane" in names(jobs[2]) and "pairing_6lane" in names(jobs[3])
-    for j in jobs:
+    pjobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(2)]      # live jobs 5 and 6: throughput form
+    for j in jobs + pjobs:
         j.run()
     want = [0 if i == 5 else 1 for i in range(130)]
-    for j in jobs:
+    for j in jobs + pjobs:
+        j.wait()
+        assert [int(x) for x in j.status()] == want
+        j.free()
+    pjobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(2)]      # alone again: latency form
+    for j in pjobs:
+        j.run()
+    for j in pjobs:
         j.wait()
         assert [int(x) for x in j.status()] == want
         j.free()
