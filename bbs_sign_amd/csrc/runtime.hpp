@@ -14,6 +14,7 @@
 #include <set>
 #include <cstring>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <atomic>
 #include <mutex>
@@ -122,12 +123,25 @@ inline int dmalloc(void** p, size_t b) {
 }
 inline void dfree(void* p, size_t b, int dev) {        // dev = the device the buffer was allocated on
     const size_t cls = size_class(b);
+    std::vector<void*> evicted;
     if (cls <= POOL_MAX_BUF) {
+        // as hfree: the size in use now is kept, buffers of other sizes make room when the pool is full
         Pools& P = Pools::get();
         std::lock_guard<std::mutex> g(P.mu);
-        if (P.pooled_bytes[dev] + cls <= POOL_MAX_TOTAL) { P.bufs[dev].emplace(cls, p); P.pooled_bytes[dev] += cls; return; }
+        auto& m = P.bufs[dev];
+        size_t& tot = P.pooled_bytes[dev];
+        while (tot + cls > POOL_MAX_TOTAL && !m.empty()) {
+            auto it = m.begin();
+            if (it->first == cls) it = std::prev(m.end());
+            if (it->first == cls) break;
+            evicted.push_back(it->second);
+            tot -= it->first;
+            m.erase(it);
+        }
+        if (tot + cls <= POOL_MAX_TOTAL) { m.emplace(cls, p); tot += cls; p = nullptr; }
     }
-    (void)hipFree(p);
+    for (void* e : evicted) (void)hipFree(e);
+    if (p) (void)hipFree(p);
 }
 inline int h2d(void* d, const void* h, size_t b, Stream& s) {
     if (!b) return 0;
@@ -164,12 +178,27 @@ inline int hmalloc(void** p, size_t b) {
 }
 inline void hfree(void* p, size_t b) {
     const size_t cls = size_class(b);
+    std::vector<void*> evicted;
     {
+        // the buffer just released is the size the caller is using NOW: it is kept, and if the pool is full, buffers of
+        // other sizes (left over from an earlier workload) make room -- otherwise a serving loop whose batch shape
+        // changed would pay hipHostMalloc / hipHostFree (milliseconds) on every batch from then on
         Pools& P = Pools::get();
         std::lock_guard<std::mutex> g(P.mu);
-        if (P.pinned_bytes + cls <= PINNED_POOL_MAX) { P.pinned.emplace(cls, p); P.pinned_bytes += cls; return; }
+        if (cls <= PINNED_POOL_MAX) {
+            while (P.pinned_bytes + cls > PINNED_POOL_MAX && !P.pinned.empty()) {
+                auto it = P.pinned.begin();
+                if (it->first == cls) it = std::prev(P.pinned.end());
+                if (it->first == cls) break;                   // only this size is cached: the pool is simply full of it
+                evicted.push_back(it->second);
+                P.pinned_bytes -= it->first;
+                P.pinned.erase(it);
+            }
+            if (P.pinned_bytes + cls <= PINNED_POOL_MAX) { P.pinned.emplace(cls, p); P.pinned_bytes += cls; p = nullptr; }
+        }
     }
-    (void)hipHostFree(p);
+    for (void* e : evicted) (void)hipHostFree(e);
+    if (p) (void)hipHostFree(p);
 }
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 inline size_t mem_free_bytes() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? f : 0; }
