@@ -174,7 +174,8 @@ def main():
     ap.add_argument("--total", type=int, default=65536, help="mixed65536 only: length of the list (8192 = one rank's share "
                     "of the 65 536-item list at 8 GPUs, to rehearse the strong-scaling regime on one GPU)")
     ap.add_argument("--min-batch", type=int, default=None, help="mixed65536 only: smallest job a rank's share is cut into")
-    ap.add_argument("--latency-mode", type=int, default=None, help="mixed65536 only, A/B: bbs_ctx_set_latency_mode on (1) / off (0)")
+    ap.add_argument("--latency-mode", type=int, default=None, help="A/B and profiling: bbs_ctx_set_latency_mode 0 = throughput form for every "
+                    "job, 1 = latency form, default = the library's AUTO (by live jobs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sign/verify/proof_gen/BN254 figures")
     ap.add_argument("--fixed-base-tree", type=int, default=None, help="A/B: bbs_ctx_set_fixed_base_tree on (1) / off (0); default = the library's")
@@ -241,6 +242,8 @@ def main():
     suite, eng, gens, sk = pc.bench_engine("bls12_381", L, None, args.window_bits, device=local_rank)
     if args.fixed_base_tree is not None:
         eng.set_fixed_base_tree(bool(args.fixed_base_tree))
+    if args.latency_mode is not None:
+        eng.set_latency_mode(args.latency_mode if args.latency_mode in (0, 1) else "auto")
     # every rank and every slot verifies its own batch: item ids offset by rank and slot
     slots, raw0 = make_slots(pc, suite, eng, n, L, R, n_slots, first_item=rank * n_slots * n)
     msgs, disclosed, rnds, sigs, proofs, dm = raw0
