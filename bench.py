@@ -135,7 +135,7 @@ def submit_loop(eng, slots, steps, inflight, first_step=0, collect_times=False):
     return bad, stage_ms, job_ms
 
 
-def resident_rate(eng, slots_data, n, steps, inflight):
+def resident_rate(eng, slots_data, n, steps, inflight, only_form=None):
     """Batches already resident in HBM (uploaded, validated, unpacked): kernels only.  -> (proof_verify/s, stage ms)"""
     from bbs_sign_amd import Job
     eng.set_latency_mode(False)                  # every resident job in the throughput form (AUTO would give the first two the other)
@@ -151,6 +151,9 @@ def resident_rate(eng, slots_data, n, steps, inflight):
     # one batch at a time, in both forms of a job (the library's AUTO picks the latency form for a job that is alone)
     single = {}
     for form, mode in (("throughput_form", False), ("latency_form", True)):
+        if only_form is not None and mode != bool(only_form):      # --latency-mode given (profiling): only that form's kernels run
+            single[form] = None
+            continue
         eng.set_latency_mode(mode)
         j = eng.core_proof_verify_upload(*slots_data[0])
         j.run(); j.wait()
@@ -275,7 +278,8 @@ def main():
 
     # ---- untimed legs ------------------------------------------------------------------------------------------
     slots_data = [(proofs, dm, disclosed)]
-    res_rate, res_stage, single = resident_rate(eng, slots_data * n_slots, n, max(32, args.steps // 2), n_slots) \
+    res_rate, res_stage, single = resident_rate(eng, slots_data * n_slots, n, max(32, args.steps // 2), n_slots,
+                                                args.latency_mode if args.latency_mode in (0, 1) else None) \
         if rank == 0 else (None, None, None)
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -317,8 +321,10 @@ def main():
                          "stage_ms_per_step": res_stage,
                          "note": "the same kernels on batches already uploaded / validated / unpacked in HBM, %d in "
                                  "flight; never the headline" % n_slots},
-            "single_batch": dict(single["latency_form"], form="latency form = what the library's AUTO mode gives a job that is alone "
-                                 "on its context (bbs_ctx_set_latency_mode)", throughput_form=single["throughput_form"]),
+            "single_batch": dict(single["latency_form"] or single["throughput_form"],
+                                 form=("latency form = what the library's AUTO mode gives a job that is alone on its context "
+                                       "(bbs_ctx_set_latency_mode)") if single["latency_form"] else "throughput form (--latency-mode 0)",
+                                 throughput_form=single["throughput_form"]),
         }
         if dt < 1.0:
             out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): filling and draining the %d in-flight slots is "
@@ -338,7 +344,7 @@ def main():
             if dom in kc:
                 traffic = (2 * kc[dom]["FETCH_SIZE_KiB"] + kc[dom]["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0)
             alg_bytes = ALG_BYTES_PER_PROOF_VERIFY * n
-            excl_ms = (single["throughput_form"]["stage_ms"].get(dom) if single else None)
+            excl_ms = (single["throughput_form"]["stage_ms"].get(dom) if single and single["throughput_form"] else None)
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
