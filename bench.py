@@ -284,7 +284,7 @@ def main():
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         from bench_extras import other_ops
-        extras = other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, local_rank, submit_loop, make_slots)
+        extras = other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, local_rank, submit_loop, make_slots, slots)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([passed], dtype=torch.int64, device=red_dev)

@@ -4,7 +4,7 @@ import ctypes
 import time
 
 
-def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, device, submit_loop, make_slots):
+def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, device, submit_loop, make_slots, slots=None):
     from bbs_sign_amd import Job
 
     def rate(j, reps=3):
@@ -54,21 +54,26 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
                              "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, d_r, rn_r))}
     bls["disclosed_sweep_L32"] = sweep
 
-    # ---- window widths on DISTINCT data (the 20-bit tables are 52 GB: every batch touches different entries)
+    # ---- window widths of the fixed-base tables (signed digits: 2^(w-1) entries per base and window), the headline's loop on
+    # the headline's own packed batches (distinct data in every slot: a 26 GB table is touched at different entries by every
+    # batch).  The packed host buffers do not depend on the context, only the tables do.
     cmp_w = {}
-    for w in sorted({16, 20} - {args.window_bits}):
+    for w in sorted({8, 12, 16, 20} - {args.window_bits}):
         s2, e2, _, _ = pc.bench_engine("bls12_381", L, None, w, device=device)
-        e2.set_latency_mode(False)
-        slots2, _ = make_slots(pc, s2, e2, n, L, R, max(1, args.inflight), first_item=0)
-        bad, _, _ = submit_loop(e2, slots2, len(slots2), len(slots2))
+        use = slots if slots is not None else make_slots(pc, s2, e2, n, L, R, max(1, args.inflight), first_item=0)[0]
+        bad, _, _ = submit_loop(e2, use, 2 * len(use), len(use))
         assert bad == 0
         t0 = time.perf_counter()
-        bad, _, _ = submit_loop(e2, slots2, 64, len(slots2))
-        cmp_w[str(w)] = n * 64 / (time.perf_counter() - t0)
+        bad, _, _ = submit_loop(e2, use, 64, len(use))
+        cmp_w[str(w)] = {"proof_verify_per_s": n * 64 / (time.perf_counter() - t0),
+                         "table_bytes": (L + 2) * ((256 + w - 1) // w) * (1 << (w - 1)) * 2 * 14 * 4}
         assert bad == 0
         e2.close()
-    bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the "
-                                                "headline's own width (%d) is `value`" % (args.inflight, args.window_bits))
+    wb = args.window_bits
+    bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the headline's own width "
+                                                "(%d bits, %d table bytes) is `value`; the library default is 8, bbs_ctx_set_window_bits(ctx, 0) picks "
+                                                "the widest of 20 / 16 / 12 / 8 that fits an eighth of the free device memory"
+                                                % (args.inflight, wb, (L + 2) * ((256 + wb - 1) // wb) * (1 << (wb - 1)) * 2 * 14 * 4))
 
     # ---- one batch at a time in latency mode (bbs_ctx_set_latency_mode: T1's three terms on three lanes), and the
     # price of that mode with eight batches in flight
