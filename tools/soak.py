@@ -10,6 +10,7 @@ from bbs_sign_amd import api
 import bench
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 45.0
+torch.cuda.mem_get_info()          # torch's HIP context first (initialising it after the engine has been using the device has failed on this pool)
 n, L, R = 4096, 32, 8
 suite, eng, gens, sk = pc.bench_engine("bls12_381", L, None, 16)
 slots, raw0 = bench.make_slots(pc, suite, eng, n, L, R, 4, first_item=0)
@@ -19,6 +20,10 @@ no, keep_o, args_o = eng._oct_inputs(octs, dm, disclosed, None, None)
 
 
 raw512 = [[bytes([b & 255, j, 7]) * (1 + (b + j) % 40) for j in range(L)] for b in range(512)]
+from bbs_sign_amd import Issuer
+iss = Issuer("bls12_381", suite.api_id, window_bits=8)
+iss.set_secret_key(sk)
+iraw = [[bytes([b & 255, j, 9]) * (1 + j) for j in range(b % 5)] for b in range(600)]          # 0 .. 4 messages per item
 
 
 def snap():
@@ -45,6 +50,18 @@ while time.time() - t0 < secs:
     assert (eng.verify_wire_batch(so, raw512) == 1).all()
     po, st = eng.proof_gen_wire_batch(so, raw512, disclosed[:512], rnds[:512]); assert (st == 1).all()
     assert (eng.proof_verify_wire_batch(po, [m[:R] for m in raw512], disclosed[:512]) == 1).all()
+    # batch-verification mode and both forms of a job on the same context, and the multi-length issuer
+    eng.set_batch_verification(True)
+    for form in (False, True):
+        eng.set_latency_mode(form)
+        bj = [eng.core_proof_verify_submit(proofs[:1024], dm[:1024], disclosed[:1024]) for _ in range(3)]
+        for j in bj:
+            j.wait(); assert (j.result == 1).all(); j.free()
+    eng.set_batch_verification(False)
+    eng.set_latency_mode("auto")
+    iso, ist = iss.sign(iraw)
+    assert (ist == 1).all()
+    assert (iss.verify(iso, iraw) == 1).all()
     rounds += 1
     if rounds in (2, 4) or rounds % 10 == 0:
         d, h = snap()

@@ -8,6 +8,7 @@ t0 = time.time()
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 done = 0
 while time.time() - t0 < budget:
+    pc.LATENCY_MODE = [None, False, True][seed % 3]          # the library's AUTO / throughput / latency form of every job
     for curve in ("bls12_381", "bn254"):
         L = [0, 1, 2, 5, 7, 12][seed % 6]
         pc.check_random_batch(curve, None, n=8 + seed % 9, L=L, seed=seed)
@@ -20,6 +21,13 @@ while time.time() - t0 < budget:
         pc.check_octets_out(curve, None, n=12 + seed % 6, L=3 + seed % 5, seed=seed)
         pc.check_proof_verify_wire(curve, None, n=12 + seed % 5, L=3 + seed % 5, seed=seed)
         pc.check_sign_verify_wire(curve, None, n=10 + seed % 5, L=1 + seed % 6, seed=seed)
+        import random as _r
+        rr = _r.Random(seed)
+        lens = [rr.randrange(0, 7) for _ in range(9)] + [7 + seed % 3]
+        rr.shuffle(lens)
+        if lens[0] > 6 or lens[1] > 6 or lens[3] > 6 or lens[4] > 6 or lens[5] > 6 or lens[6] > 6:      # the case tampers with items 0 .. 6
+            lens.sort()
+        pc.check_issuer_mixed_lengths(curve, None, seed=seed, lengths=tuple(lens), oracle_items=(0,))
         done += 1
     seed += 1
     print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
