@@ -1697,7 +1697,7 @@ def check_sign_verify_wire(curve, lib_path=None, n=10, L=4, seed=99):
 
 
 
-def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1, 5, 3, 2, 5, 1, 7, 3), oracle_items=(0, 1, 3, 5)):
+def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1, 5, 3, 2, 5, 1, 7, 3), oracle_items=(0, 1, 3, 5), window_bits="fixed"):
     """bbs_issuer_*: ONE call over items whose numbers of messages differ -- every item gets the generators of its own
     length, as the reference's public functions do (create_generators(messages.len() + 1): src/sign.rs:44-49,
     src/verify.rs:30-35, src/proof_gen.rs:91-96; commitments + disclosed indexes + 1: src/proof_verify.rs:40-43).
@@ -1711,7 +1711,8 @@ def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1,
     n = len(lengths)
     sk = rng.randrange(1, c.r)
     pk = bbs.sk_to_pk(suite, sk)
-    iss = Issuer(curve, suite.api_id, lib_path=lib_path, max_messages=6, window_bits=4 if lib_path else 8)
+    # window_bits = 0: the library picks the width of every context's tables from the free device memory
+    iss = Issuer(curve, suite.api_id, lib_path=lib_path, max_messages=6, window_bits=(4 if lib_path else 8) if window_bits == "fixed" else window_bits)
     iss.set_secret_key(sk)
     raw = [[bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 32, 70]))) for _ in range(L)] for L in lengths]
     headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 9, 66]))) for _ in range(n)]
