@@ -174,7 +174,7 @@ inline int hmalloc(void** p, size_t b) {
         auto it = P.pinned.find(cls);
         if (it != P.pinned.end()) { *p = it->second; P.pinned.erase(it); P.pinned_bytes -= cls; return 0; }
     }
-    return hipHostMalloc(p, cls, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+    return hipHostMalloc(p, cls, hipHostMallocPortable) == hipSuccess ? 0 : -1;      // portable: the pool is shared by every device of the process
 }
 inline void hfree(void* p, size_t b) {
     const size_t cls = size_class(b);

@@ -56,7 +56,55 @@ extern "C" {
         ph: *const u8, ph_off: *const u64, status: *mut i8, job_out: *mut *mut BbsJob) -> c_int;
     fn bbs_job_wait(job: *mut BbsJob) -> c_int;
     fn bbs_job_free(job: *mut BbsJob);
+    // items of ANY number of messages in one call (one context per count inside the library): see `GpuIssuerAnyLength`
+    fn bbs_issuer_create(curve: c_int, device_id: c_int, api_id: *const u8, api_id_len: usize, out: *mut *mut BbsIssuer) -> c_int;
+    fn bbs_issuer_destroy(issuer: *mut BbsIssuer);
+    fn bbs_issuer_set_public_key(issuer: *mut BbsIssuer, pk: *const u8, is_identity: c_int) -> c_int;
+    fn bbs_issuer_set_limits(issuer: *mut BbsIssuer, max_messages: usize, window_bits: c_int) -> c_int;
+    fn bbs_issuer_proof_verify(issuer: *mut BbsIssuer, n: usize, proof_octets: *const u8, oct_off: *const u64,
+        msg_bytes: *const u8, msg_byte_off: *const u64, msg_item_off: *const u64, disclosed_idx: *const u64, didx_off: *const u64,
+        headers: *const u8, hdr_off: *const u64, ph: *const u8, ph_off: *const u64, status: *mut i8) -> c_int;
 }
+#[repr(C)] pub struct BbsIssuer { _p: [u8; 0] }
+
+/// `proof_verify` (src/proof_verify.rs:19-61) for a list of proofs whose numbers of messages differ: the reference derives the
+/// generators from `proof.commitments.len() + disclosed_indexes.len() + 1` on every call (:40-43); here the library keeps
+/// one table set per message count and routes the proofs.  Proofs travel as the octet strings a verifier receives
+/// (`CanonicalSerialize` of the reference's `Proof`: 3 compressed G1 points, then the scalars), messages as raw bytes.
+pub struct GpuIssuerAnyLength { issuer: *mut BbsIssuer }
+impl GpuIssuerAnyLength {
+    pub fn new<E: GpuCurve>(device: c_int, api_id: &[u8], pk_affine_le: &[u8], max_messages: usize) -> Self {
+        let mut issuer = std::ptr::null_mut();
+        let rc = unsafe { bbs_issuer_create(E::CURVE_ID, device, api_id.as_ptr(), api_id.len(), &mut issuer) };
+        assert_eq!(rc, 0, "bbs_issuer_create: {rc}");
+        unsafe {
+            assert_eq!(bbs_issuer_set_limits(issuer, max_messages, 0), 0);          // table width by free device memory
+            assert_eq!(bbs_issuer_set_public_key(issuer, pk_affine_le.as_ptr(), 0), 0);
+        }
+        GpuIssuerAnyLength { issuer }
+    }
+    /// One call for the whole list; `Err(InvalidMessageAndGeneratorsLength)` only for a proof above `max_messages`.
+    pub fn proof_verify(&self, proof_octets: &[&[u8]], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
+                        disclosed_indexes: &[&[usize]]) -> Vec<Result<bool, ProofGenError>> {
+        let n = proof_octets.len();
+        let (ob, oo) = ragged(proof_octets);
+        let (mut mb, mut mbo, mut mio, mut di, mut dio) = (Vec::new(), vec![0u64], vec![0u64], Vec::new(), vec![0u64]);
+        for i in 0..n {
+            for m in disclosed_messages[i] { mb.extend_from_slice(m); mbo.push(mb.len() as u64); }
+            mio.push((mbo.len() - 1) as u64);
+            di.extend(disclosed_indexes[i].iter().map(|&x| x as u64));
+            dio.push(di.len() as u64);
+        }
+        let (hb, ho) = ragged(headers);
+        let (pb, po) = ragged(phs);
+        let mut status = vec![-128i8; n];
+        let rc = unsafe { bbs_issuer_proof_verify(self.issuer, n, ob.as_ptr(), oo.as_ptr(), mb.as_ptr(), mbo.as_ptr(), mio.as_ptr(),
+                                                  di.as_ptr(), dio.as_ptr(), hb.as_ptr(), ho.as_ptr(), pb.as_ptr(), po.as_ptr(), status.as_mut_ptr()) };
+        assert_eq!(rc, 0, "bbs_issuer_proof_verify: {rc}");
+        status.iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
+    }
+}
+impl Drop for GpuIssuerAnyLength { fn drop(&mut self) { unsafe { bbs_issuer_destroy(self.issuer) } } }
 
 /// Curves the engine knows (BBS_CURVE_* of the header).
 pub trait GpuCurve: Pairing {

@@ -230,6 +230,49 @@ static int run_curve(int curve) {
         pocts[poff[1] + 3 * fpb + 5] ^= 1;               /* e^ of item 1 altered */
         CHECK(bbs_proof_verify_wire_batch(vctx, 3, pocts, poff, dmb, dmbo, dmio, di, dio_w, hdr4, ho_w, ph_bytes, po_w, sw) == BBS_OK);
         CHECK(sw[0] == 1 && sw[1] == 0 && sw[2] == 1);
+        pocts[poff[1] + 3 * fpb + 5] ^= 1;
+        /* ---- the same three proofs PLUS one of another length through bbs_issuer_*: the library picks the generators by the
+         * item's own message count (commitments + disclosed indexes, src/proof_verify.rs:40-43) ---- */
+        bbs_issuer* issuer = NULL;
+        CHECK(bbs_issuer_create(curve, 0, (const uint8_t*)api_id, alen, &issuer) == BBS_OK && issuer);
+        CHECK(bbs_issuer_set_limits(issuer, 16, 5) == BBS_OK);
+        CHECK(bbs_issuer_set_public_key(issuer, pk, 0) == BBS_OK);
+        /* a fourth item of ONE message: signed and proven through the issuer's own one-message context */
+        bbs_ctx* c1 = NULL;
+        CHECK(bbs_issuer_context(issuer, 1, &c1) == BBS_OK && c1);
+        CHECK(bbs_ctx_set_secret_key(c1, sk) == BBS_OK);
+        const uint8_t one_msg[5] = {'h', 'e', 'l', 'l', 'o'};
+        const uint64_t one_bo[2] = {0, 5}, one_io[2] = {0, 1}, none_off[2] = {0, 0}, one_dio[2] = {0, 1}, one_ro[2] = {0, 5};
+        const uint64_t one_di[1] = {0};
+        uint8_t so1[48 + 32], p1[3 * 48 + 32 * 5];
+        uint64_t p1off[2];
+        int8_t s1 = 0;
+        CHECK(bbs_sign_wire_batch(c1, 1, one_msg, one_bo, one_io, NULL, none_off, so1, &s1) == BBS_OK && s1 == 1);
+        CHECK(bbs_proof_gen_wire_batch(c1, 1, so1, one_msg, one_bo, one_io, one_di, one_dio, rnd, one_ro, NULL, none_off, NULL, none_off,
+                                       p1, p1off, &s1) == BBS_OK && s1 == 1);
+        /* the list: items 0 .. 2 (L messages each) and the one-message proof */
+        uint8_t all_oct[sizeof(pocts) + sizeof(p1)], all_mb[128], all_hdr[64], all_ph[64];
+        uint64_t all_oo[5], all_mbo[8], all_mio[5], all_di[8], all_dio[5], all_ho[5], all_po[5];
+        memcpy(all_oct, pocts, poff[3]); memcpy(all_oct + poff[3], p1, p1off[1]);
+        for (int i = 0; i <= 3; i++) all_oo[i] = poff[i];
+        all_oo[4] = poff[3] + p1off[1];
+        memcpy(all_mb, dmb, dmbo[3]); memcpy(all_mb + dmbo[3], one_msg, 5);
+        for (int i = 0; i <= 3; i++) all_mbo[i] = dmbo[i];
+        all_mbo[4] = dmbo[3] + 5;
+        for (int i = 0; i <= 3; i++) all_mio[i] = dmio[i];
+        all_mio[4] = dmio[3] + 1;
+        for (uint64_t k = 0; k < dio_w[3]; k++) all_di[k] = di[k];
+        all_di[dio_w[3]] = 0;
+        for (int i = 0; i <= 3; i++) { all_dio[i] = dio_w[i]; all_ho[i] = ho_w[i]; all_po[i] = po_w[i]; }
+        all_dio[4] = dio_w[3] + 1; all_ho[4] = ho_w[3]; all_po[4] = po_w[3];
+        memcpy(all_hdr, hdr4, ho_w[3]); memcpy(all_ph, ph_bytes, po_w[3]);
+        int8_t s4[4];
+        CHECK(bbs_issuer_proof_verify(issuer, 4, all_oct, all_oo, all_mb, all_mbo, all_mio, all_di, all_dio, all_hdr, all_ho, all_ph, all_po, s4) == BBS_OK);
+        CHECK(s4[0] == 1 && s4[1] == 1 && s4[2] == 1 && s4[3] == 1);
+        all_mb[all_mbo[3]] ^= 1;                         /* the one-message item's message altered */
+        CHECK(bbs_issuer_proof_verify(issuer, 4, all_oct, all_oo, all_mb, all_mbo, all_mio, all_di, all_dio, all_hdr, all_ho, all_ph, all_po, s4) == BBS_OK);
+        CHECK(s4[0] == 1 && s4[1] == 1 && s4[2] == 1 && s4[3] == 0);
+        bbs_issuer_destroy(issuer);
     }
 
     bbs_ctx_destroy(vctx);                                                                                               /* step 18 */
