@@ -106,8 +106,32 @@ BBS_HD_NOINLINE void sha256_word(Sha256& s, uint32_t wv) {
     }
 }
 
+// big-endian word at p: one 32-bit load when p is aligned, four byte loads otherwise
+BBS_HD uint32_t sha256_be32(const uint8_t* p) {
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) {
+        const uint32_t l = *reinterpret_cast<const uint32_t*>(p);
+        return (l << 24) | ((l & 0xff00u) << 8) | ((l >> 8) & 0xff00u) | (l >> 24);
+    }
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+// Byte strings are absorbed a byte at a time only until the stream is word aligned and for the last n mod 4 bytes; in
+// between whole 64-byte blocks go straight from memory into the compression function when the block buffer is empty, and
+// whole words through sha256_word otherwise (round 3: one select chain per WORD instead of per byte -- the raw-message
+// forms hash 32 messages per signature and were bound by this loop).
 BBS_HD_NOINLINE void sha256_bytes(Sha256& s, const uint8_t* p, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) sha256_byte(s, p[i]);
+    uint32_t i = 0;
+    while (i < n && (s.fill & 3u)) sha256_byte(s, p[i++]);
+    while (s.fill == 0 && n - i >= 64) {
+        uint32_t w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = sha256_be32(p + i + 4 * k);
+        sha256_compress(s.h, w);
+        s.total += 64;
+        i += 64;
+    }
+    while (n - i >= 4) { sha256_word(s, sha256_be32(p + i)); i += 4; }
+    while (i < n) sha256_byte(s, p[i++]);
 }
 
 BBS_HD void sha256_u64be(Sha256& s, uint64_t v) {
@@ -117,8 +141,13 @@ BBS_HD void sha256_u64be(Sha256& s, uint64_t v) {
 
 BBS_HD_NOINLINE void sha256_final(Sha256& s, uint32_t* out8) {
     const uint64_t bits = s.total * 8;
-    sha256_byte(s, 0x80);
-    while (s.fill != 56) sha256_byte(s, 0);
+    sha256_byte(s, 0x80);                          // (compresses and clears the buffer by itself when this was byte 64)
+    // the zero padding is already there: the buffer is cleared after every compression and bytes are OR-ed in
+    if (s.fill > 56) {                             // no room for the length: one more block
+        sha256_compress(s.h, s.w);
+#pragma unroll
+        for (int i = 0; i < 16; i++) s.w[i] = 0;
+    }
     s.w[14] = (uint32_t)(bits >> 32);
     s.w[15] = (uint32_t)bits;
     sha256_compress(s.h, s.w);
