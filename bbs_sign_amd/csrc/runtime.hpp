@@ -415,7 +415,7 @@ struct Ctx : bbs_ctx {
     int device = 0;
     rt::Stream stream{};
     int win_bits = 8;                // width of the tables that are built
-    int win_bits_requested = 8;      // bbs_ctx_set_window_bits: 0 = choose at set_generators from the free device memory
+    int win_bits_requested = 0;      // bbs_ctx_set_window_bits; 0 (the default) = choose at set_generators from the free device memory
     // host state
     bool gens_set = false, pk_set = false, sk_set = false, dst_too_long = false;
     int L = 0;

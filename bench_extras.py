@@ -71,7 +71,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         e2.close()
     wb = args.window_bits
     bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the headline's own width "
-                                                "(%d bits, %d table bytes) is `value`; the library default is 8, bbs_ctx_set_window_bits(ctx, 0) picks "
+                                                "(%d bits, %d table bytes) is `value`; the library default, bbs_ctx_set_window_bits(ctx, 0), picks "
                                                 "the widest of 20 / 16 / 12 / 8 that fits an eighth of the free device memory"
                                                 % (args.inflight, wb, (L + 2) * ((256 + wb - 1) // wb) * (1 << (wb - 1)) * 2 * 14 * 4))
 
