@@ -96,8 +96,8 @@ void bbs_ctx_destroy(bbs_ctx* ctx);
 /* window width (bits) of the fixed-base tables, 4..22, or 0 (THE DEFAULT) = chosen at bbs_ctx_set_generators from the
  * memory free on the device: the widest of 20 / 16 / 12 / 8 whose tables fit an eighth of it and 32 GiB; takes effect at
  * the next bbs_ctx_set_generators.  Digits are SIGNED: table bytes = (count+1) * ceil(256/w) * 2^(w-1) * 2 * limb bytes of
- * an Fp element (56 on BLS12-381, 40 on BN254) -- for 32 messages 26 GB at w = 20 (1.45 M proof_verify/s), 2 GB at 16
- * (1.30 M), 172 MB at 12 (1.30 M: the table stays in the 256 MB Infinity Cache), 16 MB at 8 (1.18 M). */
+ * an Fp element (56 on BLS12-381, 40 on BN254) -- for 32 messages 26 GB at w = 20 (1.45 M proof_verify/s, 8.0 M sign/s),
+ * 2 GB at 16 (1.30 M, 7.3 M), 172 MB at 12 (1.30 M, 6.1 M), 16 MB at 8 (1.18 M, 4.4 M). */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 
 /* Subgroup vouching (off by default).  The reference's point types (ark-ec `Affine`, built by `deserialize_compressed`
