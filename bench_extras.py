@@ -176,6 +176,31 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         retire_o()
     bls["proof_verify_wire_raw_messages_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
 
+    # ---- bbs_issuer: ONE call over proofs of two different lengths (half 32 messages / 8 disclosed, half 16 / 4), raw
+    # disclosed messages, the library routing the items to the context of their own message count (two groups in flight);
+    # the call is synchronous, so this is one list at a time
+    from bbs_sign_amd import Issuer
+    s16, e16, _, _ = pc.bench_engine("bls12_381", 16, None, 16, device=device)
+    m16, d16, r16 = pc.bench_items(s16, e16, n // 2, 16, 4, 0)
+    sg16, st16 = e16.core_sign_batch(m16)
+    pf16, st16 = e16.core_proof_gen_batch(sg16, m16, d16, r16)
+    assert (st16 == 1).all()
+    raw16 = [[pc.expand_message(b"bbs-bench-msg" + pc.i2osp(b, 8) + pc.i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32) for j in range(4)] for b in range(n // 2)]
+    oct16 = [_api.proof_to_octets("bls12_381", p_) for p_ in pf16]
+    e16.close()
+    iss = Issuer("bls12_381", suite.api_id, device=device, window_bits=16)
+    iss.set_public_key(eng.public_key())
+    mix_oct = [x for pair in zip(octs[:n // 2], oct16) for x in pair]
+    mix_raw = [x for pair in zip(raw_msgs[:n // 2], raw16) for x in pair]
+    mix_idx = [x for pair in zip(disclosed[:n // 2], d16) for x in pair]
+    assert (iss.proof_verify(mix_oct, mix_raw, mix_idx) == 1).all()
+    t1 = time.perf_counter()
+    for _ in range(8):
+        st_i = iss.proof_verify(mix_oct, mix_raw, mix_idx)
+    bls["issuer_proof_verify_two_lengths_one_list_at_a_time"] = 8 * n / (time.perf_counter() - t1)
+    assert (st_i == 1).all() and iss.context_count() == 2
+    iss.close()
+
     # ---- the other three operations from HOST buffers through their submit forms, 8 batches in flight, results checked:
     # verify from signature records and from signature octets (decompression + subgroup check on the device), sign and
     # proof_gen with the records delivered at wait
