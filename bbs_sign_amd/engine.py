@@ -908,17 +908,25 @@ class Issuer:
         flat = b"".join(o if len(o) == want else bytes(want) for o in octets)
         return (_bytes_arr(flat) if octets else np.zeros(1, dtype=np.uint8)), bad
 
-    def proof_verify(self, proof_octets, disclosed_raw, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+    def pack_proof_verify(self, proof_octets, disclosed_raw, disclosed_idx, headers=None, phs=None):
+        """The flat host buffers of one bbs_issuer_proof_verify call: (n, arrays to keep alive, ctypes arguments)."""
         n = len(proof_octets)
         ob, oo = _ragged_bytes(proof_octets)
         mb, mbo, mio = Engine._raw_msgs(disclosed_raw)
         di, dio = Engine._indexes(disclosed_idx)
         hb, ho = _ragged_bytes(headers if headers is not None else [b""] * n)
         pb, po = _ragged_bytes(phs if phs is not None else [b""] * n)
+        keep = (ob, oo, mb, mbo, mio, di, dio, hb, ho, pb, po)
+        return n, keep, (_u8(ob), _u64(oo), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio), _u8(hb), _u64(ho), _u8(pb), _u64(po))
+
+    def proof_verify_packed(self, n, args) -> np.ndarray:
         st = np.full(max(n, 1), -128, dtype=np.int8)
-        Engine._chk(self.lib.bbs_issuer_proof_verify(self.h, n, _u8(ob), _u64(oo), _u8(mb), _u64(mbo), _u64(mio), _u64(di), _u64(dio),
-                                                     _u8(hb), _u64(ho), _u8(pb), _u64(po), st.ctypes.data_as(_lib.c_i8p)), "bbs_issuer_proof_verify")
+        Engine._chk(self.lib.bbs_issuer_proof_verify(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p)), "bbs_issuer_proof_verify")
         return st[:n]
+
+    def proof_verify(self, proof_octets, disclosed_raw, disclosed_idx, headers=None, phs=None) -> np.ndarray:
+        n, keep, args = self.pack_proof_verify(proof_octets, disclosed_raw, disclosed_idx, headers, phs)
+        return self.proof_verify_packed(n, args)
 
     def verify(self, sig_octets, messages_raw, headers=None) -> np.ndarray:
         n = len(sig_octets)
