@@ -30,6 +30,14 @@ SIGNATURES = {
     "bbs_issuer_set_modes": (ci, [vp, ci, ci, ci]),
     "bbs_issuer_context": (ci, [vp, sz, ctypes.POINTER(vp)]),
     "bbs_issuer_context_count": (sz, [vp]),
+    "bbs_issuer_proof_verify_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p,
+                                            ctypes.POINTER(vp)]),
+    "bbs_issuer_verify_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_issuer_sign_submit": (ci, [vp, sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_issuer_proof_gen_submit": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p,
+                                         c_u8p, c_u64p, c_i8p, ctypes.POINTER(vp)]),
+    "bbs_issuer_job_wait": (ci, [vp]),
+    "bbs_issuer_job_free": (None, [vp]),
     "bbs_issuer_proof_verify": (ci, [vp, sz, c_u8p, c_u64p, c_u8p, c_u64p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_issuer_verify": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_i8p]),
     "bbs_issuer_sign": (ci, [vp, sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_u8p, c_i8p]),

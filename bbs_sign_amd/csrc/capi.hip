@@ -1070,10 +1070,40 @@ static void issuer_group(bbs_issuer* is, size_t n, const std::vector<uint64_t>& 
 
 // the reference's PUBLIC proof_verify (src/proof_verify.rs:19-61), every item with the generators of ITS OWN length
 // L_i = U_i + R_i (:40-43): U_i from the length of the proof's octet string, R_i = number of disclosed indexes
-int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const uint64_t* oct_off, const uint8_t* msg_bytes,
-                            const uint64_t* msg_byte_off, const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio,
-                            const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
-    if (!is || !status || (n && (!oct_off || !msg_item_off || !dio))) return BBS_E_ARG;
+// the asynchronous form of every bbs_issuer_* call: *_submit packs and submits the groups and returns; bbs_issuer_job_wait
+// waits for every group and scatters statuses / outputs into the caller's buffers (which stay valid until then; the inputs may
+// be released when submit returns)
+static int issuer_finish_submit(int rc, std::unique_ptr<bbs_issuer_job>& job, bbs_issuer_job** out) {
+    if (rc) { issuer_detail::free_jobs(job->groups); return rc; }
+    *out = job.release();
+    return BBS_OK;
+}
+int bbs_issuer_job_wait(bbs_issuer_job* job) {
+    if (!job) return BBS_E_ARG;
+    if (job->delivered) return BBS_OK;
+    const int rc = issuer_detail::wait_all(job->groups);
+    if (rc) return rc;
+    if (job->scatter) job->scatter(job->groups);
+    job->delivered = true;
+    return BBS_OK;
+}
+void bbs_issuer_job_free(bbs_issuer_job* job) {
+    if (!job) return;
+    if (!job->delivered) (void)issuer_detail::wait_all(job->groups);       // the groups' buffers must outlive their jobs
+    delete job;
+}
+static int issuer_sync(int rc, bbs_issuer_job* job) {
+    if (rc) return rc;
+    rc = bbs_issuer_job_wait(job);
+    bbs_issuer_job_free(job);
+    return rc;
+}
+
+int bbs_issuer_proof_verify_submit(bbs_issuer* is, size_t n, const uint8_t* oct, const uint64_t* oct_off, const uint8_t* msg_bytes,
+                                   const uint64_t* msg_byte_off, const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio,
+                                   const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
+                                   bbs_issuer_job** job_out) {
+    if (!is || !status || !job_out || (n && (!oct_off || !msg_item_off || !dio))) return BBS_E_ARG;
     if (!is->pk_set) return BBS_E_STATE;
     const Ragged ro{oct, oct_off, 1}, rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rh{h, ho, 1}, rp{ph, pho, 1};
     if (!ro.sane(n) || !rdi.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
@@ -1086,7 +1116,8 @@ int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const 
         if (len < floor_ || (len - floor_) % 32) { pre[i] = BBS_ST_INVALID_ENCODING; continue; }
         count[i] = (len - floor_) / 32 + rdi.count(i);
     }
-    std::map<size_t, Group> groups;
+    std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, pre, status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
@@ -1101,23 +1132,30 @@ int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const 
                                           g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.status.data(), &g.job);
         if (rc) break;
     }
-    if (rc) { issuer_detail::free_jobs(groups); return rc; }
-    if ((rc = issuer_detail::wait_all(groups))) return rc;
-    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
-    return BBS_OK;
+    job->scatter = [status](std::map<size_t, Group>& gs) {
+        for (auto& kv : gs) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
+    };
+    return issuer_finish_submit(rc, job, job_out);
+}
+int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const uint64_t* oct_off, const uint8_t* msg_bytes,
+                            const uint64_t* msg_byte_off, const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio,
+                            const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
+    bbs_issuer_job* job = nullptr;
+    return issuer_sync(bbs_issuer_proof_verify_submit(is, n, oct, oct_off, msg_bytes, msg_byte_off, msg_item_off, di, dio, h, ho, ph, pho, status, &job), job);
 }
 
 // the reference's PUBLIC verify (src/verify.rs:18-50): generators by the item's number of messages (:30-35)
-int bbs_issuer_verify(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
-                      const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status) {
-    if (!is || !status || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
+int bbs_issuer_verify_submit(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                             const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_issuer_job** job_out) {
+    if (!is || !status || !job_out || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
     if (!is->pk_set) return BBS_E_STATE;
     const Ragged rh{h, ho, 1};
     if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t so = bbs_fp_bytes(is->curve) + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
-    std::map<size_t, Group> groups;
+    std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
@@ -1133,26 +1171,32 @@ int bbs_issuer_verify(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const
                                     g.hdr.data.data(), g.hdr.off.data(), g.status.data(), &g.job);
         if (rc) break;
     }
-    if (rc) { issuer_detail::free_jobs(groups); return rc; }
-    if ((rc = issuer_detail::wait_all(groups))) return rc;
-    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
-    return BBS_OK;
+    job->scatter = [status](std::map<size_t, Group>& gs) {
+        for (auto& kv : gs) for (size_t k = 0; k < kv.second.items.size(); k++) status[kv.second.items[k]] = kv.second.status[k];
+    };
+    return issuer_finish_submit(rc, job, job_out);
+}
+int bbs_issuer_verify(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                      const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status) {
+    bbs_issuer_job* job = nullptr;
+    return issuer_sync(bbs_issuer_verify_submit(is, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, h, ho, status, &job), job);
 }
 
 // the reference's PUBLIC sign (src/sign.rs:32-60): generators by the item's number of messages (:44-49); signature octet
 // strings (fp_bytes + 32 each, zeros where status != 1) in the caller's order
-int bbs_issuer_sign(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
-                    const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status) {
-    if (!is || !status || (n && (!sig_octets_out || !msg_item_off))) return BBS_E_ARG;
+int bbs_issuer_sign_submit(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                           const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status, bbs_issuer_job** job_out) {
+    if (!is || !status || !job_out || (n && (!sig_octets_out || !msg_item_off))) return BBS_E_ARG;
     if (!is->sk_set) return BBS_E_STATE;
     const Ragged rh{h, ho, 1};
     if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t so = bbs_fp_bytes(is->curve) + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
-    std::map<size_t, Group> groups;
+    std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
-    std::memset(sig_octets_out, 0, n * so);
+    if (n) std::memset(sig_octets_out, 0, n * so);
     int rc = BBS_OK;
     for (auto& kv : groups) {
         Group& g = kv.second;
@@ -1166,30 +1210,36 @@ int bbs_issuer_sign(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const ui
                                   g.hdr.off.data(), g.out.data(), g.status.data(), &g.job);
         if (rc) break;
     }
-    if (rc) { issuer_detail::free_jobs(groups); return rc; }
-    if ((rc = issuer_detail::wait_all(groups))) return rc;
-    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) {
-        status[kv.second.items[k]] = kv.second.status[k];
-        std::memcpy(sig_octets_out + kv.second.items[k] * so, kv.second.out.data() + k * so, so);
-    }
-    return BBS_OK;
+    job->scatter = [status, sig_octets_out, so](std::map<size_t, Group>& gs) {
+        for (auto& kv : gs) for (size_t k = 0; k < kv.second.items.size(); k++) {
+            status[kv.second.items[k]] = kv.second.status[k];
+            std::memcpy(sig_octets_out + kv.second.items[k] * so, kv.second.out.data() + k * so, so);
+        }
+    };
+    return issuer_finish_submit(rc, job, job_out);
+}
+int bbs_issuer_sign(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                    const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status) {
+    bbs_issuer_job* job = nullptr;
+    return issuer_sync(bbs_issuer_sign_submit(is, n, msg_bytes, msg_byte_off, msg_item_off, h, ho, sig_octets_out, status, &job), job);
 }
 
 // the reference's PUBLIC proof_gen (src/proof_gen.rs:78-113): generators by the item's number of messages (:91-96); proof
 // octet strings packed in the caller's order (oct_off_out: n + 1 byte offsets; a failed item is empty).  octets_out needs
 // sum_i (3 * fp_bytes + 32 * (4 + messages_i)) bytes.
-int bbs_issuer_proof_gen(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
-                         const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
-                         const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
-                         uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
-    if (!is || !status || !oct_off_out || (n && (!sig_octets || !octets_out || !msg_item_off || !dio || !rno))) return BBS_E_ARG;
+int bbs_issuer_proof_gen_submit(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                                const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                                const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_issuer_job** job_out) {
+    if (!is || !status || !oct_off_out || !job_out || (n && (!sig_octets || !octets_out || !msg_item_off || !dio || !rno))) return BBS_E_ARG;
     if (!is->pk_set) return BBS_E_STATE;
     const Ragged rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rr{rnd, rno, 32}, rh{h, ho, 1}, rp{ph, pho, 1};
     if (!rdi.sane(n) || !rr.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t fpb = bbs_fp_bytes(is->curve), so = fpb + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
-    std::map<size_t, Group> groups;
+    std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
@@ -1209,23 +1259,31 @@ int bbs_issuer_proof_gen(bbs_issuer* is, size_t n, const uint8_t* sig_octets, co
                                        g.status.data(), &g.job);
         if (rc) break;
     }
-    if (rc) { issuer_detail::free_jobs(groups); return rc; }
-    if ((rc = issuer_detail::wait_all(groups))) return rc;
-    // scatter: lengths in the caller's order, then the bytes
-    std::vector<uint64_t> len(n, 0);
-    std::vector<const uint8_t*> src(n, nullptr);
-    for (auto& kv : groups) for (size_t k = 0; k < kv.second.items.size(); k++) {
-        const size_t i = kv.second.items[k];
-        status[i] = kv.second.status[k];
-        len[i] = kv.second.out_off[k + 1] - kv.second.out_off[k];
-        src[i] = kv.second.out.data() + kv.second.out_off[k];
-    }
-    oct_off_out[0] = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (len[i]) std::memcpy(octets_out + oct_off_out[i], src[i], (size_t)len[i]);
-        oct_off_out[i + 1] = oct_off_out[i] + len[i];
-    }
-    return BBS_OK;
+    job->scatter = [status, octets_out, oct_off_out, n](std::map<size_t, Group>& gs) {
+        // lengths in the caller's order, then the bytes
+        std::vector<uint64_t> len(n, 0);
+        std::vector<const uint8_t*> src(n, nullptr);
+        for (auto& kv : gs) for (size_t k = 0; k < kv.second.items.size(); k++) {
+            const size_t i = kv.second.items[k];
+            status[i] = kv.second.status[k];
+            len[i] = kv.second.out_off[k + 1] - kv.second.out_off[k];
+            src[i] = kv.second.out.data() + kv.second.out_off[k];
+        }
+        oct_off_out[0] = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (len[i]) std::memcpy(octets_out + oct_off_out[i], src[i], (size_t)len[i]);
+            oct_off_out[i + 1] = oct_off_out[i] + len[i];
+        }
+    };
+    return issuer_finish_submit(rc, job, job_out);
+}
+int bbs_issuer_proof_gen(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                         const uint64_t* msg_item_off, const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
+                         const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
+                         uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
+    bbs_issuer_job* job = nullptr;
+    return issuer_sync(bbs_issuer_proof_gen_submit(is, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho,
+                                                   octets_out, oct_off_out, status, &job), job);
 }
 
 int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa, const uint8_t* pb, int8_t* status) {

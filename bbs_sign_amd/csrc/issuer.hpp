@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -136,6 +137,17 @@ struct Group {
     std::vector<uint64_t> out_off;
     bbs_job* job = nullptr;
 };
+}  // namespace issuer_detail
+
+// a routed call in flight: the groups (packed inputs, their jobs, their result buffers) and how to scatter the results
+// into the caller's buffers once every group has been waited for
+struct bbs_issuer_job {
+    std::map<size_t, issuer_detail::Group> groups;
+    std::function<void(std::map<size_t, issuer_detail::Group>&)> scatter;
+    bool delivered = false;
+};
+
+namespace issuer_detail {
 inline void free_jobs(std::map<size_t, Group>& groups) {
     for (auto& kv : groups) if (kv.second.job) { bbs_job_free(kv.second.job); kv.second.job = nullptr; }
 }

@@ -928,6 +928,14 @@ class Issuer:
         n, keep, args = self.pack_proof_verify(proof_octets, disclosed_raw, disclosed_idx, headers, phs)
         return self.proof_verify_packed(n, args)
 
+    def proof_verify_submit_packed(self, n, args) -> "IssuerJob":
+        """bbs_issuer_proof_verify_submit: returns at once; ``job.wait()`` delivers ``job.result`` (the statuses)."""
+        st = np.full(max(n, 1), -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        Engine._chk(self.lib.bbs_issuer_proof_verify_submit(self.h, n, *args, st.ctypes.data_as(_lib.c_i8p), ctypes.byref(j)),
+                    "bbs_issuer_proof_verify_submit")
+        return IssuerJob(self.lib, j, st[:n])
+
     def verify(self, sig_octets, messages_raw, headers=None) -> np.ndarray:
         n = len(sig_octets)
         ob, bad = self._sig_octets(sig_octets)
@@ -976,3 +984,24 @@ class Issuer:
         for i in bad:
             st[i] = -42
         return [bytes(out[int(off[i]):int(off[i + 1])]) if st[i] == 1 else b"" for i in range(n)], st[:n]
+
+
+class IssuerJob:
+    """A routed issuer call in flight (bbs_issuer_job)."""
+
+    def __init__(self, lib, handle, result):
+        self.lib, self.h, self.result = lib, handle, result
+
+    def wait(self):
+        Engine._chk(self.lib.bbs_issuer_job_wait(self.h), "bbs_issuer_job_wait")
+
+    def free(self):
+        if self.h:
+            self.lib.bbs_issuer_job_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

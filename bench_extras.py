@@ -200,6 +200,22 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         st_i = iss.proof_verify_packed(n_i, args_i)
     bls["issuer_proof_verify_two_lengths_one_list_at_a_time"] = 16 * n / (time.perf_counter() - t1)
     assert (st_i == 1).all() and iss.context_count() == 2
+    pend_i = []
+
+    def retire_i():
+        j = pend_i.pop(0)
+        j.wait()
+        assert (j.result == 1).all()
+        j.free()
+    for phase in (0, 1):                              # warm, then timed: four lists (eight jobs) in flight
+        t1 = time.perf_counter()
+        for _ in range(32):
+            if len(pend_i) >= 4:
+                retire_i()
+            pend_i.append(iss.proof_verify_submit_packed(n_i, args_i))
+        while pend_i:
+            retire_i()
+    bls["issuer_proof_verify_two_lengths_4_lists_in_flight"] = 32 * n / (time.perf_counter() - t1)
     iss.close()
 
     # ---- the other three operations from HOST buffers through their submit forms, 8 batches in flight, results checked:

@@ -466,6 +466,32 @@ int bbs_issuer_proof_gen(bbs_issuer* issuer, size_t n, const uint8_t* signature_
                          const uint8_t* ph, const uint64_t* ph_off,
                          uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status);
 
+/* The asynchronous forms, for a serving loop that keeps several lists in flight: *_submit packs the groups, submits them and
+ * returns; the inputs may be released at once, `status` and the output buffers must stay valid until bbs_issuer_job_wait,
+ * which waits for every group and scatters the results into the caller's order (BBS_E_STATE if an item was left undecided).
+ * bbs_issuer_job_free releases the job (after waiting for it if that has not happened).  Arguments as the synchronous calls. */
+typedef struct bbs_issuer_job bbs_issuer_job;
+int bbs_issuer_proof_verify_submit(bbs_issuer* issuer, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
+                                   const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                   const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                   const uint8_t* headers, const uint64_t* hdr_off,
+                                   const uint8_t* ph, const uint64_t* ph_off, int8_t* status, bbs_issuer_job** job_out);
+int bbs_issuer_verify_submit(bbs_issuer* issuer, size_t n, const uint8_t* signature_octets,
+                             const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                             const uint8_t* headers, const uint64_t* hdr_off, int8_t* status, bbs_issuer_job** job_out);
+int bbs_issuer_sign_submit(bbs_issuer* issuer, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
+                           const uint64_t* msg_item_off, const uint8_t* headers, const uint64_t* hdr_off,
+                           uint8_t* signature_octets_out, int8_t* status, bbs_issuer_job** job_out);
+int bbs_issuer_proof_gen_submit(bbs_issuer* issuer, size_t n, const uint8_t* signature_octets,
+                                const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
+                                const uint64_t* disclosed_idx, const uint64_t* didx_off,
+                                const uint8_t* random_scalars, const uint64_t* rnd_off,
+                                const uint8_t* headers, const uint64_t* hdr_off,
+                                const uint8_t* ph, const uint64_t* ph_off,
+                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_issuer_job** job_out);
+int bbs_issuer_job_wait(bbs_issuer_job* job);
+void bbs_issuer_job_free(bbs_issuer_job* job);
+
 /* ------------------------------------------------------------------------------------------
  * Host-side setup helpers: once per ciphersuite / key, no GPU involved.
  * ------------------------------------------------------------------------------------------ */

@@ -1787,6 +1787,18 @@ def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1,
         if i in (i_cut, long_i):
             continue
         assert int(bbs.proof_verify(suite, pk, proofs[i], headers[i], vph[i], vdm[i], disclosed[i])) == got[i], (curve, "proof_verify", i)
+    # the asynchronous form: three lists in flight (the second one is the tampered list), the same statuses
+    n_a, keep_a, args_a = iss.pack_proof_verify(vp, vdm, vdisc, headers, vph)
+    gp = [p if p else bytes(3 * c.fp_bytes + 128) for p in poct]
+    n_b, keep_b, args_b = iss.pack_proof_verify([gp[i] for i in ok], [dm[i] for i in ok], [disclosed[i] for i in ok],
+                                                [headers[i] for i in ok], [phs[i] for i in ok])
+    jobs = [iss.proof_verify_submit_packed(n_b, args_b), iss.proof_verify_submit_packed(n_a, args_a), iss.proof_verify_submit_packed(n_b, args_b)]
+    for j in jobs:
+        j.wait()
+    assert [int(x) for x in jobs[0].result] == [1] * len(ok) and [int(x) for x in jobs[2].result] == [1] * len(ok)
+    assert [int(x) for x in jobs[1].result] == want
+    for j in jobs:
+        j.free()
     # empty calls
     assert list(iss.proof_verify([], [], [])) == [] and list(iss.verify([], [])) == []
     iss.close()
