@@ -196,6 +196,8 @@ def test_latency_form_random_batch_and_errors(curve):
     pc.check_error_semantics(curve, None)
     pc.check_verify_octets(curve, None)
     pc.check_proof_verify_octets(curve, None)
+    pc.check_empty_batches(curve, None)
+    pc.check_batch_verification(curve, None, window_bits=8)
 
 
 @LATENCY

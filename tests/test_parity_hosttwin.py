@@ -129,3 +129,14 @@ def test_sign_verify_wire(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_issuer_mixed_lengths(twin, curve):
     pc.check_issuer_mixed_lengths(curve, twin)
+
+
+@pytest.mark.job_form(True)
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_latency_form_of_every_job(twin, curve):
+    """The latency form of a job (on the host twin: T1 on three lanes; the pairing stages are the one-lane ones in both forms)
+    through the cases that create jobs of every kind, incl. empty batches and batch verification."""
+    pc.check_random_batch(curve, twin, n=6, L=3, seed=3)
+    pc.check_empty_batches(curve, twin)
+    pc.check_batch_verification(curve, twin)
+    pc.check_submit(curve, twin)
