@@ -135,7 +135,9 @@ int bbs_ctx_set_fixed_base_tree(bbs_ctx* ctx, int enabled);
  * linear combinations of the items' G1 arguments (sum rho_i * Abar_i, sum rho_i * Bbar_i; for verify
  * sum rho_i * A_i, sum rho_i * (e_i A_i - B_i)) with 16 independent 8-bit coefficients rho_i per item derived
  * from a secret seed (bucket-method multi-scalar multiplication on the device), taken over the items that passed
- * every earlier check; only if one of those combined checks fails are the items checked one by one.  The booleans
+ * every earlier check (a proof_verify job in its latency form combines beside the challenge check instead of behind it:
+ * over the structurally valid items); only if one of those combined checks fails are the items still pending checked
+ * one by one.  The booleans
  * equal the reference's except with probability 2^-128 per batch.  seed32 = NULL draws the seed from the operating
  * system; a caller-supplied seed must be secret and fresh.  Takes effect for jobs uploaded afterwards. */
 int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32);
