@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the process group (RCCL for --backend nccl) even "
+                    "with one rank, so that the collectives of the N > 1 path run on the real backend of a one-GPU box")
     ap.add_argument("--min-region-s", type=float, default=1.0, help="if the K timed steps last less than this, a second, "
                     "longer region of the same loop is timed and reported beside `value` as `long_region` (0 = off)")
     args = ap.parse_args()
@@ -208,9 +210,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.all_ranks_on_device is not None:
             local_rank = args.all_ranks_on_device
         torch.cuda.set_device(local_rank)
