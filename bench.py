@@ -172,7 +172,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--window-bits", type=int, default=20)
-    ap.add_argument("--inflight", type=int, default=8, help="batches in flight per GPU (distinct data in every slot)")
+    ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU (distinct data in every slot).  6 = the measured "
+                    "optimum: a job owns two streams and the runtime has 14 hardware queues -- 4 / 6 in flight 1.51 / 1.52 M/s, 7 / 8 in "
+                    "flight (14 / 16 streams) 1.48 / 1.44 M/s (profiles/r03_x_inflight_sweep.log)")
     ap.add_argument("--config", default="proof_verify_4096", choices=["proof_verify_4096", "mixed65536"])
     ap.add_argument("--total", type=int, default=65536, help="mixed65536 only: length of the list (8192 = one rank's share "
                     "of the 65 536-item list at 8 GPUs, to rehearse the strong-scaling regime on one GPU)")

@@ -22,7 +22,7 @@ def short(name):
 
 
 with open(os.path.join(src, "stats", "stats_kernel_stats.csv")) as f, open(dst + "_kernel_stats.csv", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras --steps 64  (MI355X, 8 distinct batches of 4096 in flight, host-inclusive loop)\n")
+    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras --steps 64  (MI355X, the default number of distinct 4096-item batches in flight -- 6 since round 3 --, host-inclusive loop)\n")
     o.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in csv.DictReader(f):
         o.write('"%s",%s,%s,%d,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
