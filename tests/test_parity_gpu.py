@@ -39,7 +39,7 @@ def test_pippenger(curve):
 
 
 # Fixed-base window widths: 8 = the library default, 16 / 20 = what bench.py runs (BN254 / BLS12-381 headline).  Width 20
-# is the one whose digits straddle 32-bit words, whose last window is clamped and whose tables take 52 GB at L = 32.
+# is the one whose digits straddle 32-bit words, whose top window holds the carry of the signed recoding and whose tables take 26 GB at L = 32.
 WIDTHS = [("bls12_381", 8), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 8), ("bn254", 16), ("bn254", 20)]
 
 
