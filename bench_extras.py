@@ -45,7 +45,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         d_r = [list(range(r))] * n
         rn_r = [rn[:5 + L - r] for rn in rnds] if r >= R else None
         if rn_r is None:                               # fewer disclosed -> more undisclosed scalars than the workload drew
-            rn_r = [pc.bbs.seeded_random_scalars(suite, b"bbs-bench-rnd-r%d-" % r + pc.i2osp(b, 8),
+            rn_r = [pc.seeded_random_scalars(suite, b"bbs-bench-rnd-r%d-" % r + pc.i2osp(b, 8),
                                                 suite.api_id + b"MOCK_RANDOM_SCALARS_DST_", 5 + L - r) for b in range(n)]
         pr, st = eng.core_proof_gen_batch(sigs, msgs, d_r, rn_r)
         assert (st == 1).all()
