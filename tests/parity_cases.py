@@ -1806,3 +1806,38 @@ def check_issuer_mixed_lengths(curve, lib_path=None, seed=131, lengths=(3, 0, 1,
     # empty calls
     assert list(iss.proof_verify([], [], [])) == [] and list(iss.verify([], [])) == []
     iss.close()
+
+
+def check_issuer_threads(curve, lib_path=None, threads=3, rounds=2, seed=151):
+    """One issuer used from several host threads at once, every thread with its own mix of lengths (so that contexts are
+    created concurrently on first use): the signatures verify, a forged one does not, the statuses are per item."""
+    import threading
+    from bbs_sign_amd import Issuer
+    suite = bbs.SUITES[curve]
+    iss = Issuer(curve, suite.api_id, lib_path=lib_path, max_messages=8, window_bits=4 if lib_path else 8)
+    iss.set_secret_key(77 + seed)
+    errors = []
+
+    def worker(t):
+        try:
+            rng = random.Random(seed + t)
+            for r in range(rounds):
+                lens = [(t + r + k) % 5 for k in range(6)]
+                raw = [[bytes(rng.randrange(256) for _ in range(rng.choice([1, 20, 65]))) for _ in range(L)] for L in lens]
+                octs, st = iss.sign(raw)
+                assert [int(x) for x in st] == [1] * len(lens), list(st)
+                bad = list(octs)
+                bad[2] = bad[2][:-1] + bytes([bad[2][-1] ^ 1])
+                got = [int(x) for x in iss.verify(bad, raw)]
+                assert got == [0 if i == 2 else 1 for i in range(len(lens))], got
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert iss.context_count() == 5
+    iss.close()

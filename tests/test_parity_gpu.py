@@ -262,3 +262,8 @@ def test_issuer_mixed_lengths(curve):
     pc.check_issuer_mixed_lengths(curve, None, seed=137, lengths=(6, 6, 2, 4, 4, 9, 0, 1, 6, 2, 3, 3, 5), oracle_items=(0, 2))
     # table width chosen by the library from the free device memory (20 bits on an empty MI355X)
     pc.check_issuer_mixed_lengths(curve, None, seed=139, lengths=(2, 2, 1, 2, 1, 2, 1, 8, 2), oracle_items=(0,), window_bits=0)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_threads(curve):
+    pc.check_issuer_threads(curve, None, threads=4, rounds=3)

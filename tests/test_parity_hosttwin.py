@@ -140,3 +140,8 @@ def test_latency_form_of_every_job(twin, curve):
     pc.check_empty_batches(curve, twin)
     pc.check_batch_verification(curve, twin)
     pc.check_submit(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_threads(twin, curve):
+    pc.check_issuer_threads(curve, twin)
