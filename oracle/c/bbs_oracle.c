@@ -852,3 +852,15 @@ int orc_core_proof_verify(const uint8_t* pk192, int pk_inf, int L, const uint8_t
     free(dm); free(isd); free(g.gens);
     return res;
 }
+
+/* Plain sum  S = sum_i k_i * P_i  as the reference writes every such sum (sign.rs:120-126, proof_verify.rs:165-182):
+   independent MSB-first double-and-add multiplications, added one by one.  The checker of the device's bucket-method
+   (Pippenger) MSM at sizes the Python oracle is too slow for.  pts_le: n affine points (x || y little-endian, all-zero =
+   identity), scal_le: n canonical 32-byte little-endian scalars, out: the affine sum (all-zero = identity). */
+void orc_g1_msm_plain(size_t n, const uint8_t* pts_le, const uint8_t* scal_le, uint8_t* out) {
+    init_all();
+    g1j acc = g1j_inf();
+    for (size_t i = 0; i < n; i++)
+        acc = g1j_add(acc, g1_mul(g1j_from_aff(g1a_from_le(pts_le + 2 * FPB * i)), fr_from_le(scal_le + 32 * i)));
+    g1a_to_le(g1j_to_aff(acc), out);
+}

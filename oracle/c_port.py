@@ -70,6 +70,14 @@ class CPort:
         f = [int.from_bytes(bytes(out)[self.fpb * i:self.fpb * (i + 1)], "little") for i in range(4)]
         return ((f[0], f[1]), (f[2], f[3]))
 
+    def g1_msm_plain(self, points, scalars):
+        """sum_i scalars[i] * points[i] by independent double-and-add multiplications (None = identity)."""
+        assert len(points) == len(scalars)
+        out = (ctypes.c_uint8 * (2 * self.fpb))()
+        self.lib.orc_g1_msm_plain(ctypes.c_size_t(len(points)), _b(b"".join(self._g1(p) for p in points)),
+                                  _b(b"".join(_fr(k) for k in scalars)), out)
+        return self._g1_dec(bytes(out))
+
     def core_sign(self, sk, generators, header, messages, api_id):
         L = len(messages)
         out = (ctypes.c_uint8 * (2 * self.fpb + 32))()

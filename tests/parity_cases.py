@@ -467,6 +467,78 @@ def check_pippenger(curve, lib_path=None, n=40):
     eng.close()
 
 
+def check_pippenger_tiles(curve, lib_path=None, n=9000, seed=27):
+    """The MULTI-TILE path of the bucket kernel (pippenger.hpp k_pip_window: n > 4096 items -> n_tiles > 1, the i0 offsets
+    of a tile's digits and points, the tile-sum array and PipTileSums) against (a) the plain-C oracle's sum of independent
+    double-and-add multiplications and (b) the Python oracle through the points' known discrete logarithms
+    (sum k_i [a_i] G = [sum k_i a_i] G).  The bucket method's edge cases sit ON the tile boundaries: the same point with
+    the same scalar in items 4095 | 4096 (last of tile 0, first of tile 1: the tile sums then meet in PipTileSums), P and -P
+    inside one tile and across a boundary, the identity as first / last item of a tile, scalars 0 / 1 / r - 1 in items
+    4095, 4096, 8191 of further sub-cases, and an off-curve point and a non-canonical scalar in the last tile."""
+    from oracle import c_port
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    P = c_port.port(curve)
+    eng = make_engine(curve, gens_for(suite, 2), b"x", lib_path)
+    T = 4096
+    logs = [rng.randrange(1, 1 << 40) for _ in range(n)]
+    pts = [c.g1_mul(c.g1, a) for a in logs]
+    sc = [rng.randrange(c.r) for _ in range(n)]
+
+    def put(i, log, k):
+        if i < n:
+            logs[i], sc[i] = log % c.r, k
+            pts[i] = c.g1_mul(c.g1, log % c.r) if log % c.r else None
+
+    last = n - 1
+    tiles = (n + T - 1) // T
+    # equal points with equal digits across the boundary 4095 | 4096; P, -P inside tile 0 and across 8191 | 8192
+    put(T - 1, logs[7], sc[7]); put(T, logs[7], sc[7])
+    put(100, logs[101], sc[101]); put(101, -logs[101], sc[101])
+    put(2 * T - 1, logs[9], sc[9]); put(2 * T, -logs[9], sc[9])
+    # identity as the first item of tile 1's neighbour and as the very last item
+    put(T + 1, 0, sc[T + 1] if n > T + 1 else 0)
+    if last > T + 5:
+        put(last, 0, 5)
+    # one byte pattern in every window (all 32 digits equal: the same bucket of every window in two tiles)
+    put(5, logs[5], 0x0101010101010101010101010101010101010101010101010101010101010101 % c.r)
+    put(T + 5, logs[T + 5] if n > T + 5 else 1, 0x0101010101010101010101010101010101010101010101010101010101010101 % c.r)
+    got, st = eng.g1_msm_pippenger(pts, sc)
+    assert list(st) == [1] * n
+    want_c = P.g1_msm_plain(pts, sc)
+    want_py = c.g1_mul(c.g1, sum(a * k for a, k in zip(logs, sc)) % c.r)
+    assert want_c == want_py, "the two oracles disagree"
+    assert got == want_c, (curve, n)
+    # scalars 0 / 1 / r - 1 on the boundary items, an off-curve point and a non-canonical scalar in the last tile
+    sc2 = list(sc)
+    for i, k in ((T - 1, 0), (T, 1), (2 * T - 1, c.r - 1), (T - 2, c.r - 1), (T + 2, 0)):
+        if i < n:
+            sc2[i] = k
+    pts2 = list(pts)
+    bad = last - 1
+    pts2[bad] = (pts[bad][0], (pts[bad][1] + 1) % c.p)
+    sc2[last - 2] = c.r
+    got, st = eng.g1_msm_pippenger(pts2, sc2)
+    want_st = [1] * n
+    want_st[bad], want_st[last - 2] = -41, -40
+    assert list(st) == want_st
+    keep = [i for i in range(n) if want_st[i] == 1]
+    assert got == P.g1_msm_plain([pts2[i] for i in keep], [sc2[i] for i in keep]), (curve, n, "edge scalars")
+    # everything cancels across tiles: item i of tile 0 against item i of the LAST tile (P, -P with the same scalar)
+    m = min(T, n - (tiles - 1) * T)
+    pts3 = [None] * n
+    sc3 = [0] * n
+    for i in range(m):
+        pts3[i], sc3[i] = pts[i], sc[i]
+        j = (tiles - 1) * T + i
+        pts3[j], sc3[j] = (c.g1_neg(pts[i]) if pts[i] is not None else None), sc[i]
+    if tiles > 1:
+        got, st = eng.g1_msm_pippenger(pts3, sc3)
+        assert got is None and list(st) == [1] * n
+    eng.close()
+
+
 def check_batch_verification(curve, lib_path=None, n=9, L=4, seed=5, window_bits=None):
     """Opt-in batch verification (one combined pairing check, per-item fallback) returns the same statuses as the
     default per-item mode and the oracle: all-valid batch; items that fail before the pairing (they are left out of
@@ -715,6 +787,65 @@ def check_big_batch(curve, lib_path=None, n=4096, L=32, R=8, spot=2, window_bits
         assert (sigs[i].a, sigs[i].e) == (want_sig.a, want_sig.e)
         want = bbs.core_proof_gen(suite, pk, want_sig, b"", gens, b"", msgs[i], disclosed[i], suite.api_id, rnds[i])
         assert proof_eq(proofs[i], want)
+    eng.close()
+
+
+def check_bv_tiles(curve, lib_path=None, n=16384, L=8, R=2, window_bits=None, job_form=None):
+    """Batch verification on ONE job of more than 4096 items: the combination's bucket kernel then runs n_tiles > 1
+    workgroups per (set, window) and PipTileSums adds them (pippenger.hpp:208-349).  A tile read at a wrong offset would not
+    show on an all-valid batch (both point sets share the digits, the combined product stays 1): it shows as an item whose
+    pairing product is NOT 1 being waved through.  So: a self-consistent proof of a forged signature (challenge matches,
+    only the pairing decides, src/proof_verify.rs:112-115) is planted in every tile in turn -- first and last item of a
+    tile included -- together with failures before the pairing (:108-110) in tiles 0 and 3, and the statuses must equal the
+    per-item mode's, which are checked against the expected pattern and, for the planted items, the oracle."""
+    suite, eng, gens, sk, msgs, disclosed, rnds = bench_workload(curve, n, L, R, lib_path, window_bits)
+    c = suite.curve
+    pk = bbs.sk_to_pk(suite, sk)
+    T = 4096
+    tiles = (n + T - 1) // T
+    sigs, st = eng.core_sign_batch(msgs)
+    assert (st == 1).all()
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    dm = [m[:R] for m in msgs]
+    # planted pairing-only failures: one position per run, covering every tile and the boundary items of the tiles
+    plant_runs = [[min(2 * T + 1234, n - 1)], [T], [n - 1], [min(3 * T, n - 1), T - 1]]
+    planted = sorted({k for run in plant_runs for k in run})
+    fsigs = [Signature(c.g1_add(sigs[k].a, c.g1), sigs[k].e) for k in planted]
+    fps, st = eng.core_proof_gen_batch(fsigs, [msgs[k] for k in planted], [disclosed[k] for k in planted], [rnds[k] for k in planted])
+    assert (st == 1).all()
+    forged = dict(zip(planted, fps))
+    k0 = planted[0]
+    op = bbs.Proof(forged[k0].a_bar, forged[k0].b_bar, forged[k0].d, forged[k0].e_cap, forged[k0].r1_cap, forged[k0].r3_cap,
+                   forged[k0].commitments, forged[k0].challenge)
+    assert bbs.core_proof_verify(suite, pk, op, gens, b"", b"", dm[k0], disclosed[k0], suite.api_id) is False
+    # failures before the pairing in tiles 0 and 3 (they never enter the combination)
+    pre = [5, T - 2] + ([3 * T + 77] if n > 3 * T + 77 else [])
+    for i in pre:
+        proofs[i].commitments[0] = (proofs[i].commitments[0] + 1) % c.r
+    eng.set_batch_verification(True)
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)                  # combined checks pass: nobody falls back
+    assert [int(x) for x in st] == [0 if i in pre else 1 for i in range(n)]
+    for run in plant_runs:
+        cur = list(proofs)
+        for k in run:
+            cur[k] = forged[k]
+        want = [0 if (i in pre or i in run) else 1 for i in range(n)]
+        eng.set_batch_verification(True)
+        st_b = [int(x) for x in eng.core_proof_verify_batch(cur, dm, disclosed)]
+        eng.set_batch_verification(False)
+        st_e = [int(x) for x in eng.core_proof_verify_batch(cur, dm, disclosed)]
+        assert st_e == want, (curve, run, "per-item mode")
+        assert st_b == st_e, (curve, run, [i for i in range(n) if st_b[i] != st_e[i]][:8])
+    # core_verify in the same mode (points A and e A - B computed on the device, Montgomery form): forged A in tiles 1 and 3
+    vs = list(sigs)
+    vbad = [T + 3, n - 2]
+    for i in vbad:
+        vs[i] = Signature(c.g1_add(sigs[i].a, c.g1), sigs[i].e)
+    eng.set_batch_verification(True)
+    st = eng.core_verify_batch(vs, msgs)
+    assert [int(x) for x in st] == [0 if i in vbad else 1 for i in range(n)]
+    assert tiles > 1
     eng.close()
 
 

@@ -106,3 +106,24 @@ def test_config1_readme_example_bn254():
     from oracle import c_baseline
     r = c_baseline.config1(c_port.port("bn254"))
     assert r["verified"] and r["matches_python_oracle"]
+
+
+def test_plain_msm_matches_python_oracle():
+    """orc_g1_msm_plain (the checker of the device's multi-tile bucket MSM) against the Python oracle's sum, both curves,
+    with the bucket method's edge cases: identity, equal points, P and -P, scalars 0 / 1 / r - 1."""
+    from oracle.curves import BN254 as CB
+    for curve, c in (("bls12_381", C), ("bn254", CB)):
+        P = c_port.port(curve)
+        rng = random.Random(17)
+        pts = [c.g1_mul(c.g1, rng.randrange(1, c.r)) for _ in range(12)]
+        sc = [rng.randrange(c.r) for _ in range(12)]
+        sc[0], sc[1], sc[2] = 0, 1, c.r - 1
+        pts[3] = None
+        pts[5], sc[5] = pts[4], sc[4]
+        pts[7], sc[7] = c.g1_neg(pts[6]), sc[6]
+        want = None
+        for p_, k in zip(pts, sc):
+            want = c.g1_add(want, c.g1_mul(p_, k))
+        assert P.g1_msm_plain(pts, sc) == want
+        assert P.g1_msm_plain([pts[6], pts[7]], [5, 5]) is None
+        assert P.g1_msm_plain([], []) is None

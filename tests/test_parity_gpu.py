@@ -38,6 +38,23 @@ def test_pippenger(curve):
     pc.check_pippenger(curve, None, n=200)
 
 
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("n", [4097, 9000, 16384])
+def test_pippenger_tiles(curve, n):
+    """n > 4096: several tiles per (set, window) in k_pip_window -- one extra item, a ragged third tile, four full tiles."""
+    pc.check_pippenger_tiles(curve, None, n=n)
+
+
+@pytest.mark.parametrize("curve,window_bits", [("bls12_381", 20), ("bn254", 16)])
+def test_batch_verification_16384_item_job(curve, window_bits):
+    """one 16384-item job (n_tiles = 4), the job size DESIGN section 5 rule 7 quotes batch-verification rates for"""
+    pc.check_bv_tiles(curve, None, n=16384, window_bits=window_bits)
+
+
+def test_batch_verification_ragged_tiles():
+    pc.check_bv_tiles("bls12_381", None, n=4096 + 4096 + 37, L=4, R=1, window_bits=16)
+
+
 # Fixed-base window widths: 8 = the library default, 16 / 20 = what bench.py runs (BN254 / BLS12-381 headline).  Width 20
 # is the one whose digits straddle 32-bit words, whose top window holds the carry of the signed recoding and whose tables take 26 GB at L = 32.
 WIDTHS = [("bls12_381", 8), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 8), ("bn254", 16), ("bn254", 20)]
@@ -58,9 +75,15 @@ def test_full_batch_4096(curve, window_bits):
     pc.check_big_batch(curve, None, n=4096, L=32, R=8, window_bits=window_bits)
 
 
-@pytest.mark.parametrize("curve,window_bits", [("bls12_381", 8), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 16)])
+@pytest.mark.parametrize("curve,window_bits", [("bls12_381", 8), ("bls12_381", 16), ("bn254", 16)])
 def test_every_item_against_c_oracle(curve, window_bits):
     pc.check_batch_vs_c_oracle(None, n=1024, window_bits=window_bits, curve=curve)
+
+
+def test_every_item_of_the_baseline_batch_against_c_oracle():
+    """BASELINE's exact batch -- 4096 items, BLS12-381, L = 32, R = 8 -- at the window width bench.py runs (20 bits): every
+    signature, proof and boolean against the plain-C oracle (about 50 ms of CPU per item, spread over the host cores)."""
+    pc.check_batch_vs_c_oracle(None, n=4096, window_bits=20, curve="bls12_381")
 
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
