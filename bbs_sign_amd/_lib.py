@@ -103,8 +103,14 @@ SIGNATURES = {
                                        c_u8p, c_u64p, c_u8p, c_u64p, ctypes.POINTER(vp)]),
     "bbs_core_proof_gen_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p,
                                       c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_u64p, c_i8p]),
+    "bbs_device_free_bytes": (sz, [ci]),
+    "bbs_ctx_table_bytes": (sz, [vp]),
+    "bbs_issuer_set_budget": (ci, [vp, sz, sz]),
+    "bbs_issuer_table_bytes": (sz, [vp]),
     "bbs_job_run": (ci, [vp]),
     "bbs_job_wait": (ci, [vp]),
+    "bbs_jobs_wait_any": (ci, [ctypes.POINTER(vp), sz, ctypes.POINTER(sz)]),
+    "bbs_job_poll": (ci, [vp]),
     "bbs_job_size": (sz, [vp]),
     "bbs_job_device_bytes": (sz, [vp]),
     "bbs_job_fetch_status": (ci, [vp, c_i8p]),

@@ -250,8 +250,8 @@ void bbs_ctx_destroy(bbs_ctx* ctx) { delete ctx; }
 
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits) {
     if (!ctx || (bits != 0 && (bits < 4 || bits > 22))) return BBS_E_ARG;      // 0: chosen from the free device memory at set_generators
-    if (ctx->curve == BBS_CURVE_BLS12_381) { AS_BLS(ctx)->win_bits_requested = bits; if (bits) AS_BLS(ctx)->win_bits = bits; }
-    else { AS_BN(ctx)->win_bits_requested = bits; if (bits) AS_BN(ctx)->win_bits = bits; }
+    // (takes effect at the next bbs_ctx_set_generators; the width of tables already built does not change)
+    if (ctx->curve == BBS_CURVE_BLS12_381) AS_BLS(ctx)->win_bits_requested = bits; else AS_BN(ctx)->win_bits_requested = bits;
     return BBS_OK;
 }
 int bbs_ctx_set_batch_verification(bbs_ctx* ctx, int enabled, const uint8_t* seed32) {
@@ -352,8 +352,45 @@ int bbs_core_proof_gen_upload(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const
                     pg_upload<BnCurve>(AS_BN(ctx), n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, job, nullptr, nullptr, nullptr));
 }
 
+size_t bbs_device_free_bytes(int device_id) {
+    if (device_id < 0 || device_id >= rt::device_count() || rt::set_device(device_id)) return 0;
+    return rt::mem_free_bytes();
+}
+size_t bbs_ctx_table_bytes(const bbs_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->curve == BBS_CURVE_BLS12_381 ? static_cast<const Ctx<BlsCurve>*>(ctx)->table_bytes() : static_cast<const Ctx<BnCurve>*>(ctx)->table_bytes();
+}
 int bbs_job_run(bbs_job* job) { return job ? job->run() : BBS_E_ARG; }
 int bbs_job_wait(bbs_job* job) { return job ? job->wait() : BBS_E_ARG; }
+int bbs_job_poll(const bbs_job* job) { return !job ? BBS_E_ARG : (job->completed() ? 1 : 0); }
+// Completion-order retire: sleeps (condition variable, woken by the host functions behind the jobs' last operations)
+// until one of the jobs that have been run has completed, delivers it exactly as bbs_job_wait does and reports its
+// position.  Among several completed jobs the one that completed FIRST is taken.
+int bbs_jobs_wait_any(bbs_job* const* jobs, size_t n, size_t* index_out) {
+    if (!jobs || !index_out) return BBS_E_ARG;
+    CompletionHub& hub = CompletionHub::get();
+    size_t best = n;
+    {
+        std::unique_lock<std::mutex> lk(hub.mu);
+        for (;;) {
+            bool any_running = false;
+            uint64_t best_seq = 0;
+            for (size_t i = 0; i < n; i++) {
+                const bbs_job* j = jobs[i];
+                if (!j || !j->ever_run()) continue;
+                if (j->completed()) {
+                    const uint64_t q = j->done_seq.load(std::memory_order_relaxed);
+                    if (best == n || q < best_seq) { best = i; best_seq = q; }
+                } else any_running = true;
+            }
+            if (best != n) break;
+            if (!any_running) return BBS_E_STATE;         // nothing in the set has been run: there is nothing to wait for
+            hub.cv.wait(lk);
+        }
+    }
+    *index_out = best;
+    return jobs[best]->wait();
+}
 size_t bbs_job_size(const bbs_job* job) { return job ? job->n : 0; }
 int bbs_job_fetch_status(bbs_job* job, int8_t* st) { return (job && st) ? job->fetch_status(st) : BBS_E_ARG; }
 size_t bbs_job_device_bytes(const bbs_job* job) { return job ? job->device_bytes() : 0; }
@@ -441,8 +478,11 @@ int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
     bbs_job* job = nullptr;
     int rc = bbs_core_proof_verify_upload(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, &job);
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -468,8 +508,11 @@ int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, c
     int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr),
                       pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr));
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -492,8 +535,11 @@ int bbs_proof_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, con
     int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off),
                       pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off));
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -526,8 +572,11 @@ int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const ui
     bbs_job* job = nullptr;
     int rc = bbs_core_verify_upload(ctx, n, sigs, m, mo, h, ho, &job);
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -542,8 +591,11 @@ int bbs_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, 
     int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr),
                       vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr));
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -573,8 +625,11 @@ int bbs_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, co
     int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off),
                       vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off));
     if (rc) return rc;
+    job->hold_arm = true;
     rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     *job_out = job;
@@ -624,9 +679,12 @@ int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uin
 // sign / proof_gen in the submit form: the records follow the statuses to page-locked memory behind the last stage and
 // bbs_job_wait unpacks them into the caller's buffers (which must stay valid until then)
 static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out) {
+    job->hold_arm = true;
     int rc = job->run();
+    job->hold_arm = false;
     if (!rc) rc = job->enqueue_status_fetch();
     if (!rc && (o1 || o2 || o3)) rc = job->enqueue_result_fetch();
+    if (!rc) rc = job->arm_completion();
     if (rc) { delete job; return rc; }
     job->deliver_to = status;
     job->results_wanted = o1 || o2 || o3;
@@ -906,6 +964,23 @@ static int pk_to_octets(const uint8_t* rec, int is_identity, uint8_t* out) {
     g2_compress<C>(q, out);
     return BBS_OK;
 }
+// what bbs_ctx_set_public_key checks, without a context (bbs_issuer validates a key when it is set, not when it is first used)
+template <class C>
+static int pk_validate(const uint8_t* rec, int is_identity) {
+    using P = typename C::FpP;
+    constexpr int NB = 4 * P::NC;
+    if (is_identity) return BBS_OK;
+    G2Aff<C> q{};
+    if (!fe_from_le_bytes<P>(rec, q.x.c0) || !fe_from_le_bytes<P>(rec + NB, q.x.c1) ||
+        !fe_from_le_bytes<P>(rec + 2 * NB, q.y.c0) || !fe_from_le_bytes<P>(rec + 3 * NB, q.y.c1)) return BBS_E_PUBLIC_KEY;
+    return (g2_on_curve<C>(q) && g2_in_subgroup<C>(q)) ? BBS_OK : BBS_E_PUBLIC_KEY;
+}
+template <class C>
+static bool sk_in_range(const uint8_t* sk32) {
+    uint32_t l[8];
+    for (int k = 0; k < 8; k++) l[k] = le32(sk32 + 4 * k);
+    return limbs_lt_mod<typename C::FrP>(l);
+}
 #pragma GCC visibility push(default)
 extern "C" {
 #define CURVE_OK(c) ((c) == BBS_CURVE_BLS12_381 || (c) == BBS_CURVE_BN254)
@@ -1009,21 +1084,27 @@ int bbs_issuer_create(int curve, int device_id, const uint8_t* api_id, size_t ap
 void bbs_issuer_destroy(bbs_issuer* is) { delete is; }
 int bbs_issuer_set_public_key(bbs_issuer* is, const uint8_t* pk_affine, int is_identity) {
     if (!is || (!is_identity && !pk_affine)) return BBS_E_ARG;
+    if (int rc = is->curve == BBS_CURVE_BLS12_381 ? pk_validate<BlsCurve>(pk_affine, is_identity) : pk_validate<BnCurve>(pk_affine, is_identity)) return rc;
     std::lock_guard<std::mutex> g(is->mu);
+    if (is->configuration_locked()) return BBS_E_STATE;       // a routed list is in flight: its jobs read the contexts' keys
     const size_t fpb = bbs_fp_bytes(is->curve);
     is->pk.assign(4 * fpb, 0);
     if (!is_identity) std::memcpy(is->pk.data(), pk_affine, 4 * fpb);
     is->pk_inf = is_identity ? 1 : 0;
-    for (auto& kv : is->by_count) if (int rc = bbs_ctx_set_public_key(kv.second, is->pk.data(), is->pk_inf)) return rc;
     is->pk_set = true; is->sk_set = false;
+    volatile uint8_t* s = is->sk;
+    for (int k = 0; k < 32; k++) s[k] = 0;
+    is->epoch++;
     return BBS_OK;
 }
 int bbs_issuer_set_secret_key(bbs_issuer* is, const uint8_t* sk32) {
     if (!is || !sk32) return BBS_E_ARG;
+    if (!(is->curve == BBS_CURVE_BLS12_381 ? sk_in_range<BlsCurve>(sk32) : sk_in_range<BnCurve>(sk32))) return BBS_E_ARG;
     std::lock_guard<std::mutex> g(is->mu);
-    for (auto& kv : is->by_count) if (int rc = bbs_ctx_set_secret_key(kv.second, sk32)) return rc;
+    if (is->configuration_locked()) return BBS_E_STATE;
     std::memcpy(is->sk, sk32, 32);
     is->sk_set = true; is->pk_set = true;
+    is->epoch++;
     return BBS_OK;
 }
 int bbs_issuer_set_limits(bbs_issuer* is, size_t max_messages, int window_bits) {
@@ -1032,16 +1113,22 @@ int bbs_issuer_set_limits(bbs_issuer* is, size_t max_messages, int window_bits) 
     is->max_messages = max_messages; is->window_bits = window_bits;
     return BBS_OK;
 }
+int bbs_issuer_set_budget(bbs_issuer* is, size_t max_contexts, size_t max_table_bytes) {
+    if (!is || max_contexts < 1) return BBS_E_ARG;
+    std::vector<std::shared_ptr<bbs_issuer_entry>> victims;
+    {
+        std::lock_guard<std::mutex> g(is->mu);
+        is->max_contexts = max_contexts; is->max_table_bytes = max_table_bytes;
+        is->evict(0, victims, nullptr);
+    }
+    return BBS_OK;                                             // (the victims' tables are released here, outside the lock)
+}
 int bbs_issuer_set_modes(bbs_issuer* is, int latency_mode, int batch_verification, int points_in_subgroup) {
     if (!is || latency_mode < 0 || latency_mode > 2) return BBS_E_ARG;
     std::lock_guard<std::mutex> g(is->mu);
+    if (is->configuration_locked()) return BBS_E_STATE;
     is->latency_mode = latency_mode; is->batch_verify = batch_verification != 0; is->in_subgroup = points_in_subgroup != 0;
-    for (auto& kv : is->by_count) {
-        int rc = bbs_ctx_set_latency_mode(kv.second, latency_mode);
-        if (!rc) rc = bbs_ctx_set_batch_verification(kv.second, is->batch_verify, nullptr);
-        if (!rc) rc = bbs_ctx_set_points_in_subgroup(kv.second, is->in_subgroup);
-        if (rc) return rc;
-    }
+    is->epoch++;
     return BBS_OK;
 }
 int bbs_issuer_context(bbs_issuer* is, size_t message_count, bbs_ctx** out) {
@@ -1053,15 +1140,22 @@ size_t bbs_issuer_context_count(bbs_issuer* is) {
     std::lock_guard<std::mutex> g(is->mu);
     return is->by_count.size();
 }
+size_t bbs_issuer_table_bytes(bbs_issuer* is) {
+    if (!is) return 0;
+    std::lock_guard<std::mutex> g(is->mu);
+    return is->table_bytes;
+}
 
 using issuer_detail::Group;
 using issuer_detail::Ragged;
 // items -> groups by message count; items whose count exceeds the issuer's limit get `too_many` and join no group
 static void issuer_group(bbs_issuer* is, size_t n, const std::vector<uint64_t>& count, const std::vector<int8_t>& pre, int8_t* status,
                          std::map<size_t, Group>& groups) {
+    size_t max_messages;
+    { std::lock_guard<std::mutex> g(is->mu); max_messages = is->max_messages; }
     for (size_t i = 0; i < n; i++) {
         if (pre[i] != 1) { status[i] = pre[i]; continue; }
-        if (count[i] > is->max_messages) { status[i] = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }
+        if (count[i] > max_messages) { status[i] = BBS_ST_INVALID_MESSAGE_AND_GENERATORS_LENGTH; continue; }
         Group& g = groups[(size_t)count[i]];
         g.L = (size_t)count[i];
         g.items.push_back(i);
@@ -1073,15 +1167,19 @@ static void issuer_group(bbs_issuer* is, size_t n, const std::vector<uint64_t>& 
 // the asynchronous form of every bbs_issuer_* call: *_submit packs and submits the groups and returns; bbs_issuer_job_wait
 // waits for every group and scatters statuses / outputs into the caller's buffers (which stay valid until then; the inputs may
 // be released when submit returns)
+static bool issuer_has(bbs_issuer* is, bool need_sk) {
+    std::lock_guard<std::mutex> g(is->mu);
+    return need_sk ? is->sk_set : is->pk_set;
+}
 static int issuer_finish_submit(int rc, std::unique_ptr<bbs_issuer_job>& job, bbs_issuer_job** out) {
-    if (rc) { issuer_detail::free_jobs(job->groups); return rc; }
+    if (rc) { (void)issuer_detail::wait_all(job->issuer, job->groups); return rc; }
     *out = job.release();
     return BBS_OK;
 }
 int bbs_issuer_job_wait(bbs_issuer_job* job) {
     if (!job) return BBS_E_ARG;
     if (job->delivered) return BBS_OK;
-    const int rc = issuer_detail::wait_all(job->groups);
+    const int rc = issuer_detail::wait_all(job->issuer, job->groups);
     if (rc) return rc;
     if (job->scatter) job->scatter(job->groups);
     job->delivered = true;
@@ -1089,7 +1187,7 @@ int bbs_issuer_job_wait(bbs_issuer_job* job) {
 }
 void bbs_issuer_job_free(bbs_issuer_job* job) {
     if (!job) return;
-    if (!job->delivered) (void)issuer_detail::wait_all(job->groups);       // the groups' buffers must outlive their jobs
+    (void)issuer_detail::wait_all(job->issuer, job->groups);       // the groups' buffers must outlive their jobs; releases the contexts
     delete job;
 }
 static int issuer_sync(int rc, bbs_issuer_job* job) {
@@ -1104,7 +1202,7 @@ int bbs_issuer_proof_verify_submit(bbs_issuer* is, size_t n, const uint8_t* oct,
                                    const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
                                    bbs_issuer_job** job_out) {
     if (!is || !status || !job_out || (n && (!oct_off || !msg_item_off || !dio))) return BBS_E_ARG;
-    if (!is->pk_set) return BBS_E_STATE;
+    if (!issuer_has(is, false)) return BBS_E_STATE;
     const Ragged ro{oct, oct_off, 1}, rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rh{h, ho, 1}, rp{ph, pho, 1};
     if (!ro.sane(n) || !rdi.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t fpb = bbs_fp_bytes(is->curve);
@@ -1117,19 +1215,20 @@ int bbs_issuer_proof_verify_submit(bbs_issuer* is, size_t n, const uint8_t* oct,
         count[i] = (len - floor_) / 32 + rdi.count(i);
     }
     std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    job->issuer = is;
     std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, pre, status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
         Group& g = kv.second;
-        bbs_ctx* c = nullptr;
-        if ((rc = is->context(g.L, &c))) break;
         g.oct.gather(ro, g.items); g.di.gather(rdi, g.items); g.hdr.gather(rh, g.items); g.ph.gather(rp, g.items);
         g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
         g.status.assign(g.items.size(), ST_PENDING);
-        rc = bbs_proof_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.oct.off.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(),
-                                          g.msgs.item_off.data(), reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(),
-                                          g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.status.data(), &g.job);
+        rc = issuer_detail::submit_group(is, g, [&g](bbs_ctx* c) {
+            return bbs_proof_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.oct.off.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(),
+                                                g.msgs.item_off.data(), reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(),
+                                                g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.status.data(), &g.job);
+        });
         if (rc) break;
     }
     job->scatter = [status](std::map<size_t, Group>& gs) {
@@ -1148,27 +1247,28 @@ int bbs_issuer_proof_verify(bbs_issuer* is, size_t n, const uint8_t* oct, const 
 int bbs_issuer_verify_submit(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
                              const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_issuer_job** job_out) {
     if (!is || !status || !job_out || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
-    if (!is->pk_set) return BBS_E_STATE;
+    if (!issuer_has(is, false)) return BBS_E_STATE;
     const Ragged rh{h, ho, 1};
     if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t so = bbs_fp_bytes(is->curve) + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
     std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    job->issuer = is;
     std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
         Group& g = kv.second;
-        bbs_ctx* c = nullptr;
-        if ((rc = is->context(g.L, &c))) break;
         g.oct.data.resize(g.items.size() * so + 8);
         for (size_t k = 0; k < g.items.size(); k++) std::memcpy(g.oct.data.data() + k * so, sig_octets + g.items[k] * so, so);
         g.hdr.gather(rh, g.items);
         g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
         g.status.assign(g.items.size(), ST_PENDING);
-        rc = bbs_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
-                                    g.hdr.data.data(), g.hdr.off.data(), g.status.data(), &g.job);
+        rc = issuer_detail::submit_group(is, g, [&g](bbs_ctx* c) {
+            return bbs_verify_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
+                                          g.hdr.data.data(), g.hdr.off.data(), g.status.data(), &g.job);
+        });
         if (rc) break;
     }
     job->scatter = [status](std::map<size_t, Group>& gs) {
@@ -1187,27 +1287,28 @@ int bbs_issuer_verify(bbs_issuer* is, size_t n, const uint8_t* sig_octets, const
 int bbs_issuer_sign_submit(bbs_issuer* is, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
                            const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status, bbs_issuer_job** job_out) {
     if (!is || !status || !job_out || (n && (!sig_octets_out || !msg_item_off))) return BBS_E_ARG;
-    if (!is->sk_set) return BBS_E_STATE;
+    if (!issuer_has(is, true)) return BBS_E_STATE;
     const Ragged rh{h, ho, 1};
     if (!rh.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t so = bbs_fp_bytes(is->curve) + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
     std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    job->issuer = is;
     std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
     if (n) std::memset(sig_octets_out, 0, n * so);
     int rc = BBS_OK;
     for (auto& kv : groups) {
         Group& g = kv.second;
-        bbs_ctx* c = nullptr;
-        if ((rc = is->context(g.L, &c))) break;
         g.hdr.gather(rh, g.items);
         g.msgs.gather(msg_bytes, msg_byte_off, msg_item_off, g.items);
         g.status.assign(g.items.size(), ST_PENDING);
         g.out.assign(g.items.size() * so + 8, 0);
-        rc = bbs_sign_wire_submit(c, g.items.size(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(), g.hdr.data.data(),
-                                  g.hdr.off.data(), g.out.data(), g.status.data(), &g.job);
+        rc = issuer_detail::submit_group(is, g, [&g](bbs_ctx* c) {
+            return bbs_sign_wire_submit(c, g.items.size(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(), g.hdr.data.data(),
+                                        g.hdr.off.data(), g.out.data(), g.status.data(), &g.job);
+        });
         if (rc) break;
     }
     job->scatter = [status, sig_octets_out, so](std::map<size_t, Group>& gs) {
@@ -1232,20 +1333,19 @@ int bbs_issuer_proof_gen_submit(bbs_issuer* is, size_t n, const uint8_t* sig_oct
                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
                                 uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status, bbs_issuer_job** job_out) {
     if (!is || !status || !oct_off_out || !job_out || (n && (!sig_octets || !octets_out || !msg_item_off || !dio || !rno))) return BBS_E_ARG;
-    if (!is->pk_set) return BBS_E_STATE;
+    if (!issuer_has(is, false)) return BBS_E_STATE;
     const Ragged rdi{reinterpret_cast<const uint8_t*>(di), dio, 8}, rr{rnd, rno, 32}, rh{h, ho, 1}, rp{ph, pho, 1};
     if (!rdi.sane(n) || !rr.sane(n) || !rh.sane(n) || !rp.sane(n) || !issuer_detail::msgs_sane(n, msg_bytes, msg_byte_off, msg_item_off)) return BBS_E_ARG;
     const size_t fpb = bbs_fp_bytes(is->curve), so = fpb + 32;
     std::vector<uint64_t> count(n);
     for (size_t i = 0; i < n; i++) count[i] = msg_item_off[i + 1] - msg_item_off[i];
     std::unique_ptr<bbs_issuer_job> job(new bbs_issuer_job());
+    job->issuer = is;
     std::map<size_t, Group>& groups = job->groups;
     issuer_group(is, n, count, std::vector<int8_t>(n, 1), status, groups);
     int rc = BBS_OK;
     for (auto& kv : groups) {
         Group& g = kv.second;
-        bbs_ctx* c = nullptr;
-        if ((rc = is->context(g.L, &c))) break;
         g.oct.data.resize(g.items.size() * so + 8);
         for (size_t k = 0; k < g.items.size(); k++) std::memcpy(g.oct.data.data() + k * so, sig_octets + g.items[k] * so, so);
         g.di.gather(rdi, g.items); g.rnd.gather(rr, g.items); g.hdr.gather(rh, g.items); g.ph.gather(rp, g.items);
@@ -1253,10 +1353,12 @@ int bbs_issuer_proof_gen_submit(bbs_issuer* is, size_t n, const uint8_t* sig_oct
         g.status.assign(g.items.size(), ST_PENDING);
         g.out.assign(g.items.size() * (3 * fpb + 32 * (4 + g.L)) + 8, 0);
         g.out_off.assign(g.items.size() + 1, 0);
-        rc = bbs_proof_gen_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
-                                       reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(), g.rnd.data.data(), g.rnd.off.data(),
-                                       g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.out.data(), g.out_off.data(),
-                                       g.status.data(), &g.job);
+        rc = issuer_detail::submit_group(is, g, [&g](bbs_ctx* c) {
+            return bbs_proof_gen_wire_submit(c, g.items.size(), g.oct.data.data(), g.msgs.bytes.data(), g.msgs.byte_off.data(), g.msgs.item_off.data(),
+                                             reinterpret_cast<const uint64_t*>(g.di.data.data()), g.di.off.data(), g.rnd.data.data(), g.rnd.off.data(),
+                                             g.hdr.data.data(), g.hdr.off.data(), g.ph.data.data(), g.ph.off.data(), g.out.data(), g.out_off.data(),
+                                             g.status.data(), &g.job);
+        });
         if (rc) break;
     }
     job->scatter = [status, octets_out, oct_off_out, n](std::map<size_t, Group>& gs) {

@@ -5,7 +5,8 @@
 // src/proof_gen.rs:91-96) and create_generators(proof.commitments.len() + disclosed_indexes.len() + 1) in proof_verify
 // (src/proof_verify.rs:40-43).  A bbs_ctx holds the device-resident tables of ONE generator set, so a batch whose items
 // differ in length needs several.  bbs_issuer keeps one context per message count it has seen -- created on first use:
-// hash-to-curve of the generators on the host, window tables and line tables on the device -- and ROUTES the items of a
+// hash-to-curve of the generators on the host, window tables and line tables on the device; at most max_contexts of them
+// and max_table_bytes of tables stay resident, idle ones leave least-recently-used first -- and ROUTES the items of a
 // call: items are grouped by their message count, every group goes through the context's one-call wire form
 // (bbs_*_wire_submit: octet strings and raw messages, everything else on the device), all groups are in flight
 // together, and the statuses / outputs are scattered back into the caller's order.
@@ -22,9 +23,25 @@
 
 #include "../../include/bbs_sign_amd.h"
 
+// one context of the issuer: the generator set of one message count
+struct bbs_issuer_entry {
+    size_t L = 0;
+    bbs_ctx* ctx = nullptr;              // built on first use, under `mu`
+    std::mutex mu;                       // serialises everything done to / submitted on this context (the bbs_ctx contract:
+                                         // one call at a time per context, one submitting thread for the asynchronous forms)
+    uint64_t config_epoch = 0;           // the issuer configuration (keys, modes) this context was last brought up to
+    size_t table_bytes = 0;
+    // guarded by the issuer's mutex:
+    int pins = 0;                        // routed lists in flight on this context (+1 for ever if it was handed out by bbs_issuer_context)
+    uint64_t last_use = 0;
+    bool dead = false;                   // evicted: a thread that still holds the entry must look it up again
+    ~bbs_issuer_entry() { if (ctx) bbs_ctx_destroy(ctx); }
+};
+
 struct bbs_issuer {
     int curve = 0, device = 0;
     std::vector<uint8_t> api_id;
+    // ---- configuration, guarded by `mu`; a context picks it up (by epoch) the next time it is used
     size_t max_messages = 1024;
     int window_bits = 0;                 // 0: by free device memory (bbs_ctx_set_window_bits(ctx, 0))
     bool pk_set = false, sk_set = false;
@@ -32,35 +49,174 @@ struct bbs_issuer {
     int pk_inf = 0;
     uint8_t sk[32] = {0};
     int latency_mode = 2, batch_verify = 0, in_subgroup = 0;
-    std::map<size_t, bbs_ctx*> by_count; // message count -> context
+    uint64_t epoch = 1;                  // bumped by every configuration change
+    // ---- resident contexts: bounded in number and in table bytes; idle ones leave least-recently-used first.  The message
+    // count of a proof comes from the length of an untrusted octet string: without the bound a caller sending one proof of
+    // every length up to max_messages would make the device hold that many table sets.
+    size_t max_contexts = 64;
+    size_t max_table_bytes = 0;          // 0: half of the device memory free when the first context is created
+    size_t table_bytes = 0;
+    uint64_t tick = 0;
+    std::map<size_t, std::shared_ptr<bbs_issuer_entry>> by_count;   // message count -> context
     std::mutex mu;
     ~bbs_issuer() {
-        for (auto& kv : by_count) bbs_ctx_destroy(kv.second);
+        by_count.clear();
         volatile uint8_t* s = sk;
         for (int k = 0; k < 32; k++) s[k] = 0;
     }
-    // the context of message count L (created and set up on first use)
-    int context(size_t L, bbs_ctx** out) {
+    struct Config {
+        bool pk_set, sk_set; std::vector<uint8_t> pk; int pk_inf; uint8_t sk[32]; int latency_mode, batch_verify, in_subgroup, window_bits;
+        uint64_t epoch;
+        ~Config() { volatile uint8_t* s = sk; for (int k = 0; k < 32; k++) s[k] = 0; }
+    };
+    void snapshot(Config& c) {           // `mu` held
+        c.pk_set = pk_set; c.sk_set = sk_set; c.pk = pk; c.pk_inf = pk_inf; std::memcpy(c.sk, sk, 32);
+        c.latency_mode = latency_mode; c.batch_verify = batch_verify; c.in_subgroup = in_subgroup; c.window_bits = window_bits; c.epoch = epoch;
+    }
+    bool configuration_locked() {        // `mu` held: a routed list is in flight
+        for (auto& kv : by_count) if (kv.second->pins > 0) return true;
+        return false;
+    }
+    // idle contexts, least recently used first, until `need_slots` more fit and the byte budget holds; the victims are
+    // destroyed by the caller AFTER releasing `mu` (bbs_ctx_destroy synchronises the context's stream)
+    void evict(size_t need_slots, std::vector<std::shared_ptr<bbs_issuer_entry>>& victims, const bbs_issuer_entry* keep) {
+        auto over = [&]() { return by_count.size() + need_slots > max_contexts || (max_table_bytes && table_bytes > max_table_bytes); };
+        while (over()) {
+            std::map<size_t, std::shared_ptr<bbs_issuer_entry>>::iterator lru = by_count.end();
+            for (auto it = by_count.begin(); it != by_count.end(); ++it) {
+                if (it->second->pins > 0 || it->second.get() == keep) continue;
+                if (lru == by_count.end() || it->second->last_use < lru->second->last_use) lru = it;
+            }
+            if (lru == by_count.end()) return;               // everything left is in use
+            lru->second->dead = true;
+            table_bytes -= std::min(table_bytes, lru->second->table_bytes);
+            victims.push_back(lru->second);
+            by_count.erase(lru);
+        }
+    }
+    // Pins the entry of message count L (created empty if new; BBS_E_NOMEM if the context limit is reached and nothing is
+    // idle) and returns the configuration to bring it up to.
+    int acquire(size_t L, std::shared_ptr<bbs_issuer_entry>& out, Config& cfg, bool forever = false) {
+        std::vector<std::shared_ptr<bbs_issuer_entry>> victims;
+        int rc = BBS_OK;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (L > max_messages) return BBS_E_ARG;
+            auto it = by_count.find(L);
+            if (it == by_count.end()) {
+                evict(1, victims, nullptr);
+                if (by_count.size() + 1 > max_contexts) rc = BBS_E_NOMEM;
+                else {
+                    auto e = std::make_shared<bbs_issuer_entry>();
+                    e->L = L;
+                    it = by_count.emplace(L, e).first;
+                }
+            }
+            if (!rc) {
+                out = it->second;
+                out->pins += forever ? (1 << 20) : 1;
+                out->last_use = ++tick;
+                snapshot(cfg);
+            }
+        }
+        victims.clear();                                     // destroyed here, outside the lock
+        return rc;
+    }
+    void release(const std::shared_ptr<bbs_issuer_entry>& e) {
+        if (!e) return;
         std::lock_guard<std::mutex> g(mu);
-        auto it = by_count.find(L);
-        if (it != by_count.end()) { *out = it->second; return BBS_OK; }
-        if (L > max_messages) return BBS_E_ARG;
-        bbs_ctx* c = nullptr;
-        int rc = bbs_ctx_create(curve, device, &c);
+        if (e->pins > 0) e->pins--;
+    }
+    // `e->mu` held: build the context if this is its first use, bring it up to the configuration
+    int prepare(bbs_issuer_entry* e, const Config& cfg) {
+        int rc = BBS_OK;
+        const bool fresh = e->ctx == nullptr;
+        if (fresh) {
+            bbs_ctx* c = nullptr;
+            if ((rc = bbs_ctx_create(curve, device, &c))) return rc;
+            if (max_table_bytes == 0) {                      // first context of the issuer: the byte budget
+                const size_t fr = bbs_device_free_bytes(device);
+                std::lock_guard<std::mutex> g(mu);
+                if (max_table_bytes == 0) max_table_bytes = std::max<size_t>(fr / 2, (size_t)64 << 20);
+            }
+            const size_t fpb = bbs_fp_bytes(curve);
+            std::vector<uint8_t> gens((e->L + 1) * 2 * fpb);
+            rc = bbs_create_generators(curve, e->L + 1, api_id.data(), api_id.size(), gens.data());
+            if (!rc) rc = bbs_ctx_set_window_bits(c, cfg.window_bits);
+            if (!rc) rc = bbs_ctx_set_generators(c, gens.data(), e->L + 1, api_id.data(), api_id.size());
+            if (rc) { bbs_ctx_destroy(c); return rc; }
+            e->ctx = c;
+            e->table_bytes = bbs_ctx_table_bytes(c);
+            e->config_epoch = 0;
+        }
+        if (e->config_epoch != cfg.epoch) {
+            bbs_ctx* c = e->ctx;
+            if (cfg.sk_set) rc = bbs_ctx_set_secret_key(c, cfg.sk);
+            else if (cfg.pk_set) rc = bbs_ctx_set_public_key(c, cfg.pk.data(), cfg.pk_inf);
+            if (!rc) rc = bbs_ctx_set_latency_mode(c, cfg.latency_mode);
+            if (!rc) rc = bbs_ctx_set_batch_verification(c, cfg.batch_verify, nullptr);
+            if (!rc) rc = bbs_ctx_set_points_in_subgroup(c, cfg.in_subgroup);
+            if (rc) return rc;
+            e->config_epoch = cfg.epoch;
+        }
+        if (fresh) {
+            // account for the new tables; make room among the idle contexts if the budget is exceeded
+            std::vector<std::shared_ptr<bbs_issuer_entry>> victims;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                table_bytes += e->table_bytes;
+                evict(0, victims, e);
+            }
+            victims.clear();
+        }
+        return BBS_OK;
+    }
+    // Runs fn(ctx) on the context of message count L with that context locked (one call at a time per context).  On success
+    // the entry stays pinned and is handed to the caller in `pinned` (released when the routed list has been waited for);
+    // on failure nothing stays pinned.
+    int with_context(size_t L, std::shared_ptr<bbs_issuer_entry>& pinned, const std::function<int(bbs_ctx*)>& fn) {
+        for (int attempt = 0; attempt < 4; attempt++) {
+            std::shared_ptr<bbs_issuer_entry> e;
+            Config cfg;
+            int rc = acquire(L, e, cfg);
+            if (rc) return rc;
+            {
+                std::lock_guard<std::mutex> g(e->mu);
+                bool dead;
+                { std::lock_guard<std::mutex> g2(mu); dead = e->dead; }
+                if (dead) { release(e); continue; }          // evicted between the look-up and the lock (it was idle then)
+                rc = prepare(e.get(), cfg);
+                if (!rc) rc = fn(e->ctx);
+            }
+            if (rc) {
+                release(e);
+                if (!e->ctx) {                               // never built: do not keep the empty slot
+                    std::lock_guard<std::mutex> g(mu);
+                    auto it = by_count.find(L);
+                    if (it != by_count.end() && it->second == e && e->pins == 0) { e->dead = true; by_count.erase(it); }
+                }
+                return rc;
+            }
+            pinned = e;
+            return BBS_OK;
+        }
+        return BBS_E_STATE;
+    }
+    // bbs_issuer_context: the raw context, for warm-up and for callers that drive it themselves; it is never evicted
+    int context(size_t L, bbs_ctx** out) {
+        std::shared_ptr<bbs_issuer_entry> e;
+        Config cfg;
+        int rc = acquire(L, e, cfg, true);
         if (rc) return rc;
-        const size_t fpb = bbs_fp_bytes(curve);
-        std::vector<uint8_t> gens((L + 1) * 2 * fpb);
-        rc = bbs_create_generators(curve, L + 1, api_id.data(), api_id.size(), gens.data());
-        if (!rc) rc = bbs_ctx_set_window_bits(c, window_bits);
-        if (!rc) rc = bbs_ctx_set_generators(c, gens.data(), L + 1, api_id.data(), api_id.size());
-        if (!rc && sk_set) rc = bbs_ctx_set_secret_key(c, sk);
-        else if (!rc && pk_set) rc = bbs_ctx_set_public_key(c, pk.data(), pk_inf);
-        if (!rc) rc = bbs_ctx_set_latency_mode(c, latency_mode);
-        if (!rc && batch_verify) rc = bbs_ctx_set_batch_verification(c, 1, nullptr);
-        if (!rc && in_subgroup) rc = bbs_ctx_set_points_in_subgroup(c, 1);
-        if (rc) { bbs_ctx_destroy(c); return rc; }
-        by_count[L] = c;
-        *out = c;
+        std::lock_guard<std::mutex> g(e->mu);
+        rc = prepare(e.get(), cfg);
+        if (rc) {
+            std::lock_guard<std::mutex> g2(mu);
+            e->pins -= (1 << 20);
+            if (!e->ctx) { auto it = by_count.find(L); if (it != by_count.end() && it->second == e) { e->dead = true; by_count.erase(it); } }
+            return rc;
+        }
+        *out = e->ctx;
         return BBS_OK;
     }
 };
@@ -136,29 +292,47 @@ struct Group {
     std::vector<uint8_t> out;            // produced octet strings
     std::vector<uint64_t> out_off;
     bbs_job* job = nullptr;
+    std::shared_ptr<bbs_issuer_entry> entry;      // pinned while the group's job is in flight
 };
 }  // namespace issuer_detail
 
 // a routed call in flight: the groups (packed inputs, their jobs, their result buffers) and how to scatter the results
 // into the caller's buffers once every group has been waited for
 struct bbs_issuer_job {
+    bbs_issuer* issuer = nullptr;
     std::map<size_t, issuer_detail::Group> groups;
     std::function<void(std::map<size_t, issuer_detail::Group>&)> scatter;
     bool delivered = false;
 };
 
 namespace issuer_detail {
-inline void free_jobs(std::map<size_t, Group>& groups) {
-    for (auto& kv : groups) if (kv.second.job) { bbs_job_free(kv.second.job); kv.second.job = nullptr; }
+// (bbs_job_free waits for the job's streams: the context is idle for this list from then on)
+inline void free_jobs(bbs_issuer* is, std::map<size_t, Group>& groups) {
+    for (auto& kv : groups) {
+        if (kv.second.job) { bbs_job_free(kv.second.job); kv.second.job = nullptr; }
+        if (kv.second.entry) { is->release(kv.second.entry); kv.second.entry.reset(); }
+    }
 }
-inline int wait_all(std::map<size_t, Group>& groups) {
+inline int wait_all(bbs_issuer* is, std::map<size_t, Group>& groups) {
     int rc = BBS_OK;
     for (auto& kv : groups) {
         if (!kv.second.job) continue;
         const int r = bbs_job_wait(kv.second.job);
         if (r && !rc) rc = r;
     }
-    free_jobs(groups);
+    free_jobs(is, groups);
+    return rc;
+}
+// One group of a routed call: fn(ctx) submits the group's job on the context of its message count.  A context that cannot
+// be set up for lack of device memory (or because every resident context is busy and the limit is reached) fails THIS
+// group's items with BBS_ST_NO_RESOURCES -- the other groups of the call are served; any other failure aborts the call.
+inline int submit_group(bbs_issuer* is, Group& g, const std::function<int(bbs_ctx*)>& fn) {
+    const int rc = is->with_context(g.L, g.entry, fn);
+    if (rc == BBS_E_NOMEM) {
+        g.status.assign(g.items.size(), (int8_t)BBS_ST_NO_RESOURCES);
+        if (g.job) { bbs_job_free(g.job); g.job = nullptr; }
+        return BBS_OK;
+    }
     return rc;
 }
 

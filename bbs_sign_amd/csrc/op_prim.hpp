@@ -13,42 +13,54 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
         if (!fe_from_le_bytes<typename C::FpP>(g + k * 2 * FPB + FPB, tmp[k].y)) return BBS_E_ARG;
         if (!g1a_on_curve<C>(tmp[k])) return BBS_E_ARG;
     }
-    gens.swap(tmp);
-    L = (int)count - 1;
-    api_id.assign(aid, aid + aid_len);
-    gens_set = true;
-    // fixed-base tables over [P1, Q1, H_1..H_L]
-    const int nb = L + 2;
-    if (win_bits_requested == 0) {
-        // automatic width: the widest of {20, 16, 12, 8} whose tables fit an eighth of the memory now free on the device and
-        // 32 GiB (20 bits: 13 additions per scalar and 26 GB at 32 messages; 16: 16 additions, 4 GB, ~3.5 % slower
-        // proof_verify; 8: 32 additions, 29 MB) -- an issuer with many message counts (bbs_issuer) keeps many table sets
+    // Nothing of the context changes until the new tables have been BUILT: a failure below (no device memory, a HIP error)
+    // leaves the previous generator set, its tables and gens_set as they were.
+    const int L_new = (int)count - 1;
+    const int nb = L_new + 2;                    // fixed-base tables over [P1, Q1, H_1..H_L]
+    auto table_bytes_at = [&](int c) { return (size_t)nb * ((256 + c - 1) / c) * ((size_t)1 << (c - 1)) * 2 * N * 4; };
+    // candidate widths, widest first.  A requested width is the only candidate.  Automatic: the widest of {20, 16, 12, 8}
+    // whose tables fit an eighth of the memory now free on the device and 32 GiB (20 bits: 13 additions per scalar and 26 GB
+    // at 32 messages; 16: 16 additions, 2 GB, ~3.5 % slower proof_verify; 8: 32 additions, 15 MB) -- and, because that is a
+    // snapshot (other ranks or processes on the device, fragmentation), every narrower width after it as a fallback when
+    // the allocation itself fails.
+    std::vector<int> widths;
+    if (win_bits_requested) widths.push_back(win_bits_requested);
+    else {
         const size_t free_b = rt::mem_free_bytes();
         const size_t budget = std::min<size_t>(free_b / 8, (size_t)32 << 30);
-        win_bits = 8;
-        for (int c : {20, 16, 12}) {
-            const size_t bytes = (size_t)nb * ((256 + c - 1) / c) * ((size_t)1 << (c - 1)) * 2 * N * 4;
-            if (bytes <= budget) { win_bits = c; break; }
-        }
+        for (int c : {20, 16, 12, 8}) if (c == 8 || table_bytes_at(c) <= budget) widths.push_back(c);
     }
-    const int W = (256 + win_bits - 1) / win_bits;
-    const size_t per_win = (size_t)1 << (win_bits - 1);            // signed digits: |digit| = 1 .. 2^(c-1)
     std::vector<uint32_t> bases((size_t)nb * 2 * N);
     auto put = [&](size_t k, const G1Aff<C>& p) {
         for (int j = 0; j < N; j++) { bases[k * 2 * N + j] = p.x.v[j]; bases[k * 2 * N + N + j] = p.y.v[j]; }
     };
     put(0, hc.p1);
-    for (size_t k = 0; k < gens.size(); k++) put(1 + k, gens[k]);
-    if (d_bases.alloc(bases.size() * 4)) return BBS_E_NOMEM;
-    if (d_winbase.alloc((size_t)nb * W * 2 * N * 4)) return BBS_E_NOMEM;
-    if (d_tables.alloc((size_t)nb * W * per_win * 2 * N * 4)) return BBS_E_NOMEM;
-    if (rt::h2d(d_bases.p, bases.data(), bases.size() * 4, stream)) return BBS_E_HIP;
+    for (size_t k = 0; k < tmp.size(); k++) put(1 + k, tmp[k]);
+    DevBuf n_bases, n_winbase, n_tables;
+    if (n_bases.alloc(bases.size() * 4)) return BBS_E_NOMEM;
+    int wb = 0, W = 0;
+    size_t per_win = 0;
+    for (int c : widths) {
+        W = (256 + c - 1) / c;
+        per_win = (size_t)1 << (c - 1);                         // signed digits: |digit| = 1 .. 2^(c-1)
+        if (n_winbase.alloc((size_t)nb * W * 2 * N * 4) == 0 && n_tables.alloc((size_t)nb * W * per_win * 2 * N * 4) == 0) { wb = c; break; }
+        n_winbase.release(); n_tables.release();
+    }
+    if (!wb) return BBS_E_NOMEM;
+    if (rt::h2d(n_bases.p, bases.data(), bases.size() * 4, stream)) return BBS_E_HIP;
     TabArgs<C> ta;
-    ta.n_bases = nb; ta.win_bits = win_bits; ta.n_windows = W;
-    ta.bases = d_bases.as<uint32_t>(); ta.winbase = d_winbase.as<uint32_t>(); ta.tables = d_tables.as<uint32_t>();
+    ta.n_bases = nb; ta.win_bits = wb; ta.n_windows = W;
+    ta.bases = n_bases.as<uint32_t>(); ta.winbase = n_winbase.as<uint32_t>(); ta.tables = n_tables.as<uint32_t>();
     if (rt::launch<TabWinBase<C>>(stream, ta, (size_t)nb)) return BBS_E_HIP;
     if (rt::launch<TabEntry<C>>(stream, ta, (size_t)nb * W * per_win)) return BBS_E_HIP;
     if (rt::sync(stream)) return BBS_E_HIP;
+    // ---- commit
+    d_bases.swap(n_bases); d_winbase.swap(n_winbase); d_tables.swap(n_tables);      // (the previous buffers are released with the locals)
+    gens.swap(tmp);
+    L = L_new;
+    api_id.assign(aid, aid + aid_len);
+    gens_set = true;
+    win_bits = wb;
     hc.L = L; hc.n_bases = nb; hc.win_bits = win_bits; hc.n_windows = W;
     for (int j = 0; j < 8; j++) hc.fix_bias[j] = 0;
     for (int w = 0; w + 1 < W; w++) { const int b = win_bits * w + win_bits - 1; hc.fix_bias[b >> 5] |= 1u << (b & 31); }

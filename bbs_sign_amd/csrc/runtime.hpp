@@ -17,6 +17,7 @@
 #include <iterator>
 #include <map>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -119,7 +120,10 @@ inline int dmalloc(void** p, size_t b) {
         auto it = m.find(cls);
         if (it != m.end()) { *p = it->second; m.erase(it); P.pooled_bytes[current_device()] -= cls; return 0; }
     }
-    return hipMalloc(p, cls) == hipSuccess ? 0 : -1;
+    if (hipMalloc(p, cls) == hipSuccess) return 0;
+    (void)hipGetLastError();      // an allocation that failed must not be reported again by the next launch's error check
+    *p = nullptr;
+    return -1;
 }
 inline void dfree(void* p, size_t b, int dev) {        // dev = the device the buffer was allocated on
     const size_t cls = size_class(b);
@@ -294,7 +298,8 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() { if (p) rt::dfree(p, bytes, dev); p = nullptr; bytes = 0; }
-    int alloc(size_t b) { release(); bytes = b; dev = rt::current_device(); return rt::dmalloc(&p, b); }
+    int alloc(size_t b) { release(); bytes = b; dev = rt::current_device(); if (rt::dmalloc(&p, b)) { p = nullptr; bytes = 0; return -1; } return 0; }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); std::swap(dev, o.dev); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -401,6 +406,14 @@ struct BytePool {
 // =============================================================================================
 // context
 // =============================================================================================
+// jobs alive per DEVICE, whatever context they belong to: what the AUTO form of a job goes by (Ctx::latency_form_now).
+// A process that drives one GPU through several contexts -- an issuer with one context per message count, a BLS12-381 and
+// a BN254 engine side by side (mixed.py) -- shares the chip among all their jobs; counting per context would give every
+// one of them the latency form (more instructions for a shorter path) exactly where throughput decides.
+inline std::atomic<int>& device_live_jobs(int dev) {
+    static std::atomic<int> live[64];
+    return live[(unsigned)dev & 63u];
+}
 struct IJob;
 struct bbs_ctx {
     int curve = 0;
@@ -435,10 +448,10 @@ struct Ctx : bbs_ctx {
     // latency form of a job (bbs_ctx_set_latency_mode): proof_verify's T1 as three multiplications on three lanes instead
     // of one joint chain, the two Miller loops of a pairing product on separate lane groups -- a shorter critical path for
     // more work.  0 = never, 1 = always, 2 = AUTO (default): a job gets the latency form iff at most one other job of
-    // this context is alive when it is created, i.e. when it will have (most of) the chip to itself
+    // the DEVICE (any context, device_live_jobs) is alive when it is created, i.e. when it will have (most of) the chip to itself
     int latency_mode = 2;
     std::atomic<int> live_jobs{0};
-    bool latency_form_now() const { return latency_mode == 1 || (latency_mode == 2 && live_jobs.load() <= 2); }
+    bool latency_form_now() const { return latency_mode == 1 || (latency_mode == 2 && device_live_jobs(device).load() <= 2); }
     bool fix_tree = false;           // bbs_ctx_set_fixed_base_tree: the fixed-base sums as trees of affine additions
     uint32_t rlc_seed[8] = {0};
     uint64_t rlc_counter = 0;
@@ -492,6 +505,7 @@ struct Ctx : bbs_ctx {
     }
 
     int use() { return rt::set_device(device) ? BBS_E_HIP : BBS_OK; }
+    size_t table_bytes() const { return d_tables.bytes + d_winbase.bytes + d_bases.bytes + d_consts.bytes; }
 
     // domain prefix:  Z_pad || compress(pk) || I2OSP(L,8) || compress(Q1) || compress(H_i).. || api_id
     void rebuild_hash() {
@@ -581,9 +595,45 @@ struct Ctx : bbs_ctx {
 // =============================================================================================
 // jobs
 // =============================================================================================
+// Completion order (bbs_jobs_wait_any / bbs_job_poll).  Behind everything a run enqueues on a job's main stream the
+// runtime places ONE host function (hipLaunchHostFunc); it stamps the job with the next sequence number and wakes the
+// waiters -- the host thread sleeps on a condition variable, nothing polls the device.  A job may be armed more than once
+// per run (the submit forms add their copies to page-locked memory behind run()): it is complete when every armed
+// notification has fired.  The job's destructor synchronises its streams, so a notification never outlives its job.
+struct CompletionHub {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t seq = 0;
+    static CompletionHub& get() { static CompletionHub* h = new CompletionHub(); return *h; }      // lives as long as the process
+};
 struct bbs_job {
     size_t n = 0;
     virtual ~bbs_job() {}
+    std::atomic<uint32_t> armed{0};              // notifications placed behind this job's work (by its submitting thread)
+    std::atomic<uint32_t> fired{0};
+    std::atomic<uint64_t> done_seq{0};           // position in the process-wide completion order (of the last notification)
+    static void on_complete(void* p) {
+        bbs_job* j = static_cast<bbs_job*>(p);
+        CompletionHub& h = CompletionHub::get();
+        std::lock_guard<std::mutex> g(h.mu);
+        j->done_seq.store(++h.seq, std::memory_order_relaxed);
+        j->fired.fetch_add(1, std::memory_order_release);
+        h.cv.notify_all();
+    }
+    // behind what has been enqueued on the main stream so far (the main stream joins the second one before its last stage)
+    int arm_completion() {
+        armed.fetch_add(1, std::memory_order_relaxed);
+#ifdef BBS_HOST_TWIN
+        on_complete(this);
+        return BBS_OK;
+#else
+        if (use()) return BBS_E_HIP;
+        return hipLaunchHostFunc(stream(), &bbs_job::on_complete, this) == hipSuccess ? BBS_OK : BBS_E_HIP;
+#endif
+    }
+    bool hold_arm = false;                       // the submit functions arm once, behind their own copies (not run())
+    bool ever_run() const { return armed.load(std::memory_order_relaxed) != 0; }
+    bool completed() const { const uint32_t a = armed.load(std::memory_order_relaxed); return a != 0 && fired.load(std::memory_order_acquire) == a; }
     // aux = 1: the stage runs on the job's second stream, concurrently with the main-stream stages
     // that follow the fork point (start of the run); join = 1: the main stream first waits for
     // everything issued on the second stream
@@ -638,6 +688,7 @@ struct bbs_job {
             rc = enqueue_status_fetch();
             if (!rc && results_wanted) rc = enqueue_result_fetch();
         }
+        if (!rc && !hold_arm) rc = arm_completion();
         return rc;
     }
     // stage durations of the last run of a timed job; call after wait()
@@ -676,10 +727,12 @@ struct JobBase : bbs_job {
     explicit JobBase(Ctx<C>* c) : ctx(c) {
         main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); timed = c->stage_timing;
         ctx->live_jobs.fetch_add(1);
+        device_live_jobs(ctx->device).fetch_add(1);
         latency_form = ctx->latency_form_now();
     }
     ~JobBase() override {
         ctx->live_jobs.fetch_sub(1);
+        device_live_jobs(ctx->device).fetch_sub(1);
         (void)ctx->use();            // streams and buffers go back to this device's pools
         if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
         if (main_ready) { rt::sync(main); rt::stream_destroy(main); }

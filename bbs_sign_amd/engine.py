@@ -775,6 +775,27 @@ class Job:
         if self._fixup is not None:
             self._fixup()
 
+    def done(self) -> bool:
+        """bbs_job_poll: everything enqueued for the job has finished (wait() will not block)."""
+        return self.eng.lib.bbs_job_poll(self.h) == 1
+
+    @staticmethod
+    def wait_any(jobs) -> int:
+        """bbs_jobs_wait_any: sleeps until one of `jobs` (entries may be None) has finished, delivers it as wait() does and
+        returns its position -- the job that finished FIRST, whatever the order of submission."""
+        live = [(k, j) for k, j in enumerate(jobs) if j is not None and j.h]
+        if not live:
+            raise ValueError("wait_any: no job")
+        arr = (ctypes.c_void_p * len(live))(*[j.h for _, j in live])
+        idx = ctypes.c_size_t(0)
+        rc = live[0][1].eng.lib.bbs_jobs_wait_any(arr, len(live), ctypes.byref(idx))
+        Engine._chk(rc, "bbs_jobs_wait_any")
+        k, j = live[idx.value]
+        j._waited = True
+        if j._fixup is not None:
+            j._fixup()
+        return k
+
     def output(self):
         """Submit form of sign / proof_gen, after wait(): (signatures | proofs with None for failed items, statuses)."""
         if self._decode is None or not self._waited:
@@ -897,6 +918,13 @@ class Issuer:
 
     def context_count(self) -> int:
         return int(self.lib.bbs_issuer_context_count(self.h))
+
+    def set_budget(self, max_contexts: int = 64, max_table_bytes: int = 0):
+        """bbs_issuer_set_budget: resident contexts / table bytes (0 = half of the free device memory); idle ones beyond leave at once."""
+        Engine._chk(self.lib.bbs_issuer_set_budget(self.h, max_contexts, max_table_bytes), "bbs_issuer_set_budget")
+
+    def table_bytes(self) -> int:
+        return int(self.lib.bbs_issuer_table_bytes(self.h))
 
     def warm(self, message_count: int):
         c = ctypes.c_void_p()

@@ -57,35 +57,66 @@ def prepare_rank(engines: Dict[str, object], plan_for_rank: Dict[str, List[int]]
     return out
 
 
-def run_rank(batches: List[PackedBatch], inflight: int = 8) -> Dict[str, np.ndarray]:
-    """Submit every batch (at most `inflight` outstanding, one submitting thread), return {curve: statuses in plan
-    order}.  Alternates curves so that BN254 and BLS12-381 batches overlap on the device."""
-    by_curve: Dict[str, List[PackedBatch]] = {}
-    for b in batches:
-        by_curve.setdefault(b.curve, []).append(b)
-    order = []
-    queues = [list(v) for _, v in sorted(by_curve.items())]
-    while any(queues):
-        for q in queues:
-            if q:
-                order.append(q.pop(0))
-    results = {id(b): None for b in batches}
-    pending = []
-    for b in order:
-        if len(pending) >= inflight:
-            ob, job = pending.pop(0)
-            job.wait()
-            results[id(ob)] = job.result.copy()
-            job.free()
-        pending.append((b, b.eng.submit_packed(b.n, b.args)))
-    for ob, job in pending:
-        job.wait()
-        results[id(ob)] = job.result.copy()
+class ListPipeline:
+    """One rank's jobs of CONSECUTIVE lists kept in flight: the jobs of list k + 1 are submitted before the statuses of
+    list k are collected, gathered and merged, so the device never drains between lists and the exchange (one all_gather
+    of int8 per list) and the merge run beside the next list's kernels.  At 8 GPUs a rank owns two jobs per list; run one
+    list at a time the GPU idles through every list's ramp, drain, gather and merge (round 3: 7.2 - 7.7 ms per 8192-item
+    share against 4.35 ms of critical path).  Jobs are retired in completion order (bbs_jobs_wait_any), at most `inflight`
+    outstanding; submission alternates curves so that BN254 and BLS12-381 jobs overlap on the device."""
+
+    def __init__(self, batches: List[PackedBatch], inflight: int = 8):
+        self.by_curve: Dict[str, List[PackedBatch]] = {}
+        for b in batches:
+            self.by_curve.setdefault(b.curve, []).append(b)
+        self.order: List[PackedBatch] = []
+        queues = [list(v) for _, v in sorted(self.by_curve.items())]
+        while any(queues):
+            for q in queues:
+                if q:
+                    self.order.append(q.pop(0))
+        self.inflight = max(1, inflight)
+        self.pending = []            # (list id, batch, job) in submission order
+        self.results: Dict[int, Dict[int, np.ndarray]] = {}
+        self.next_id = 0
+
+    def _retire_one(self):
+        from .engine import Job
+        k = Job.wait_any([j for _, _, j in self.pending])      # raises if an item was left undecided (BBS_E_STATE)
+        lid, b, job = self.pending.pop(k)
+        self.results[lid][id(b)] = job.result.copy()
         job.free()
-    out = {}
-    for curve, bs in by_curve.items():
-        out[curve] = np.concatenate([results[id(b)] for b in bs]) if bs else np.zeros(0, dtype=np.int8)
-    return out
+
+    def submit_list(self) -> int:
+        """Enqueue one pass over this rank's share; returns the list's handle for collect()."""
+        lid = self.next_id
+        self.next_id += 1
+        self.results[lid] = {}
+        for b in self.order:
+            while len(self.pending) >= self.inflight:
+                self._retire_one()
+            self.pending.append((lid, b, b.eng.submit_packed(b.n, b.args)))
+        return lid
+
+    def collect(self, lid: int) -> Dict[str, np.ndarray]:
+        """Wait until every job of list `lid` has delivered -> {curve: statuses in plan order}.  Jobs of later lists that
+        finish meanwhile are retired too (their statuses wait for their own collect)."""
+        while len(self.results[lid]) < len(self.order):
+            self._retire_one()
+        res = self.results.pop(lid)
+        return {curve: (np.concatenate([res[id(b)] for b in bs]) if bs else np.zeros(0, dtype=np.int8))
+                for curve, bs in self.by_curve.items()}
+
+    def lists_in_flight_for(self, want_jobs: int) -> int:
+        """How many lists to keep submitted ahead so that about `want_jobs` jobs are alive (at least two lists)."""
+        return max(2, -(-max(1, want_jobs) // max(1, len(self.order))))
+
+
+def run_rank(batches: List[PackedBatch], inflight: int = 8) -> Dict[str, np.ndarray]:
+    """One list, start to finish: submit every batch (at most `inflight` outstanding, one submitting thread, completion-order
+    retire), return {curve: statuses in plan order}."""
+    pipe = ListPipeline(batches, inflight)
+    return pipe.collect(pipe.submit_list())
 
 
 def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> np.ndarray:

@@ -106,22 +106,30 @@ def make_slots(pc, suite, eng, n, L, R, n_slots, first_item, corrupt_slot=1):
     return slots, raw0
 
 
-def submit_loop(eng, slots, steps, inflight, first_step=0, collect_times=False):
+def submit_loop(eng, slots, steps, inflight, first_step=0, collect_times=False, fifo=False):
     """The serving loop of one submitting thread: step k submits slot k % len(slots); at most `inflight` jobs are
-    outstanding; every job's statuses are read.  Returns (#status mismatches, {stage: summed ms}, summed job ms)."""
+    outstanding; every job's statuses are read.  Jobs are retired in COMPLETION order (bbs_jobs_wait_any: the thread sleeps
+    until whichever outstanding job finishes first, reads its statuses and submits the next batch in its place) -- waiting
+    for the oldest job instead (fifo=True, round 3's loop, kept for the A/B) makes jobs submitted together finish together
+    and the loop run in convoys.  Returns (#status mismatches, {stage: summed ms}, summed job ms)."""
+    from bbs_sign_amd import Job
     pending, bad = [], 0
     stage_ms, job_ms = {}, 0.0
 
     def retire():
         nonlocal bad, job_ms
-        slot, job = pending.pop(0)
-        job.wait()                                   # raises if any item was left undecided (BBS_E_STATE)
+        if fifo:
+            k = 0
+            pending[0][1].wait()                     # raises if any item was left undecided (BBS_E_STATE)
+        else:
+            k = Job.wait_any([j for _, j in pending])
+        slot, job = pending.pop(k)
         bad += int((job.result != slot.expect).sum())
         if collect_times:
             tot, st = job.stage_times()
             job_ms += tot
-            for k, v in st.items():
-                stage_ms[k] = stage_ms.get(k, 0.0) + v
+            for nm, v in st.items():
+                stage_ms[nm] = stage_ms.get(nm, 0.0) + v
         job.free()
 
     for k in range(first_step, first_step + steps):
@@ -177,9 +185,13 @@ def main():
     ap.add_argument("--config", default="proof_verify_4096", choices=["proof_verify_4096", "mixed65536"])
     ap.add_argument("--total", type=int, default=65536, help="mixed65536 only: length of the list (8192 = one rank's share "
                     "of the 65 536-item list at 8 GPUs, to rehearse the strong-scaling regime on one GPU)")
+    ap.add_argument("--lists-in-flight", type=int, default=None, help="mixed65536 only: lists (steps) submitted ahead of the one being "
+                    "collected; default = enough for --inflight jobs alive, at least 2")
     ap.add_argument("--min-batch", type=int, default=None, help="mixed65536 only: smallest job a rank's share is cut into")
     ap.add_argument("--latency-mode", type=int, default=None, help="A/B and profiling: bbs_ctx_set_latency_mode 0 = throughput form for every "
                     "job, 1 = latency form, default = the library's AUTO (by live jobs)")
+    ap.add_argument("--fifo-retire", action="store_true", help="A/B: wait for the OLDEST outstanding job (round 3's loop) instead of "
+                    "bbs_jobs_wait_any's completion order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sign/verify/proof_gen/BN254 figures")
     ap.add_argument("--fixed-base-tree", type=int, default=None, help="A/B: bbs_ctx_set_fixed_base_tree on (1) / off (0); default = the library's")
@@ -258,12 +270,12 @@ def main():
     msgs, disclosed, rnds, sigs, proofs, dm = raw0
     eng.set_stage_timing(not args.no_stage_timing)
 
-    bad, _, _ = submit_loop(eng, slots, max(args.warmup, n_slots), n_slots)
+    bad, _, _ = submit_loop(eng, slots, max(args.warmup, n_slots), n_slots, fifo=args.fifo_retire)
     assert bad == 0, "warm-up statuses differ from the expected pattern"
 
     barrier()
     t0 = time.perf_counter()
-    bad, stage_ms, job_ms = submit_loop(eng, slots, args.steps, n_slots, first_step=0, collect_times=not args.no_stage_timing)
+    bad, stage_ms, job_ms = submit_loop(eng, slots, args.steps, n_slots, first_step=0, collect_times=not args.no_stage_timing, fifo=args.fifo_retire)
     barrier()
     dt = time.perf_counter() - t0
     assert bad == 0, "timed statuses differ from the expected pattern (%d items)" % bad
@@ -276,7 +288,7 @@ def main():
         k2 = int(min(4096, max(args.steps, args.min_region_s / (dt / args.steps) * 1.1)))
         barrier()
         t1 = time.perf_counter()
-        bad2, _, _ = submit_loop(eng, slots, k2, n_slots)
+        bad2, _, _ = submit_loop(eng, slots, k2, n_slots, fifo=args.fifo_retire)
         barrier()
         dt2 = time.perf_counter() - t1
         assert bad2 == 0, "long-region statuses differ from the expected pattern"
@@ -315,7 +327,8 @@ def main():
             "config": {"workload": "BLS12-381 core_proof_verify, batch %d per GPU, 32 msgs / 8 disclosed, empty "
                                    "header/ph, one issuer key (BASELINE configs[3], proof_verify leg)" % n,
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
-                       "batches_in_flight": n_slots, "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),
+                       "batches_in_flight": n_slots, "retire_order": "fifo (oldest first)" if args.fifo_retire else "completion (bbs_jobs_wait_any)",
+                       "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),
                        "timed_region": "host buffers -> page-locked staging -> one async H2D -> device-side validation/"
                                        "unpack -> kernels -> async D2H of statuses; one submitting thread per GPU "
                                        "(SURVEY 8d)",

@@ -5,7 +5,9 @@ A step = the whole list once: `sharding.shard_plan` splits it by curve and then 
 rank owns two contexts (BLS12-381 with --window-bits, BN254 with 16-bit windows), cuts its share into 4096-item
 batches in HOST buffers, runs them through bbs_core_proof_verify_submit (one submitting thread, --inflight outstanding,
 curves alternating), and the statuses are exchanged with ONE all_gather of int8 (RCCL for --backend nccl) and merged
-with `sharding.merge_status`.  Strong scaling: the list is fixed, `value` = 65 536 x steps / wall.  Every 16th item of
+with `sharding.merge_status`.  Consecutive steps are PIPELINED (mixed.ListPipeline): the jobs of the next lists are
+submitted before the statuses of the oldest one are collected, so gather and merge run beside kernels and a rank that owns
+two jobs per list (8 GPUs) never drains; every list's merged statuses are still checked.  Strong scaling: the list is fixed, `value` = 65 536 x steps / wall.  Every 16th item of
 the global list is corrupted (one commitment incremented) and the merged statuses are compared with that pattern on
 every rank after every step.
 
@@ -54,19 +56,32 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
     batches = mixed.prepare_rank(engines, plan[rank], fetch_items, batch, args.inflight, min_batch)
     t_prep = time.perf_counter() - t_prep
     depth = max(1, args.inflight)
+    pipe = mixed.ListPipeline(batches, depth)
+    ahead = getattr(args, "lists_in_flight", None) or pipe.lists_in_flight_for(max(depth, 8))     # measured: 8192-item share 7.3 / 5.2 / 5.0 / 4.9 ms per list at 1 / 2 / 3 / 4 lists ahead (profiles/r04_b_*)
 
-    def step():
-        mine = mixed.run_rank(batches, depth)
-        return mixed.gather_statuses(plan, rank, mine, total, dist, red_dev)
+    def run_lists(count):
+        """`count` passes over the list, `ahead` of them submitted before the oldest is collected: while the statuses of
+        list k are gathered (one all_gather) and merged, the jobs of lists k + 1 .. k + ahead - 1 keep the device busy."""
+        out, handles = [], []
+        for k in range(count):
+            handles.append(pipe.submit_list())
+            if len(handles) >= ahead:
+                out.append(mixed.gather_statuses(plan, rank, pipe.collect(handles.pop(0)), total, dist, red_dev))
+        while handles:
+            out.append(mixed.gather_statuses(plan, rank, pipe.collect(handles.pop(0)), total, dist, red_dev))
+        return out
 
-    for _ in range(max(1, min(args.warmup, 2))):
-        assert np.array_equal(step(), expect), "warm-up statuses differ from the expected pattern"
-    steps = max(1, min(args.steps, 8))
+    if args.warmup < 0 or args.steps < 1:
+        raise SystemExit("bench_mixed: --steps must be >= 1 and --warmup >= 0 (got %d / %d)" % (args.steps, args.warmup))
+    warmup, steps = args.warmup, args.steps                # the driver's values, as given: never clamped
+    for res in run_lists(warmup):
+        assert np.array_equal(res, expect), "warm-up statuses differ from the expected pattern"
     barrier()
     t0 = time.perf_counter()
-    results = [step() for _ in range(steps)]
+    results = run_lists(steps)
     barrier()
     dt = time.perf_counter() - t0
+    assert len(results) == steps
     for res in results:
         assert np.array_equal(res, expect), "merged statuses differ from the expected pattern"
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -76,14 +91,15 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
     if rank == 0:
         emit(json.dumps({
             "metric": "BBS+ proof_verify/sec (mixed BN254 + BLS12-381 list of 65536)", "value": total * steps / dt,
-            "unit": "proof_verify/s", "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)),
+            "unit": "proof_verify/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: %d proof_verify = %d BN254 + %d BLS12-381 (L=%d, R=%d), sharded by curve "
                                    "then contiguously over %d GPU(s), batches of at most %d items from host buffers, one all_gather of int8 "
                                    "statuses per step" % (total, total // 2, total // 2, L, R, world, batch),
                        "batches_per_rank": len(batches), "batch_sizes_rank0": sorted({b.n for b in batches}, reverse=True),
-                       "items_per_rank": sum(b.n for b in batches), "batches_in_flight": depth,
+                       "items_per_rank": sum(b.n for b in batches), "batches_in_flight": depth, "lists_in_flight": ahead,
+                       "retire_order": "completion (bbs_jobs_wait_any)",
                        "backend": args.backend if world > 1 else None,
                        "fixed_base_window_bits": {"bls12_381": args.window_bits, "bn254": min(args.window_bits, 16)}},
             "checks": {"merged_statuses_exact_every_step": True, "corrupted": "every 16th global item"},

@@ -60,6 +60,9 @@ extern "C" {
 #define BBS_ST_NONCANONICAL (-40)             /* scalar >= r or coordinate >= p */
 #define BBS_ST_NOT_ON_CURVE (-41)            /* also: not in the prime-order subgroup (codec) */
 #define BBS_ST_INVALID_ENCODING (-42)        /* octet string of the wrong shape / forbidden identity or zero */
+#define BBS_ST_NO_RESOURCES (-43)            /* bbs_issuer_* only: the context of this item's message count could not be set
+                                              * up (device memory, or every resident context busy at the context limit); the
+                                              * item was NOT computed -- the other items of the call were; retry later */
 
 /* batch-level errors */
 #define BBS_OK 0
@@ -89,13 +92,18 @@ const char* bbs_source_hash(void);
  * this library was loaded before the process's first HIP call ("Build / deployment"). */
 int bbs_runtime_hw_queues(void);
 int bbs_device_count(void);
+size_t bbs_device_free_bytes(int device_id);          /* device memory free right now (0: no such device) */
 
 int bbs_ctx_create(int curve, int device_id, bbs_ctx** out);
 void bbs_ctx_destroy(bbs_ctx* ctx);
+/* device memory of the context's tables (fixed-base window tables, line tables, constants), in bytes */
+size_t bbs_ctx_table_bytes(const bbs_ctx* ctx);
 
 /* window width (bits) of the fixed-base tables, 4..22, or 0 (THE DEFAULT) = chosen at bbs_ctx_set_generators from the
- * memory free on the device: the widest of 20 / 16 / 12 / 8 whose tables fit an eighth of it and 32 GiB; takes effect at
- * the next bbs_ctx_set_generators.  Digits are SIGNED: table bytes = (count+1) * ceil(256/w) * 2^(w-1) * 2 * limb bytes of
+ * memory free on the device: the widest of 20 / 16 / 12 / 8 whose tables fit an eighth of it and 32 GiB -- and, if that
+ * allocation fails all the same (the free figure is a snapshot: other ranks or processes on the device, fragmentation),
+ * the next narrower width, down to 8, before BBS_E_NOMEM; takes effect at the next bbs_ctx_set_generators, which changes
+ * nothing of the context unless it succeeds.  Digits are SIGNED: table bytes = (count+1) * ceil(256/w) * 2^(w-1) * 2 * limb bytes of
  * an Fp element (56 on BLS12-381, 40 on BN254) -- for 32 messages 26 GB at w = 20 (1.45 M proof_verify/s, 8.0 M sign/s),
  * 2 GB at 16 (1.30 M, 7.3 M), 172 MB at 12 (1.30 M, 6.1 M), 16 MB at 8 (1.18 M, 4.4 M). */
 int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
@@ -117,9 +125,11 @@ int bbs_ctx_set_points_in_subgroup(bbs_ctx* ctx, int vouched);
  * multiplications on three lanes, summed afterwards; the two Miller loops on separate wavefronts, multiplied before the
  * final exponentiation).  Same group elements and booleans; the latency form is ~25 % shorter for a batch that has the
  * chip to itself and costs ~15 % more instructions, so it loses once several batches are in flight.
- *   enabled = 0: never; 1: always; 2: AUTO (the default) -- a job gets the latency form iff at most one other job of this
- *   context is alive when it is created (upload / submit), i.e. a serving loop that keeps many batches in flight runs in
- *   the throughput form, a caller that verifies one batch at a time gets the short path without asking.
+ *   enabled = 0: never; 1: always; 2: AUTO (the default) -- a job gets the latency form iff at most one other job is alive
+ *   ON THE DEVICE when it is created (upload / submit; jobs of every context of the process count: the contexts of one
+ *   bbs_issuer, or a BLS12-381 and a BN254 context side by side, share the chip), i.e. a serving loop that keeps many
+ *   batches in flight runs in the throughput form, a caller that verifies one batch at a time gets the short path
+ *   without asking.
  * Takes effect for jobs created afterwards. */
 int bbs_ctx_set_latency_mode(bbs_ctx* ctx, int enabled);
 /* Fixed-base sums (the generators' multiples: B of sign / verify / proof_gen, the fixed part of T2 of proof_verify) as
@@ -363,6 +373,18 @@ int bbs_core_proof_gen_submit(bbs_ctx* ctx, size_t n, const uint8_t* signatures,
 
 int bbs_job_run(bbs_job* job);                       /* asynchronous */
 int bbs_job_wait(bbs_job* job);
+/* Completion-order retire for a serving loop that keeps several batches in flight (the reference has no counterpart: its
+ * calls are synchronous, src/proof_verify.rs:19-61).  Jobs submitted together do not finish in submission order -- they
+ * share the chip -- and a loop that always waits for its OLDEST job runs in convoys (profiles/r03_pt_pipeline_trace_k20.log).
+ * bbs_jobs_wait_any sleeps until ONE of jobs[0 .. n) -- entries may be NULL; jobs that were never run are ignored -- has
+ * finished everything enqueued for it, then does what bbs_job_wait does for that job (delivers statuses / records of the
+ * submit forms, BBS_E_STATE if an item was left undecided) and stores its position in *index_out; if several have
+ * finished, the one that finished first.  The caller then frees or re-runs that job and calls again with the rest.
+ * Event-driven: a host function placed on the job's stream behind its last operation wakes the waiter; nothing polls the
+ * device.  BBS_E_STATE if no job of the set has been run.  Jobs of different contexts, curves and devices may be mixed.
+ * bbs_job_poll: 1 if the job has finished everything enqueued for it (bbs_job_wait will not block), 0 if not. */
+int bbs_jobs_wait_any(bbs_job* const* jobs, size_t n, size_t* index_out);
+int bbs_job_poll(const bbs_job* job);
 size_t bbs_job_size(const bbs_job* job);
 /* device memory the job holds until bbs_job_free, in bytes (sizing: INTEGRATION.md); batch verification adds its own */
 size_t bbs_job_device_bytes(const bbs_job* job);
@@ -429,8 +451,21 @@ int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa_
  * 1024; bbs_issuer_set_limits), which gets that code and is not computed: a table set per length is device memory an
  * untrusted caller must not be able to allocate without bound.  A proof octet string of the wrong shape is
  * BBS_ST_INVALID_ENCODING (its length does not define a message count).
- * Thread-compatible: calls on one issuer from several threads are allowed (context creation is locked; jobs are
- * independent).
+ *
+ * Resident contexts are BOUNDED: at most max_contexts (default 64) and max_table_bytes of window tables (default: half of
+ * the device memory free when the issuer builds its first context) stay on the device; when a new message count arrives
+ * and a bound is reached, idle contexts leave least-recently-used first (a context is idle when no routed list is in
+ * flight on it) and are rebuilt if their length comes back.  The message count of a proof is read from the length of an
+ * untrusted octet string: the bounds are what keeps a caller who sends one proof of every length from filling the device.
+ * If the context of a group cannot be set up -- the device is out of memory even for the narrowest tables, or every
+ * resident context is busy at the limit -- the items of THAT group get BBS_ST_NO_RESOURCES and the rest of the call is
+ * served.  A new context is built (hash-to-curve on the host, table build on the device) under that context's own lock:
+ * calls for other message counts proceed meanwhile.
+ *
+ * Threads: bbs_issuer_* may be called on one issuer from several threads.  Submissions to the same context are
+ * serialised inside (the bbs_ctx contract: one call at a time per context), every routed list owns its jobs.  The
+ * configuration calls (set_public_key, set_secret_key, set_modes) are BBS_E_STATE while a routed list is in flight --
+ * its jobs read the contexts' keys -- and otherwise take effect for every context, resident or future, at its next use.
  * ------------------------------------------------------------------------------------------ */
 typedef struct bbs_issuer bbs_issuer;
 int bbs_issuer_create(int curve, int device_id, const uint8_t* api_id, size_t api_id_len, bbs_issuer** out);
@@ -439,10 +474,16 @@ int bbs_issuer_set_public_key(bbs_issuer* issuer, const uint8_t* pk_affine, int 
 int bbs_issuer_set_secret_key(bbs_issuer* issuer, const uint8_t* sk32);          /* also sets pk = sk * BP2 */
 /* max_messages: longest item served; window_bits: 0 = by free device memory, else 4..22 -- for contexts created afterwards */
 int bbs_issuer_set_limits(bbs_issuer* issuer, size_t max_messages, int window_bits);
+/* resident contexts: at most max_contexts (>= 1) and max_table_bytes (0 = half of the free device memory at the first
+ * context) of tables; idle contexts beyond the new bounds leave at once.  bbs_issuer_table_bytes: what is resident now. */
+int bbs_issuer_set_budget(bbs_issuer* issuer, size_t max_contexts, size_t max_table_bytes);
+size_t bbs_issuer_table_bytes(bbs_issuer* issuer);
 /* bbs_ctx_set_latency_mode / _set_batch_verification (seed from the operating system) / _set_points_in_subgroup on every
  * context of the issuer, present and future */
 int bbs_issuer_set_modes(bbs_issuer* issuer, int latency_mode, int batch_verification, int points_in_subgroup);
-/* the context serving items of `message_count` messages (created if needed), e.g. to warm it up before traffic arrives */
+/* the context serving items of `message_count` messages (created if needed), e.g. to warm it up before traffic arrives, or
+ * to drive it directly (one call at a time, and not while the issuer routes lists to it).  A context handed out this way
+ * is never evicted. */
 int bbs_issuer_context(bbs_issuer* issuer, size_t message_count, bbs_ctx** out);
 size_t bbs_issuer_context_count(bbs_issuer* issuer);
 /* proof_verify (src/proof_verify.rs:19-61); message count of item i = (its proof's commitments) + (its disclosed indexes) */

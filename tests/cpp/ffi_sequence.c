@@ -173,6 +173,39 @@ static int run_curve(int curve) {
     bbs_job_free(jobB);
     CHECK(stA[0] == 1 && stA[1] == 1 && stA[2] == 1);
     CHECK(stB[0] == 0 && stB[1] == BBS_ST_INVALID_DISCLOSED_INDEX && stB[2] == BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH);
+    /* ---- a serving loop: four batches in flight, retired in COMPLETION order (bbs_jobs_wait_any), every slot refilled
+     * once; a retired slot is NULL until it is refilled.  Slots 0 / 2 hold batch A, slots 1 / 3 batch B. -------------- */
+    {
+        bbs_job* fl[4] = {NULL, NULL, NULL, NULL};
+        int8_t stq[4][3];
+        int refills = 4, retired = 0;
+        uint64_t diB2[] = {0, 2, L + 4};
+        uint64_t dmoB2[4] = {0, 2, 3, 4};
+        memset(stq, 99, sizeof stq);
+        size_t none = 7;
+        CHECK(bbs_jobs_wait_any(fl, 4, &none) == BBS_E_STATE);            /* nothing has been run */
+        for (int k = 0; k < 4; k++) {
+            if (k & 1) CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cm, cmo, dm, dmoB2, diB2, dio3, hdr4, ho4, ph_bytes, po, stq[k], &fl[k]) == BBS_OK);
+            else CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph_bytes, po, stq[k], &fl[k]) == BBS_OK);
+        }
+        while (fl[0] || fl[1] || fl[2] || fl[3]) {
+            size_t k = 9;
+            CHECK(bbs_jobs_wait_any(fl, 4, &k) == BBS_OK && k < 4 && fl[k]);
+            CHECK(bbs_job_poll(fl[k]) == 1);
+            if (k & 1) CHECK(stq[k][0] == 1 && stq[k][1] == BBS_ST_INVALID_DISCLOSED_INDEX && stq[k][2] == BBS_ST_INVALID_INDICES_AND_MESSAGES_LENGTH);
+            else CHECK(stq[k][0] == 1 && stq[k][1] == 1 && stq[k][2] == 1);
+            bbs_job_free(fl[k]);
+            fl[k] = NULL;
+            retired++;
+            if (refills > 0) {
+                refills--;
+                memset(stq[k], 99, 3);
+                if (k & 1) CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cm, cmo, dm, dmoB2, diB2, dio3, hdr4, ho4, ph_bytes, po, stq[k], &fl[k]) == BBS_OK);
+                else CHECK(bbs_core_proof_verify_submit(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph_bytes, po, stq[k], &fl[k]) == BBS_OK);
+            }
+        }
+        CHECK(retired == 8);
+    }
     /* the synchronous form returns the same */
     int8_t stC[3];
     CHECK(bbs_core_proof_verify_batch(vctx, 3, pf, cm, cmo, dm, dmo, di, dio3, hdr4, ho4, ph_bytes, po, stC) == BBS_OK);

@@ -1128,6 +1128,43 @@ def check_submit(curve, lib_path=None, n=7, L=4, seed=23):
                 op = bbs.Proof(p.a_bar, p.b_bar, p.d, p.e_cap, p.r1_cap, p.r3_cap, list(p.commitments), p.challenge)
                 assert int(bbs.core_proof_verify(suite, pk, op, gens, headers[i], phs[i], dm[i], idx[i], api_id)) == got[i]
         job.free()
+    # completion-order retire (bbs_jobs_wait_any): jobs of three operations in flight, taken in whatever order they finish;
+    # every job is delivered exactly once, to ITS OWN buffers, with the statuses of the one-shot call; a job that is freed
+    # leaves the set (None entries are skipped); a resident job that was never run is ignored; the set without a run job
+    # is BBS_E_STATE; bbs_job_poll agrees with what was delivered
+    from bbs_sign_amd import Job
+    from bbs_sign_amd.engine import BbsRuntimeError
+    want = [[int(x) for x in eng.core_proof_verify_batch(*b)] for b in batches]
+    sm, sh = sin[0]
+    sig_want, sig_st = eng.core_sign_batch(sm, sh)
+    never_run = eng.core_proof_verify_upload(*batches[0])
+    try:
+        Job.wait_any([never_run, None])
+    except BbsRuntimeError as e:
+        assert e.rc == -102, e.rc
+    else:
+        raise AssertionError("wait_any over jobs that were never run returned")
+    for rep in range(3):
+        live = [eng.core_proof_verify_submit(*batches[k % 3]) for k in range(rep, rep + 5)] + [eng.core_sign_submit(sm, sh), never_run, None]
+        kinds = [(k % 3) for k in range(rep, rep + 5)] + ["sign", "idle", None]
+        seen = 0
+        while any(j is not None and j is not never_run for j in live):
+            k = Job.wait_any(live)
+            job = live[k]
+            assert job is not None and job is not never_run and job.done()
+            if kinds[k] == "sign":
+                sigs2, st2 = job.output()
+                assert list(st2) == list(sig_st) and [(s_.a, s_.e) if s_ else None for s_ in sigs2] == [(s_.a, s_.e) if s_ else None for s_ in sig_want]
+            else:
+                assert [int(x) for x in job.result] == want[kinds[k]], (curve, rep, k)
+            job.free()
+            live[k] = None
+            seen += 1
+        assert seen == 6
+    assert not never_run.done()
+    never_run.run()
+    assert Job.wait_any([never_run]) == 0 and [int(x) for x in never_run.status()] == want[0]
+    never_run.free()
     eng.close()
 
 
@@ -1971,4 +2008,92 @@ def check_issuer_threads(curve, lib_path=None, threads=3, rounds=2, seed=151):
         t.join()
     assert not errors, errors
     assert iss.context_count() == 5
+    iss.close()
+
+
+def check_issuer_budget(curve, lib_path=None, seed=171):
+    """bbs_issuer's resident contexts are BOUNDED (bbs_issuer_set_budget): message counts keep arriving -- in proof_verify they
+    are read from untrusted octet strings -- and idle contexts leave least-recently-used first; a length that comes back is
+    rebuilt and gives the same signatures (byte for byte against the oracle's public sign, src/sign.rs:32-60).  A call whose
+    groups need more contexts than the limit allows fails only the group that found no slot (BBS_ST_NO_RESOURCES, -43:
+    not computed) -- the others are served.  Configuration calls are refused (BBS_E_STATE) while a routed list is in flight
+    and take effect for every context, resident or rebuilt, afterwards."""
+    from bbs_sign_amd import Issuer, api
+    from bbs_sign_amd.engine import BbsRuntimeError
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    sk = rng.randrange(1, c.r)
+    iss = Issuer(curve, suite.api_id, lib_path=lib_path, max_messages=8, window_bits=4 if lib_path else 8)
+    iss.set_secret_key(sk)
+    iss.set_budget(2, 0)
+
+    def msgs_of(L):
+        return [bytes(rng.randrange(256) for _ in range(rng.choice([1, 9, 40]))) for _ in range(L)]
+
+    def want_sig(raw):
+        w = bbs.sign(suite, sk, raw, b"")
+        return api.signature_to_octets(curve, Signature(w.a, w.e), lib_path)
+
+    # lengths 1, 2, 3, 1, 4 one call each: never more than two contexts resident, every signature right
+    first = {}
+    for L in (1, 2, 3, 1, 4, 2):
+        raw = [msgs_of(L), msgs_of(L)]
+        octs, st = iss.sign(raw)
+        assert [int(x) for x in st] == [1, 1], (L, list(st))
+        assert octs[0] == want_sig(raw[0]) and octs[1] == want_sig(raw[1]), (curve, L)
+        assert iss.context_count() <= 2, iss.context_count()
+        first.setdefault(L, (raw[0], octs[0]))
+    assert iss.table_bytes() > 0
+    # verify with rebuilt contexts: the signatures made before the evictions still verify
+    for L, (raw0, o0) in first.items():
+        assert [int(x) for x in iss.verify([o0], [raw0])] == [1], L
+        assert iss.context_count() <= 2
+    # one call with THREE lengths at a limit of two: the groups are served in order of message count; the last finds every
+    # resident context busy (pinned by this very list) -> its items are -43, the others are computed
+    raw = [msgs_of(3), msgs_of(1), msgs_of(2), msgs_of(1), msgs_of(3)]
+    octs, st = iss.sign(raw)
+    assert [int(x) for x in st] == [-43, 1, 1, 1, -43], list(st)
+    assert octs[0] == b"" and octs[4] == b"" and octs[1] == want_sig(raw[1]) and octs[2] == want_sig(raw[2])
+    # ... and the same list passes once the limit allows three
+    iss.set_budget(3, 0)
+    octs, st = iss.sign(raw)
+    assert [int(x) for x in st] == [1] * 5 and octs[0] == want_sig(raw[0])
+    assert iss.context_count() == 3
+    # shrinking the budget evicts idle contexts at once
+    iss.set_budget(1, 0)
+    assert iss.context_count() == 1
+    iss.set_budget(4, 0)
+    # configuration while a routed list is in flight: refused; afterwards: applied to resident and future contexts
+    sig1 = first[1][1]
+    n_a, keep_a, args_a = iss.pack_proof_verify([], [], [])
+    octs2, st2 = iss.sign([first[2][0]])
+    vjob = None
+    try:
+        import ctypes
+        ob, bad = iss._sig_octets([sig1])
+        # (a routed verify in flight through the submit form)
+        from bbs_sign_amd.engine import _u8, _u64, _ragged_bytes, Engine
+        mb, mbo, mio = Engine._raw_msgs([first[1][0]])
+        hb, ho = _ragged_bytes([b""])
+        stv = np.full(1, -128, dtype=np.int8)
+        j = ctypes.c_void_p()
+        rc = iss.lib.bbs_issuer_verify_submit(iss.h, 1, _u8(ob), _u8(mb), _u64(mbo), _u64(mio), _u8(hb), _u64(ho), stv.ctypes.data_as(_lib.c_i8p), ctypes.byref(j))
+        assert rc == 0
+        vjob = j
+        try:
+            iss.set_secret_key(sk + 1)
+        except BbsRuntimeError as e:
+            assert e.rc == -102, e.rc
+        else:
+            raise AssertionError("set_secret_key was accepted while a routed list was in flight")
+        assert iss.lib.bbs_issuer_job_wait(vjob) == 0 and int(stv[0]) == 1
+    finally:
+        if vjob is not None:
+            iss.lib.bbs_issuer_job_free(vjob)
+    iss.set_secret_key(sk + 1)                                # now idle: accepted; contexts pick the key up at their next use
+    assert [int(x) for x in iss.verify([sig1], [first[1][0]])] == [0]          # the old signature is not valid under the new key
+    o_new, st_new = iss.sign([first[1][0]])
+    w = bbs.sign(suite, sk + 1, first[1][0], b"")
+    assert list(st_new) == [1] and o_new[0] == api.signature_to_octets(curve, Signature(w.a, w.e), lib_path)
     iss.close()

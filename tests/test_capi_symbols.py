@@ -50,5 +50,5 @@ def test_only_the_c_abi_is_exported():
     names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
     api = [n for n in names if n.startswith("bbs_")]
     assert set(api) == set(_lib.SIGNATURES), set(api) ^ set(_lib.SIGNATURES)
-    other = [n for n in names if not n.startswith("bbs_") and "k_stage" not in n and "k_pip_window" not in n and not n.startswith(("_ZNSt", "_ZSt", "_ZNKSt", "__hip_"))]
+    other = [n for n in names if not n.startswith("bbs_") and "k_stage" not in n and "k_pip_window" not in n and not n.startswith(("_ZNSt", "_ZSt", "_ZNKSt", "_ZTISt", "_ZTSSt", "_ZTVSt", "_ZZNSt", "__hip_"))]
     assert not other, other[:10]

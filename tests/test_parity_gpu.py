@@ -177,7 +177,7 @@ def test_mixed_list_configs4_one_gpu(total):
     import json
     import torch
     import bench_mixed
-    args = argparse.Namespace(batch=4096, inflight=8, window_bits=20, warmup=1, steps=2, backend="nccl")
+    args = argparse.Namespace(batch=4096, inflight=8, window_bits=20, warmup=1, steps=3, backend="nccl")
     lines = []
     # (single process: every job is waited for by the library itself; torch only holds the timing scalar, on the CPU --
     # torch.cuda is not initialised here, after the engine has been using the device for the whole session)
@@ -290,3 +290,8 @@ def test_issuer_mixed_lengths(curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_issuer_threads(curve):
     pc.check_issuer_threads(curve, None, threads=4, rounds=3)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_budget(curve):
+    pc.check_issuer_budget(curve, None)

@@ -145,3 +145,8 @@ def test_latency_form_of_every_job(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_issuer_threads(twin, curve):
     pc.check_issuer_threads(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_issuer_budget(twin, curve):
+    pc.check_issuer_budget(curve, twin)

@@ -79,7 +79,7 @@ def _engine_worker(rank, world, port, twin, q):
     import parity_cases as pc
     import bench_mixed
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    args = argparse.Namespace(batch=5, inflight=3, window_bits=4, warmup=1, steps=2, backend="gloo")
+    args = argparse.Namespace(batch=5, inflight=3, window_bits=4, warmup=1, steps=4, backend="gloo")
     lines = []
     bench_mixed.run_mixed(args, pc, torch, dist, rank, 0, world, "cpu", dist.barrier, total=18 * world, lib_path=twin,
                           emit=lines.append, L=4, R=2)
