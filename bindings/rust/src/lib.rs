@@ -55,6 +55,7 @@ extern "C" {
         disclosed_idx: *const u64, didx_off: *const u64, headers: *const u8, hdr_off: *const u64,
         ph: *const u8, ph_off: *const u64, status: *mut i8, job_out: *mut *mut BbsJob) -> c_int;
     fn bbs_job_wait(job: *mut BbsJob) -> c_int;
+    fn bbs_jobs_wait_any(jobs: *const *mut BbsJob, n: usize, index_out: *mut usize) -> c_int;
     fn bbs_job_free(job: *mut BbsJob);
     // items of ANY number of messages in one call (one context per count inside the library): see `GpuIssuerAnyLength`
     fn bbs_issuer_create(curve: c_int, device_id: c_int, api_id: *const u8, api_id_len: usize, out: *mut *mut BbsIssuer) -> c_int;
@@ -74,19 +75,26 @@ extern "C" {
 pub struct GpuIssuerAnyLength { issuer: *mut BbsIssuer }
 impl GpuIssuerAnyLength {
     pub fn new<E: GpuCurve>(device: c_int, api_id: &[u8], pk_affine_le: &[u8], max_messages: usize) -> Self {
+        // every length the FFI will read is checked BEFORE the first unsafe call: the library reads exactly 4 * fp_bytes of the key
+        let fpb = unsafe { bbs_fp_bytes(E::CURVE_ID) };
+        assert_eq!(pk_affine_le.len(), 4 * fpb, "public key record: x.c0 | x.c1 | y.c0 | y.c1, {} bytes each", fpb);
         let mut issuer = std::ptr::null_mut();
         let rc = unsafe { bbs_issuer_create(E::CURVE_ID, device, api_id.as_ptr(), api_id.len(), &mut issuer) };
         assert_eq!(rc, 0, "bbs_issuer_create: {rc}");
+        // the owning value exists before the fallible calls: if one of them panics, Drop destroys the issuer
+        let me = GpuIssuerAnyLength { issuer };
         unsafe {
-            assert_eq!(bbs_issuer_set_limits(issuer, max_messages, 0), 0);          // table width by free device memory
-            assert_eq!(bbs_issuer_set_public_key(issuer, pk_affine_le.as_ptr(), 0), 0);
+            assert_eq!(bbs_issuer_set_limits(me.issuer, max_messages, 0), 0);       // table width by free device memory
+            assert_eq!(bbs_issuer_set_public_key(me.issuer, pk_affine_le.as_ptr(), 0), 0);
         }
-        GpuIssuerAnyLength { issuer }
+        me
     }
     /// One call for the whole list; `Err(InvalidMessageAndGeneratorsLength)` only for a proof above `max_messages`.
     pub fn proof_verify(&self, proof_octets: &[&[u8]], headers: &[&[u8]], phs: &[&[u8]], disclosed_messages: &[&[&[u8]]],
                         disclosed_indexes: &[&[usize]]) -> Vec<Result<bool, ProofGenError>> {
         let n = proof_octets.len();
+        assert!(headers.len() == n && phs.len() == n && disclosed_messages.len() == n && disclosed_indexes.len() == n,
+                "proof_verify: every input slice holds one entry per proof ({n})");
         let (ob, oo) = ragged(proof_octets);
         let (mut mb, mut mbo, mut mio, mut di, mut dio) = (Vec::new(), vec![0u64], vec![0u64], Vec::new(), vec![0u64]);
         for i in 0..n {
@@ -360,6 +368,20 @@ impl<'a> PendingVerify<'a> {
         assert_eq!(rc, 0, "bbs_job_wait: {rc} (-102: an item was left undecided; the library fails closed)");
         self.status.iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
     }
+}
+/// Completion-order retire for a serving loop with several batches in flight (bbs_jobs_wait_any): sleeps until ONE of the
+/// pending batches has finished, removes it from `pending` and returns its position there together with its results.
+/// Batches submitted together share the chip and do not finish in submission order; waiting for the oldest one first makes
+/// the loop run in convoys.
+pub fn wait_any<'a>(pending: &mut Vec<PendingVerify<'a>>) -> Option<(usize, Vec<Result<bool, ProofGenError>>)> {
+    if pending.is_empty() { return None; }
+    let jobs: Vec<*mut BbsJob> = pending.iter().map(|p| p.job).collect();
+    let mut k = 0usize;
+    let rc = unsafe { bbs_jobs_wait_any(jobs.as_ptr(), jobs.len(), &mut k) };
+    assert_eq!(rc, 0, "bbs_jobs_wait_any: {rc} (-102: an item was left undecided; the library fails closed)");
+    assert!(k < pending.len());
+    let done = pending.remove(k);
+    Some((k, done.wait()))                // the job has been delivered: wait() returns at once and frees it (steps 16, 17)
 }
 impl<'a> Drop for PendingVerify<'a> {
     fn drop(&mut self) { if !self.job.is_null() { unsafe { bbs_job_wait(self.job); bbs_job_free(self.job); } } }

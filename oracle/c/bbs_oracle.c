@@ -864,3 +864,82 @@ void orc_g1_msm_plain(size_t n, const uint8_t* pts_le, const uint8_t* scal_le, u
         acc = g1j_add(acc, g1_mul(g1j_from_aff(g1a_from_le(pts_le + 2 * FPB * i)), fr_from_le(scal_le + 32 * i)));
     g1a_to_le(g1j_to_aff(acc), out);
 }
+
+#ifdef ORC_BN254
+/* ---- BN254 hash_to_curve (interface_utilities.rs:24-28 calls crate bn254_hash2curve 0.1.2, not vendored): RFC 9380
+   hash_to_curve, expand_message_xmd(SHA-256), L = 48, Shallue-van de Woestijne map (section 6.6.1, straight-line form),
+   Z = 1 on y^2 = x^3 + 3, cofactor 1.  A THIRD statement of the map (after oracle/hashing.py and the product's host_h2c.hpp),
+   with its constants derived here from Z: c1 = g(Z), c2 = -Z / 2, c3 = sqrt(-g(Z) (3 Z^2)) with sgn0(c3) = 0,
+   c4 = -4 g(Z) / (3 Z^2).  The reference's one BN254 known answer (P1, constants.rs:39-51) never has both candidates x1, x2
+   on the curve at once, so it does not see the sign of c3; orc_bn_svdw_map reports which candidates were squares so that
+   tests can pick inputs that do. */
+static void xmd(const uint8_t* msg, size_t mlen, const uint8_t* dst, size_t dlen, uint8_t* out, size_t len) {
+    uint8_t z[64] = {0}, lib[3], dl = (uint8_t)dlen, b0[32], bi[32], t[32], c;
+    lib[0] = (uint8_t)(len >> 8); lib[1] = (uint8_t)len; lib[2] = 0;
+    sha s; sha_init(&s);
+    sha_upd(&s, z, 64); sha_upd(&s, msg, mlen); sha_upd(&s, lib, 3); sha_upd(&s, dst, dlen); sha_upd(&s, &dl, 1); sha_fin(&s, b0);
+    memset(bi, 0, 32);
+    size_t at = 0;
+    for (c = 1; at < len; c++) {
+        for (int i = 0; i < 32; i++) t[i] = b0[i] ^ bi[i];
+        sha_init(&s); sha_upd(&s, t, 32); sha_upd(&s, &c, 1); sha_upd(&s, dst, dlen); sha_upd(&s, &dl, 1); sha_fin(&s, bi);
+        size_t k = len - at < 32 ? len - at : 32;
+        memcpy(out + at, bi, k); at += k;
+    }
+}
+static fp fp_small(u64 v) { u64 w[NP] = {0}; w[0] = v; return fp_from_raw(w); }
+static fp fp_sqrt_exp(fp a) {                       /* a^((p+1)/4): p = 3 mod 4 */
+    u64 e[NP]; memcpy(e, P, sizeof e); e[0] += 1;
+    u64 c = 0; for (int i = NP - 1; i >= 0; i--) { u64 n = e[i] & 3; e[i] = (e[i] >> 2) | (c << 62); c = n; }
+    return fp_pow(a, e, NP);
+}
+static int fp_is_square(fp a, fp* root) { fp r = fp_sqrt_exp(a); if (root) *root = r; return fp_eq(fp_sqr(r), a); }
+static int fp_sgn0(fp a) { u64 w[NP]; fp_to_raw(a, w); return (int)(w[0] & 1); }
+static fp bn_g(fp x) { return fp_add(fp_mul(fp_sqr(x), x), fp_small(3)); }
+/* 48 big-endian bytes mod p */
+static fp fp_from_be48(const uint8_t* b) {
+    fp acc = fp_zero(), k256 = fp_small(256);
+    for (int i = 0; i < 48; i++) acc = fp_add(fp_mul(acc, k256), fp_small(b[i]));
+    return acc;
+}
+static g1a bn_svdw(fp u, int* squares) {
+    const fp Z = fp_one(), gz = bn_g(Z), one = fp_one();
+    const fp z2x3 = fp_mul(fp_small(3), fp_sqr(Z));
+    const fp c1 = gz, c2 = fp_neg(fp_mul(Z, fp_inv(fp_small(2))));
+    fp c3; int ok = fp_is_square(fp_neg(fp_mul(gz, z2x3)), &c3); (void)ok;
+    if (fp_sgn0(c3)) c3 = fp_neg(c3);
+    const fp c4 = fp_neg(fp_mul(fp_mul(fp_small(4), gz), fp_inv(z2x3)));
+    fp tv1 = fp_mul(fp_sqr(u), c1), tv2 = fp_add(one, tv1);
+    tv1 = fp_sub(one, tv1);
+    fp tv3 = fp_mul(tv1, tv2);
+    tv3 = fp_is_zero(tv3) ? tv3 : fp_inv(tv3);                         /* inv0 */
+    fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
+    fp x1 = fp_sub(c2, tv4), x2 = fp_add(c2, tv4);
+    fp x3 = fp_mul(fp_sqr(tv2), tv3);
+    x3 = fp_add(fp_mul(fp_sqr(x3), c4), Z);
+    const int e1 = fp_is_square(bn_g(x1), NULL), e2 = fp_is_square(bn_g(x2), NULL), e3 = fp_is_square(bn_g(x3), NULL);
+    if (squares) *squares = e1 | (e2 << 1) | (e3 << 2);
+    fp x = e1 ? x1 : (e2 ? x2 : x3), y;
+    fp_is_square(bn_g(x), &y);
+    if (fp_sgn0(u) != fp_sgn0(y)) y = fp_neg(y);
+    g1a r; r.inf = 0; r.x = x; r.y = y;
+    return r;
+}
+/* u: 48 big-endian bytes (reduced mod p); out: x || y little-endian; returns the squares mask (bit 0: g(x1), 1: g(x2), 2: g(x3)) */
+int orc_bn_svdw_map(const uint8_t* u_be48, uint8_t* out) {
+    init_all();
+    int sq = 0;
+    g1a_to_le(bn_svdw(fp_from_be48(u_be48), &sq), out);
+    return sq;
+}
+/* hash_to_curve; squares_out[2] (may be NULL): the masks of the two maps */
+void orc_bn_hash_to_g1(const uint8_t* msg, size_t mlen, const uint8_t* dst, size_t dlen, uint8_t* out, int* squares_out) {
+    init_all();
+    uint8_t uni[96];
+    xmd(msg, mlen, dst, dlen, uni, 96);
+    int s0 = 0, s1 = 0;
+    g1a q0 = bn_svdw(fp_from_be48(uni), &s0), q1 = bn_svdw(fp_from_be48(uni + 48), &s1);
+    if (squares_out) { squares_out[0] = s0; squares_out[1] = s1; }
+    g1a_to_le(g1j_to_aff(g1j_add(g1j_from_aff(q0), g1j_from_aff(q1))), out);
+}
+#endif

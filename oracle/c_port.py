@@ -78,6 +78,15 @@ class CPort:
                                   _b(b"".join(_fr(k) for k in scalars)), out)
         return self._g1_dec(bytes(out))
 
+    def bn_hash_to_g1(self, msg: bytes, dst: bytes):
+        """BN254 build only: RFC 9380 hash_to_curve with the SvdW map -> (point, (mask0, mask1)); mask bit k set = candidate
+        x_(k+1) of that map was on the curve (bits 0 and 1 both set = the case that sees the sign of the constant c3)."""
+        assert self.curve == "bn254"
+        out = (ctypes.c_uint8 * (2 * self.fpb))()
+        sq = (ctypes.c_int * 2)()
+        self.lib.orc_bn_hash_to_g1(_b(msg), ctypes.c_size_t(len(msg)), _b(dst), ctypes.c_size_t(len(dst)), out, sq)
+        return self._g1_dec(bytes(out)), (int(sq[0]), int(sq[1]))
+
     def core_sign(self, sk, generators, header, messages, api_id):
         L = len(messages)
         out = (ctypes.c_uint8 * (2 * self.fpb + 32))()

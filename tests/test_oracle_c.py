@@ -127,3 +127,46 @@ def test_plain_msm_matches_python_oracle():
         assert P.g1_msm_plain(pts, sc) == want
         assert P.g1_msm_plain([pts[6], pts[7]], [5, 5]) is None
         assert P.g1_msm_plain([], []) is None
+
+
+def test_bn254_svdw_sign_of_c3_three_implementations():
+    """BN254 hash-to-G1 (crate bn254_hash2curve 0.1.2, not vendored; restated as RFC 9380 + Shallue-van de Woestijne).
+    The map's constant c3 enters only through x1 = c2 - tv4, x2 = c2 + tv4: flipping its sign swaps the two candidates, which
+    changes the result exactly when BOTH are on the curve (the RFC then takes x1).  The reference's one BN254 known answer
+    (P1, constants.rs:39-51) has the masks (x2 only, x1 only) -- it cannot see the sign.  Here: inputs for which both
+    candidates are squares in one or both of the two maps, through three separately written implementations -- the Python
+    oracle, the C oracle (constants derived from Z in C) and the product's host code (host_h2c.hpp, through the test
+    build) -- which must agree, and which all follow the RFC's sgn0(c3) = 0."""
+    import ctypes
+    from bbs_sign_amd import _lib, build
+    from oracle.bbs import BN_SUITE
+    from oracle.curves import BN254 as CB
+    from oracle.hashing import SVDW_C3, expand_message, hash_to_g1_bn, i2osp
+    assert SVDW_C3 % 2 == 0                                         # sgn0(c3) = 0 (RFC 9380 6.6.1)
+    P = c_port.port("bn254")
+    lib = _lib.load_library(build.build(twin=True, verbose=False))
+    api = BN_SUITE.api_id
+    dst = api + b"SIG_GENERATOR_DST_"
+    # the known answer and what it exercises
+    v = expand_message(api + b"BP_MESSAGE_GENERATOR_SEED", api + b"SIG_GENERATOR_SEED_", 48)
+    v = expand_message(v + i2osp(1, 8), api + b"SIG_GENERATOR_SEED_", 48)
+    pt, masks = P.bn_hash_to_g1(v, dst)
+    assert pt == BN_SUITE.p1 and masks == (2, 1), masks              # only x2 / only x1 on the curve: c3's sign is not seen
+    seen = {"first": 0, "second": 0, "both": 0}
+    for i in range(64):
+        msg = b"bn254-svdw-both-candidates-%d" % i
+        pt, (m0, m1) = P.bn_hash_to_g1(msg, dst)
+        b0, b1 = (m0 & 3) == 3, (m1 & 3) == 3
+        if not (b0 or b1):
+            continue
+        seen["both" if (b0 and b1) else ("first" if b0 else "second")] += 1
+        assert m0 in (1, 2, 4, 7) and m1 in (1, 2, 4, 7)              # g(x1) g(x2) g(x3) is a square: one or all three
+        assert pt == hash_to_g1_bn(msg, dst), i
+        out = (ctypes.c_uint8 * 64)()
+        mb = (ctypes.c_uint8 * len(msg)).from_buffer_copy(msg)
+        db = (ctypes.c_uint8 * len(dst)).from_buffer_copy(dst)
+        assert lib.bbs_hash_to_g1(1, mb, len(msg), db, len(dst), out) == 0
+        o = bytes(out)
+        assert (int.from_bytes(o[:32], "little"), int.from_bytes(o[32:], "little")) == pt, i
+        assert CB.g1_is_on_curve(pt)
+    assert seen["first"] and seen["second"] and seen["both"], seen
