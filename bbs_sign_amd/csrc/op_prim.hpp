@@ -19,15 +19,16 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
     const int nb = L_new + 2;                    // fixed-base tables over [P1, Q1, H_1..H_L]
     auto table_bytes_at = [&](int c) { return (size_t)nb * ((256 + c - 1) / c) * ((size_t)1 << (c - 1)) * 2 * N * 4; };
     // candidate widths, widest first.  A requested width is the only candidate.  Automatic: the widest of {20, 16, 12, 8}
-    // whose tables fit an eighth of the memory now free on the device and 32 GiB (20 bits: 13 additions per scalar and 26 GB
-    // at 32 messages; 16: 16 additions, 2 GB, ~3.5 % slower proof_verify; 8: 32 additions, 15 MB) -- and, because that is a
-    // snapshot (other ranks or processes on the device, fragmentation), every narrower width after it as a fallback when
-    // the allocation itself fails.
+    // whose tables fit 1/32 of the memory now free on the device and 8 GiB -- at 32 messages that is 16 bits (2 GB, 16
+    // additions per scalar); 20 bits (26 GB, 13 additions, +3.5 % proof_verify/s) is a deliberate choice for a verifier with
+    // ONE issuer and memory to spare (bench.py asks for it), not a default: a verifier of many issuers or message counts
+    // keeps many table sets -- and, because the free figure is a snapshot (other ranks or processes on the device,
+    // fragmentation), every narrower width after it as a fallback when the allocation itself fails.
     std::vector<int> widths;
     if (win_bits_requested) widths.push_back(win_bits_requested);
     else {
         const size_t free_b = rt::mem_free_bytes();
-        const size_t budget = std::min<size_t>(free_b / 8, (size_t)32 << 30);
+        const size_t budget = std::min<size_t>(free_b / 32, (size_t)8 << 30);
         for (int c : {20, 16, 12, 8}) if (c == 8 || table_bytes_at(c) <= budget) widths.push_back(c);
     }
     std::vector<uint32_t> bases((size_t)nb * 2 * N);

@@ -90,7 +90,7 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 // f * h: lane k computes its own output coefficient  c_k = sum_j g_j h_{(k-j) mod 6} xi^[j > k]  as ONE Fp2 dot
 // product (tower.hpp F2Acc): the six products are accumulated as unreduced column sums and reduced once --
 // 6 * 3 N^2 + 2 N^2 multiply-accumulates instead of 6 * 5 N^2.  Operands come in by ds_bpermute.
-template <class C>
+template <class C, int V = 0>
 __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
     const int k = L.m;
 #if BBS_DIST_TWOPASS_FINAL
@@ -208,7 +208,7 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
 // (m + j) mod 6 and, on the RECEIVING lane k, lands in the plain sum (k >= j) or in the sum that
 // still has to be multiplied by xi (k < j, i.e. m + j >= 6).  Both sums are accumulated lazily
 // (limb-wise, no reduction) and reduced once: 2 chains per product instead of 24.
-template <class C>
+template <class C, int V = 0>
 __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& g, const Fp2<C>& h) {
     using P = typename C::FpP;
     constexpr int N = P::N;
@@ -434,7 +434,7 @@ BBS_DIST_CYCLO Fp2<C> d_cyclo_sqr(const Lane6& L, const Fp2<C>& g) {
     return f2_lin_pm<C, 3, 2>(t, g, (L.m & 1) != 0);
 }
 
-template <class C, int K>
+template <class C, int K, int V = 0>
 __device__ __attribute__((noinline)) Fp2<C> d_frob(const Lane6& L, const Fp2<C>& g, const uint32_t* frob_tab) {
     // frob_tab: [3][6][2][N] Montgomery constants xi^(m (p^K - 1)/6)
     constexpr int N = C::FpP::N;
@@ -470,10 +470,10 @@ __device__ __forceinline__ Fp2<C> d_scatter(const Lane6& L, const Fp12<C>& f) {
 // coefficients (lanes 0, 2, 4).  Every lane fetches (n0, n1, n2), inverts the cubic extension
 // element redundantly (one Fp inversion, the only long chain), then multiplies its rotated
 // coefficients of conj6(f) by the three coefficients of N^-1.  No lane ever holds a whole Fp12.
-template <class C>
+template <class C, int V = 0>
 __device__ __attribute__((noinline)) Fp2<C> d_inv(const Lane6& L, const Fp2<C>& g) {
     const Fp2<C> gc = d_conj<C>(L, g);
-    const Fp2<C> nn = d_mul<C>(L, g, gc);
+    const Fp2<C> nn = d_mul<C, V>(L, g, gc);
     const Fp2<C> n0 = d_coef<C>(L, nn, 0), n1 = d_coef<C>(L, nn, 2), n2 = d_coef<C>(L, nn, 4);
     Fp2<C> t0 = f2_sub<C>(f2_sqr<C>(n0), f2_mul_xi<C>(f2_mul<C>(n1, n2)));
     Fp2<C> t1 = f2_sub<C>(f2_mul_xi<C>(f2_sqr<C>(n2)), f2_mul<C>(n0, n1));
@@ -510,7 +510,7 @@ __device__ __forceinline__ bool d_is_one(const Lane6& L, const Fp2<C>& g) {
 // it a memory object for the whole loop, so that every squaring began with a scratch round trip (7 loads, wait, ...,
 // 7 stores): being the function's return slot, and being handed by reference to the non-inlined multiplication.
 // Hence the explicit output parameter and the copy `t`.
-template <class C>
+template <class C, int V = 0>
 __device__ __attribute__((noinline)) void d_pow_xabs_to(const Lane6& L, const Fp2<C>& f_in, Fp2<C>& out) {
     const Fp2<C> f = f_in;
     Fp2<C> r = f;
@@ -521,62 +521,65 @@ __device__ __attribute__((noinline)) void d_pow_xabs_to(const Lane6& L, const Fp
         r = d_cyclo_sqr<C>(L, r);
         if ((x >> i) & 1) {
             const Fp2<C> t = r, h = f;
-            r = d_mul<C>(L, t, h);
+            r = d_mul<C, V>(L, t, h);
         }
     }
     out = r;
 }
-template <class C>
+template <class C, int V = 0>
 __device__ __forceinline__ Fp2<C> d_pow_xabs(const Lane6& L, const Fp2<C>& f) {
     Fp2<C> r;
-    d_pow_xabs_to<C>(L, f, r);
+    d_pow_xabs_to<C, V>(L, f, r);
     return r;
 }
-template <class C>
+template <class C, int V = 0>
 __device__ __forceinline__ Fp2<C> d_pow_x(const Lane6& L, const Fp2<C>& f) {
-    Fp2<C> r = d_pow_xabs<C>(L, f);
+    Fp2<C> r = d_pow_xabs<C, V>(L, f);
     if constexpr (C::K::X_NEG) r = d_conj<C>(L, r);
     return r;
 }
 
 // same exponent as final_exponentiation() in pairing.hpp
-template <class C>
+// V: instance tag.  A device function is compiled for the LOOSEST register budget among the kernels that reach it; the
+// final-exponentiation kernel that runs two wavefronts per SIMD (PairFinalDist, <= 256 registers) therefore has its own
+// instances (V = 1) of every non-inlined function below it, apart from the ones the one-wavefront kernels call.
+template <class C, int V = 0>
 __device__ __attribute__((noinline)) Fp2<C> d_final_exp(const Lane6& L, const Fp2<C>& f_in, const uint32_t* frob_tab) {
-    Fp2<C> f = d_mul<C>(L, d_conj<C>(L, f_in), d_inv<C>(L, f_in));
-    f = d_mul<C>(L, d_frob<C, 2>(L, f, frob_tab), f);
+    Fp2<C> f = d_mul<C, V>(L, d_conj<C>(L, f_in), d_inv<C, V>(L, f_in));
+    f = d_mul<C, V>(L, d_frob<C, 2, V>(L, f, frob_tab), f);
     if constexpr (C::ID == 0) {
-        Fp2<C> a = d_mul<C>(L, d_pow_x<C>(L, f), d_conj<C>(L, f));
-        a = d_mul<C>(L, d_pow_x<C>(L, a), d_conj<C>(L, a));
-        Fp2<C> b = d_mul<C>(L, d_pow_x<C>(L, a), d_frob<C, 1>(L, a, frob_tab));
-        Fp2<C> c = d_pow_x<C>(L, d_pow_x<C>(L, b));
-        c = d_mul<C>(L, c, d_frob<C, 2>(L, b, frob_tab));
-        c = d_mul<C>(L, c, d_conj<C>(L, b));
-        Fp2<C> f3 = d_mul<C>(L, d_cyclo_sqr<C>(L, f), f);
-        return d_mul<C>(L, c, f3);
+        Fp2<C> a = d_mul<C, V>(L, d_pow_x<C, V>(L, f), d_conj<C>(L, f));
+        a = d_mul<C, V>(L, d_pow_x<C, V>(L, a), d_conj<C>(L, a));
+        Fp2<C> b = d_mul<C, V>(L, d_pow_x<C, V>(L, a), d_frob<C, 1, V>(L, a, frob_tab));
+        Fp2<C> c = d_pow_x<C, V>(L, d_pow_x<C, V>(L, b));
+        c = d_mul<C, V>(L, c, d_frob<C, 2, V>(L, b, frob_tab));
+        c = d_mul<C, V>(L, c, d_conj<C>(L, b));
+        Fp2<C> f3 = d_mul<C, V>(L, d_cyclo_sqr<C>(L, f), f);
+        return d_mul<C, V>(L, c, f3);
     } else {
-        Fp2<C> fu = d_pow_x<C>(L, f);
-        Fp2<C> fu2 = d_pow_x<C>(L, fu);
-        Fp2<C> fu3 = d_pow_x<C>(L, fu2);
-        Fp2<C> y0 = d_mul<C>(L, d_mul<C>(L, d_frob<C, 1>(L, f, frob_tab), d_frob<C, 2>(L, f, frob_tab)), d_frob<C, 3>(L, f, frob_tab));
+        Fp2<C> fu = d_pow_x<C, V>(L, f);
+        Fp2<C> fu2 = d_pow_x<C, V>(L, fu);
+        Fp2<C> fu3 = d_pow_x<C, V>(L, fu2);
+        Fp2<C> y0 = d_mul<C, V>(L, d_mul<C, V>(L, d_frob<C, 1, V>(L, f, frob_tab), d_frob<C, 2, V>(L, f, frob_tab)), d_frob<C, 3, V>(L, f, frob_tab));
         Fp2<C> y1 = d_conj<C>(L, f);
-        Fp2<C> y2 = d_frob<C, 2>(L, fu2, frob_tab);
-        Fp2<C> y3 = d_conj<C>(L, d_frob<C, 1>(L, fu, frob_tab));
-        Fp2<C> y4 = d_conj<C>(L, d_mul<C>(L, fu, d_frob<C, 1>(L, fu2, frob_tab)));
+        Fp2<C> y2 = d_frob<C, 2, V>(L, fu2, frob_tab);
+        Fp2<C> y3 = d_conj<C>(L, d_frob<C, 1, V>(L, fu, frob_tab));
+        Fp2<C> y4 = d_conj<C>(L, d_mul<C, V>(L, fu, d_frob<C, 1, V>(L, fu2, frob_tab)));
         Fp2<C> y5 = d_conj<C>(L, fu2);
-        Fp2<C> y6 = d_conj<C>(L, d_mul<C>(L, fu3, d_frob<C, 1>(L, fu3, frob_tab)));
+        Fp2<C> y6 = d_conj<C>(L, d_mul<C, V>(L, fu3, d_frob<C, 1, V>(L, fu3, frob_tab)));
         Fp2<C> t0 = d_cyclo_sqr<C>(L, y6);
-        t0 = d_mul<C>(L, t0, y4);
-        t0 = d_mul<C>(L, t0, y5);
-        Fp2<C> t1 = d_mul<C>(L, y3, y5);
-        t1 = d_mul<C>(L, t1, t0);
-        t0 = d_mul<C>(L, t0, y2);
+        t0 = d_mul<C, V>(L, t0, y4);
+        t0 = d_mul<C, V>(L, t0, y5);
+        Fp2<C> t1 = d_mul<C, V>(L, y3, y5);
+        t1 = d_mul<C, V>(L, t1, t0);
+        t0 = d_mul<C, V>(L, t0, y2);
         t1 = d_cyclo_sqr<C>(L, t1);
-        t1 = d_mul<C>(L, t1, t0);
+        t1 = d_mul<C, V>(L, t1, t0);
         t1 = d_cyclo_sqr<C>(L, t1);
-        t0 = d_mul<C>(L, t1, y1);
-        t1 = d_mul<C>(L, t1, y0);
+        t0 = d_mul<C, V>(L, t1, y1);
+        t1 = d_mul<C, V>(L, t1, y0);
         t0 = d_cyclo_sqr<C>(L, t0);
-        return d_mul<C>(L, t0, t1);
+        return d_mul<C, V>(L, t0, t1);
     }
 }
 

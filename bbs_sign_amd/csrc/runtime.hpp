@@ -932,11 +932,20 @@ void add_pairing_stages(J* j, PairArgs<C>* pargs, int aux, const char* nm_miller
 #else
     if ((j->latency_form && allow_split) || force_split) {
         // the two Miller loops of every item on separate wavefronts, then product + final exponentiation (stages.hpp)
+        pargs->single = 0;
         j->stages.push_back({nm_miller, [j, pargs, aux]() { return rt::launch<PairMillerHalf<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 128); }, aux, 0});
         j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinalDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
         return;
     }
+#if BBS_PAIR_SPLIT2
+    // both Miller loops on one six-lane group (the whole register file), then the final exponentiation two wavefronts per SIMD
+    pargs->single = 1;
+    j->stages.push_back({"pair_miller_both", [j, pargs, aux]() { return rt::launch<PairMillerBoth<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
+    j->stages.push_back({nm_final, [j, pargs, aux]() { return rt::launch<PairFinalDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
+#else
+    pargs->single = 0;
     j->stages.push_back({nm_dist, [j, pargs, aux]() { return rt::launch<PairDist<C>>(aux ? j->stream_aux() : j->stream(), *pargs, ((pargs->n + GRP_PER_WAVE - 1) / GRP_PER_WAVE) * 64); }, aux, 0});
+#endif
 #endif
 }
 

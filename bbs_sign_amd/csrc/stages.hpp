@@ -39,6 +39,22 @@ constexpr int8_t ST_PAIRING = -127;   // every check before the pairing passed: 
 #ifndef BBS_PAIR_WAVES
 #define BBS_PAIR_WAVES 1
 #endif
+// A/B knobs (round 4): the throughput form of a per-item pairing check as TWO kernels -- PairMillerBoth (both Miller loops of
+// an item on one six-lane group, shared squarings: the first half of PairDist) and PairFinalDist (the final exponentiation)
+// -- so that the final exponentiation, which alone fits 256 registers with 6 spilled and the same instruction count
+// (profiles/r04_c_occupancy_resource_usage.txt), can run TWO wavefronts per SIMD (BBS_PAIRFINAL_WAVES = 2) while the Miller
+// loop (277 spills under that cap) keeps the whole register file.  Measured (profiles/r04_d_ab.log, two alternating repeats,
+// 96 steps): fused 1.511 / 1.513 M proof_verify/s, split with one wavefront per SIMD 1.511 / 1.513, split with two 1.490 /
+// 1.483 -- and a batch that is alone gets SLOWER (final exponentiation 2.45 -> 3.1 - 4.0 ms: the dispatcher packs two
+// wavefronts onto one SIMD while others idle).  Two co-resident wavefronts do not issue faster here: in time units the
+// kernels already run at 2.28 ns per wave-instruction per SIMD against 2.18 ns for this opcode mix at two wavefronts per
+// SIMD (tools/ubench, profiles/r03_p_ubench_valu_int.csv; the chip clocks down as more wavefronts issue).  Hence: fused.
+#ifndef BBS_PAIR_SPLIT2
+#define BBS_PAIR_SPLIT2 0
+#endif
+#ifndef BBS_PAIRFINAL_WAVES
+#define BBS_PAIRFINAL_WAVES 1
+#endif
 #ifndef BBS_MSM_WAVES
 #define BBS_MSM_WAVES 1          // multi-scalar-multiplication stages (2 and 3 measured: no gain, spills)
 #endif
@@ -707,6 +723,7 @@ struct PairArgs {
     int gate;
     int8_t* out;              // result 1 / 0 per item (may alias the status array)
     uint32_t* fmiller;        // [2][12N][n]
+    int single;               // fmiller holds ONE value per item (PairMillerBoth), not one per pair (PairMillerHalf)
     // batch verification: this launch is the per-item FALLBACK behind the combined checks -- if all n_checks of them passed
     // (batch_ok[k] == 1), every gated item's product is 1 (error 2^-128) and the lane only writes that; null otherwise
     const int8_t* batch_ok;
@@ -1706,6 +1723,48 @@ struct PairDist {
     }
 };
 
+// ---- throughput form in two kernels (round 4, BBS_PAIR_SPLIT2): PairDist up to the end of the Miller loops; the value is
+// handed to PairFinalDist in HBM ([coefficient][2N][n], coalesced over the items' lanes m: 1.3 KB per item each way)
+template <class C>
+struct PairMillerBoth {
+    static constexpr int WAVES_PER_EU = BBS_PAIR_WAVES;
+    static __device__ void run(const PairArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const int lane = (int)(t & 63);
+        const int grp = lane / GRP;
+        if (grp >= GRP_PER_WAVE) return;
+        const size_t i = (t >> 6) * GRP_PER_WAVE + grp;
+        if (i >= a.n) return;
+        if (a.gate_arr[i] != a.gate) return;
+        if (pair_batch_passed<C>(a)) return;                   // PairFinalDist writes the verdict
+        Lane6 L{grp * GRP, lane - grp * GRP};
+        G1Aff<C> Pa = pair_load_point<C>(a, a.pa, i);
+        G1Aff<C> Pb = pair_load_point<C>(a, a.pb, i);
+        if (a.negate_b) Pb = g1a_neg<C>(Pb);
+        const CtxConsts<C>* cc = a.cc;
+        const bool skipA = g1a_is_inf<C>(Pa) | (cc->tab_pk.q_is_identity != 0);
+        const bool skipB = g1a_is_inf<C>(Pb) | (cc->tab_bp2.q_is_identity != 0);
+        Fp2<C> m = d_one<C>(L);
+        if (!(skipA & skipB)) {
+            int li = 0;
+            const int nops = cc->sched.n_ops;
+            for (int k = 0; k < nops; k++) {
+                if (cc->sched.op[k] == 0) {
+                    m = d_sqr<C>(L, m);
+                } else {
+                    if (!skipA) m = d_mul_line<C>(L, m, cc->tab_pk.e[li], Pa);
+                    if (!skipB) m = d_mul_line<C>(L, m, cc->tab_bp2.e[li], Pb);
+                    li++;
+                }
+            }
+            if constexpr (C::K::X_NEG) m = d_conj<C>(L, m);
+        }
+        uint32_t* o = a.fmiller + (size_t)L.m * 2 * N * a.n + i;
+#pragma unroll
+        for (int j = 0; j < N; j++) { o[(size_t)j * a.n] = m.c0.v[j]; o[(size_t)(N + j) * a.n] = m.c1.v[j]; }
+    }
+};
+
 // ---- latency form (round 3): the two Miller loops of an item on SEPARATE six-lane groups ------------------------------
 // PairDist runs both pairs of an item on one group (63 shared squarings + 2 x 68 line products) and then the final
 // exponentiation: 410 wavefronts of ~4.9 ms for a 4096-item batch on a chip of 1024 SIMDs.  When a batch has the chip to
@@ -1751,7 +1810,8 @@ struct PairMillerHalf {
 };
 template <class C>
 struct PairFinalDist {
-    static constexpr int WAVES_PER_EU = BBS_PAIR_WAVES;
+    static constexpr int WAVES_PER_EU = BBS_PAIRFINAL_WAVES;      // 2: fits 256 registers, see BBS_PAIR_SPLIT2
+    static constexpr int V = BBS_PAIRFINAL_WAVES > 1 ? 1 : 0;     // its own instances of the non-inlined functions (pairing_dist.hpp d_final_exp)
     static __device__ void run(const PairArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const int lane = (int)(t & 63);
@@ -1762,16 +1822,20 @@ struct PairFinalDist {
         if (a.gate_arr[i] != a.gate) return;
         Lane6 L{grp * GRP, lane - grp * GRP};
         if (pair_batch_passed<C>(a)) { if (L.m == 0) a.out[i] = 1; return; }
-        Fp2<C> g0, g1;
+        Fp2<C> g0;
         const uint32_t* p0 = a.fmiller + (size_t)L.m * 2 * N * a.n + i;
-        const uint32_t* p1 = a.fmiller + ((size_t)GRP + L.m) * 2 * N * a.n + i;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            g0.c0.v[j] = p0[(size_t)j * a.n]; g0.c1.v[j] = p0[(size_t)(N + j) * a.n];
-            g1.c0.v[j] = p1[(size_t)j * a.n]; g1.c1.v[j] = p1[(size_t)(N + j) * a.n];
+        for (int j = 0; j < N; j++) { g0.c0.v[j] = p0[(size_t)j * a.n]; g0.c1.v[j] = p0[(size_t)(N + j) * a.n]; }
+        Fp2<C> mf = g0;
+        if (!a.single) {                                        // (uniform over the launch)
+            Fp2<C> g1;
+            const uint32_t* p1 = a.fmiller + ((size_t)GRP + L.m) * 2 * N * a.n + i;
+#pragma unroll
+            for (int j = 0; j < N; j++) { g1.c0.v[j] = p1[(size_t)j * a.n]; g1.c1.v[j] = p1[(size_t)(N + j) * a.n]; }
+            mf = d_mul<C, V>(L, g0, g1);
         }
-        const Fp2<C> mf = d_mul<C>(L, g0, g1);
-        const Fp2<C> f = d_final_exp<C>(L, mf, &a.cc->frob[0][0][0][0]);
+        const Fp2<C> mfc = mf;
+        const Fp2<C> f = d_final_exp<C, V>(L, mfc, &a.cc->frob[0][0][0][0]);
         const bool one = d_is_one<C>(L, f);
         if (L.m == 0) a.out[i] = one ? 1 : 0;
     }

@@ -319,6 +319,9 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         counters, counters_file = load_counters()
+        lib_hash = eng.lib.bbs_source_hash().decode()
+        counters_hash = (counters or {}).get("library_source_hash")
+        counters_current = (counters_hash == lib_hash) if counters_hash else None
         out = {
             "metric": "BBS+ proof_verify/sec (BLS12-381, 32-msg)",
             "value": value, "unit": "proof_verify/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -373,6 +376,7 @@ def main():
                 "frac_exclusive": (alg_bytes / (excl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if excl_ms else None,
                 "frac_per_step": alg_bytes / (dt / args.steps / world) / 1e9 / HBM_PEAK_GBS,
                 "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                "traffic_from_this_library": counters_current,
                 "target_40_percent_of_hbm": "NOT MET and not attainable: 1361 algorithmic bytes against ~2.9e5 wavefront "
                                             "instructions per proof (SURVEY 7/8d); the binding resource is integer VALU issue (valu_issue)",
                 "note": "algorithmic bytes/unit = %d (SURVEY 8d) x %d units per launch; `frac` divides them by the launch duration "
@@ -394,19 +398,47 @@ def main():
                 tot_cyc8 = sum(k["valu_insts"] * k["cycles_per_inst_if_waves_per_simd"]["8"] for k in kc.values()) * (n / 4096.0)
                 clk = counters["clock_ghz_under_load"]
                 avail = 1024 * clk * 1e9 * (dt / args.steps) / world
+                tot_cyc2 = sum(k["valu_insts"] * k["cycles_per_inst_if_waves_per_simd"]["2"] for k in kc.values()) * (n / 4096.0)
+                # the same in TIME (the chip clocks down as more wavefronts issue: a cycle count priced at another occupancy's
+                # clock over-states what co-residency buys): nanoseconds one SIMD spent per wave-instruction in this run against
+                # the micro-benchmarked cost of this opcode mix at 1 / 2 / 4 / 8 wavefronts per SIMD
+                ns_mix = None
+                if all("ns_per_inst_if_waves_per_simd" in k for k in kc.values()):
+                    ns_mix = {w: sum(k["valu_insts"] * k["ns_per_inst_if_waves_per_simd"][w] for k in kc.values()) / sum(k["valu_insts"] for k in kc.values())
+                              for w in ("1", "2", "4", "8")}
+                ns_run = 1024 * (dt / args.steps / world) * 1e9 / tot_inst
                 out["valu_issue"] = {
                     "frac": tot_cyc / avail, "issue_cycles_per_step": tot_cyc, "simd_cycles_available_per_step": avail,
-                    "frac_of_4cycle_peak": tot_inst * 4.0 / avail,
-                    "frac_if_8_waves_per_simd_issue_costs": tot_cyc8 / avail,
+                    "frac_of_multiwave_ceiling": tot_cyc8 / avail,
+                    "frac_if_2_waves_per_simd_issue_costs": tot_cyc2 / avail,
+                    "cycles_per_inst": {"as_run_1_wave_per_simd": tot_cyc / tot_inst, "2_waves_per_simd": tot_cyc2 / tot_inst,
+                                        "8_waves_per_simd": tot_cyc8 / tot_inst},
+                    "ns_per_wave_inst_per_simd": {"this_run": ns_run, "ubench_mix_by_waves_per_simd": ns_mix,
+                                                  "frac_of_2_wave_cost": (ns_mix["2"] / ns_run) if ns_mix else None,
+                                                  "frac_of_8_wave_cost": (ns_mix["8"] / ns_run) if ns_mix else None,
+                                                  "note": "time, not cycles: 1024 SIMDs x step time / wave-instructions of the step; the "
+                                                          "8-wavefront cost of the same opcode mix is the hardware's ceiling, the 2-wavefront "
+                                                          "cost what fitting 256 registers could buy at best -- measured: nothing "
+                                                          "(profiles/r04_d_ab_split_pairing_two_waves.log)"},
                     "valu_wave_insts_per_step": tot_inst, "achieved_ginstr_s": tot_inst * args.steps * world / dt / 1e9 / world,
                     "clock_ghz_under_load": clk, "source": counters_file,
+                    "counters_from_this_library": counters_current,
+                    "counters_note": (None if counters_current else
+                                      ("the counters in %s were taken from a library built from other sources (%s; this run: %s): "
+                                       "instruction counts and traffic are those of THAT build -- re-run tools/run_profile.sh"
+                                       % (counters_file, counters_hash or "no hash recorded", lib_hash))),
                     "note": "issue cycles = sum over kernels of SQ_INSTS_VALU x (opcode histogram of the kernel's ISA . "
-                            "micro-benchmarked issue cost at this kernel's waves per SIMD = 1); reproducible by hand from "
-                            "profiles/ (tools/valu_model.py).  frac = share of the SIMD cycles the step needs just to ISSUE "
-                            "its vector instructions one wavefront per SIMD; frac_if_8_waves_per_simd_issue_costs prices the "
-                            "same instructions at the cheaper issue costs eight co-resident wavefronts would see (the "
-                            "kernels need 400 of 512 registers, so they run one per SIMD); frac_of_4cycle_peak prices every "
-                            "instruction at the hard floor of a wave64 instruction on a 16-lane SIMD (4 cycles)"}
+                            "micro-benchmarked issue cost of every opcode class); reproducible by hand from profiles/ "
+                            "(tools/valu_model.py).  gfx950 SIMDs are 32 lanes wide: a wave64 VALU instruction occupies its SIMD "
+                            "for 2 cycles (simple VOP2) to ~4 (v_mad_u64_u32, 61 percent of these kernels), but ONE wavefront alone "
+                            "issues at most one instruction per 4 - 5 cycles (MI355X_MICROARCH.md:54,473,489; "
+                            "profiles/*_ubench_valu_int.csv).  frac = share of the SIMD cycles the step needs to issue its "
+                            "instructions at the costs a wavefront ALONE on its SIMD pays -- what the kernels run at (398 / 384 "
+                            "VGPRs: one wavefront per SIMD).  frac_of_multiwave_ceiling prices the SAME instructions at the costs "
+                            "eight co-resident wavefronts see (this instruction mix: %.2f cycles per instruction instead of %.2f): "
+                            "the hardware's real ceiling for this mix, which the design cannot reach without fitting 2+ wavefronts "
+                            "per SIMD (<= 256 VGPRs, no spills; DESIGN.md 5, profiles/r04_*_occupancy*)" % (
+                                tot_cyc8 / tot_inst, tot_cyc / tot_inst)}
                 out["kernels"] = [{"kernel": k, "ms_per_launch": per_step.get(k), "valu_wave_insts": v["valu_insts"] * (n / 4096.0),
                                    "cycles_per_inst": v["cycles_per_inst"],
                                    "hbm_bytes": (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 * (n / 4096.0),

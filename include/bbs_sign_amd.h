@@ -100,7 +100,8 @@ void bbs_ctx_destroy(bbs_ctx* ctx);
 size_t bbs_ctx_table_bytes(const bbs_ctx* ctx);
 
 /* window width (bits) of the fixed-base tables, 4..22, or 0 (THE DEFAULT) = chosen at bbs_ctx_set_generators from the
- * memory free on the device: the widest of 20 / 16 / 12 / 8 whose tables fit an eighth of it and 32 GiB -- and, if that
+ * memory free on the device: the widest of 20 / 16 / 12 / 8 whose tables fit 1/32 of it and 8 GiB (32 messages on an empty
+ * MI355X: 16 bits, 2 GB; ask for 20 explicitly where one issuer may have 26 GB for +3.5 %) -- and, if that
  * allocation fails all the same (the free figure is a snapshot: other ranks or processes on the device, fragmentation),
  * the next narrower width, down to 8, before BBS_E_NOMEM; takes effect at the next bbs_ctx_set_generators, which changes
  * nothing of the context unless it succeeds.  Digits are SIGNED: table bytes = (count+1) * ceil(256/w) * 2^(w-1) * 2 * limb bytes of

@@ -259,8 +259,11 @@ def test_auto_form(curve):
             if not nm:
                 return out
             out.append(nm.decode()); k += 1
-    assert "pair_final_exp" in names(jobs[0]) and "pair_final_exp" in names(jobs[1])
-    assert "pairing_6lane" in names(jobs[2]) and "pairing_6lane" in names(jobs[3])
+    # latency form: the two Miller loops of an item on separate wavefronts; throughput form: both on one six-lane group
+    # (either as its own kernel in front of the final exponentiation, or fused with it: BBS_PAIR_SPLIT2)
+    assert "pair_miller" in names(jobs[0]) and "pair_miller" in names(jobs[1])
+    assert ("pair_miller_both" in names(jobs[2]) or "pairing_6lane" in names(jobs[2])) and "pair_miller" not in names(jobs[2])
+    assert ("pair_miller_both" in names(jobs[3]) or "pairing_6lane" in names(jobs[3])) and "pair_miller" not in names(jobs[3])
     pjobs = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(2)]      # live jobs 5 and 6: throughput form
     for j in jobs + pjobs:
         j.run()

@@ -47,6 +47,20 @@ def class_costs(ub, waves):
     return {"mad": mad, "vop3": vop3, "simple": simple, "carry": carry}
 
 
+def class_costs_ns(ub, waves):
+    """the same four classes in NANOSECONDS per wave-instruction per SIMD (8 independent chains).  Time, not cycles: the
+    chip clocks down as more wavefronts issue (the micro-benchmark's own clock column: 2.4 GHz at one wavefront per SIMD,
+    1.3 - 1.6 at four), so a cost in cycles at one occupancy times a clock measured at another over-states what
+    co-residency buys; a cost in nanoseconds is what the SIMD actually delivered."""
+    w = min((1, 2, 4, 8), key=lambda x: abs(x - waves))
+    ns = lambda op: ub[op][(8, w)][0]
+    simple_ops = ["v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_lshrrev_b32", "v_mov_b32"]
+    vop3_ops = ["v_mul_lo_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_and_or_b32", "v_bfe_u32", "v_alignbit_b32", "v_lshl_add_u64"]
+    mix = "mix:3xv_mad_u64_u32+1xv_and_b32"
+    return {"mad": (4 * ns(mix) - ns("v_and_b32")) / 3.0, "vop3": sum(ns(o) for o in vop3_ops) / len(vop3_ops),
+            "simple": sum(ns(o) for o in simple_ops) / len(simple_ops), "carry": ns("v_add_co_u32+v_addc_co_u32")}
+
+
 def classify(op):
     base = op.replace("_e32", "").replace("_e64", "").replace("_sdwa", "").replace("_dpp", "")
     if base == "v_mad_u64_u32" or base == "v_mad_i64_i32":
@@ -89,6 +103,9 @@ def main():
         def cpi_at(w):
             cw = class_costs(ub, w)
             return sum(share[cl] * cw[cl] for cl in share)
+        def ns_at(w):
+            cw = class_costs_ns(ub, w)
+            return sum(share[cl] * cw[cl] for cl in share)
         cpi = cpi_at(waves_per_simd)
         # clock = GRBM_GUI_ACTIVE / 8 / duration: only meaningful for a kernel that runs long enough for the counter window to
         # be the kernel (a 10 us kernel reads 9 GHz)
@@ -96,6 +113,7 @@ def main():
         kernels[stage] = {"kernel": k, "valu_insts": c["SQ_INSTS_VALU"], "FETCH_SIZE_KiB": c.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": c.get("WRITE_SIZE", 0.0),
                           "waves": c.get("SQ_WAVES"), "waves_per_simd": waves_per_simd, "cycles_per_inst": cpi, "own_isa_histogram": own,
                           "cycles_per_inst_if_waves_per_simd": {str(w): round(cpi_at(w), 3) for w in (1, 2, 4, 8)},
+                          "ns_per_inst_if_waves_per_simd": {str(w): round(ns_at(w), 4) for w in (1, 2, 4, 8)},
                           "opcode_class_share": {cl: round(share[cl], 4) for cl in ("mad", "vop3", "simple", "carry")},
                           "class_cost_cycles": {cl: round(cost[cl], 3) for cl in cost},
                           "wait_any_over_wave_cycles": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
@@ -103,7 +121,11 @@ def main():
         print("%-24s %12.4g %7.3f %7.3f %7.3f %7.3f %9.3f" % (k, c["SQ_INSTS_VALU"], share["mad"], share["vop3"], share["simple"], share["carry"], cpi))
     big = [v for v in kernels.values() if v["clock_ghz_grbm"] and v["valu_insts"] > 1e8]
     clock = sum(v["clock_ghz_grbm"] * v["duration_ns_exclusive"] for v in big) / sum(v["duration_ns_exclusive"] for v in big)
-    out = {"kernels": kernels, "clock_ghz_under_load": clock,
+    # the sources the profiled library was built from: bench.py compares this with the library it runs and flags a mismatch
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bbs_sign_amd import build as _build
+    out = {"kernels": kernels, "clock_ghz_under_load": clock, "library_source_hash": os.environ.get("BBS_PROFILED_HASH") or _build.source_hash(),
            "source": "%s_{pmc,ubench_valu_int,isa_histogram}.csv via tools/valu_model.py" % pre,
            "note": "SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE: rocprofv3 --pmc, mean of the last launches, one 4096-item BLS12-381 batch; rocprofv3 "
                    "serialises dispatches while collecting counters, so cycle counters are exclusive-run values; clock = GRBM_GUI_ACTIVE / 8 / kernel duration"}
