@@ -102,6 +102,7 @@ struct Pools {
     std::multimap<size_t, void*> pinned;
     size_t pinned_bytes = 0;
     std::map<int, std::vector<hipEvent_t>> timing_events;      // events WITH timing (stage timers), recycled
+    std::map<int, int> dedicated_made;                         // streams with a hardware queue of their own, per device
     static Pools& get() { static Pools* p = new Pools(); return *p; }      // lives as long as the process
 };
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -207,12 +208,32 @@ inline void hfree(void* p, size_t b) {
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 inline size_t mem_free_bytes() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? f : 0; }
 using Event = hipEvent_t;
+// -1: not decided yet (the environment is read at the first stream); 0: off; k > 0: up to k job streams per device
+inline std::atomic<int>& dedicated_queues() { static std::atomic<int> v{-1}; return v; }
 inline int stream_create(Stream* s) {
     Pools& P = Pools::get();
     std::lock_guard<std::mutex> g(P.mu);
     auto& v = P.streams[current_device()];
     if (!v.empty()) { *s = v.begin()->second; v.erase(v.begin()); return 0; }
-    if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) return -1;
+    // Dedicated hardware queues (bbs_runtime_set_dedicated_queues / BBS_DEDICATED_QUEUES=k): the runtime gives a stream
+    // created with a compute-unit mask (here: all ones, no restriction) a hardware queue of its own instead of a share of
+    // the GPU_MAX_HW_QUEUES pool.  For a process whose first HIP call came BEFORE this library was loaded (any torch user):
+    // the pool is then fixed at the runtime's default of 4, several jobs share a queue and a long narrow kernel blocks the
+    // others (measured: 1.30 M proof_verify/s instead of 1.50 M; with dedicated queues 1.50 M whatever the pool,
+    // profiles/r04_f_dedicated_queues.log).  At most k streams per device are created this way (default cap 12: every
+    // queue reserves scratch for the largest kernel it has run, and queues x bytes per lane is a budget, DESIGN.md 5 rule
+    // 6); further streams come from the pool.  Such streams are BLOCKING with respect to the legacy default stream (the
+    // runtime offers no flags for them): off unless asked for.
+    int want = dedicated_queues().load();
+    if (want < 0) { const char* v = getenv("BBS_DEDICATED_QUEUES"); want = v ? atoi(v) : 0; if (want == 1) want = 12; if (want < 0) want = 0; dedicated_queues().store(want); }
+    bool made = false;
+    if (want > 0 && P.dedicated_made[current_device()] < want) {
+        uint32_t mask[16];
+        for (auto& m : mask) m = 0xFFFFFFFFu;
+        if (hipExtStreamCreateWithCUMask(s, 16, mask) == hipSuccess) { made = true; P.dedicated_made[current_device()]++; }
+        else (void)hipGetLastError();
+    }
+    if (!made && hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) return -1;
     P.stream_index[*s] = P.next_stream_index++;
     return 0;
 }

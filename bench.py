@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--min-batch", type=int, default=None, help="mixed65536 only: smallest job a rank's share is cut into")
     ap.add_argument("--latency-mode", type=int, default=None, help="A/B and profiling: bbs_ctx_set_latency_mode 0 = throughput form for every "
                     "job, 1 = latency form, default = the library's AUTO (by live jobs)")
+    ap.add_argument("--dedicated-queues", type=int, default=None, help="bbs_runtime_set_dedicated_queues(k): up to k job streams get a "
+                    "hardware queue of their own, independent of GPU_MAX_HW_QUEUES (for processes whose first HIP call precedes the library)")
     ap.add_argument("--fifo-retire", action="store_true", help="A/B: wait for the OLDEST outstanding job (round 3's loop) instead of "
                     "bbs_jobs_wait_any's completion order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,6 +252,9 @@ def main():
 
     from bbs_sign_amd import workload as pc    # SURVEY 8(d) inputs from the product's own host functions: no oracle, no tests/
     from bbs_sign_amd import Engine  # noqa: F401  (fails loudly if the HIP library is missing)
+    if args.dedicated_queues is not None:
+        from bbs_sign_amd import _lib
+        assert _lib.load_library().bbs_runtime_set_dedicated_queues(args.dedicated_queues) == 0
 
     if args.config == "mixed65536":
         from bench_mixed import run_mixed
@@ -332,6 +337,7 @@ def main():
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
                        "batches_in_flight": n_slots, "retire_order": "fifo (oldest first)" if args.fifo_retire else "completion (bbs_jobs_wait_any)",
                        "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),
+                       "dedicated_queues": args.dedicated_queues if args.dedicated_queues is not None else (os.environ.get("BBS_DEDICATED_QUEUES") or 0),
                        "timed_region": "host buffers -> page-locked staging -> one async H2D -> device-side validation/"
                                        "unpack -> kernels -> async D2H of statuses; one submitting thread per GPU "
                                        "(SURVEY 8d)",

@@ -91,6 +91,16 @@ const char* bbs_source_hash(void);
  * variable is already set; the HIP runtime reads it at its own initialisation, so the setting only takes effect if
  * this library was loaded before the process's first HIP call ("Build / deployment"). */
 int bbs_runtime_hw_queues(void);
+/* For a process that cannot arrange that (its first HIP call -- any torch import that touches the GPU -- comes before this
+ * library is loaded: the runtime's pool is then 4 hardware queues, several jobs share one, 1.30 M proof_verify/s instead
+ * of 1.50 M): up to k job streams per device get a hardware queue OF THEIR OWN (streams created with an all-ones
+ * compute-unit mask, which the runtime does not draw from the pool) -- 1.50 M/s whatever GPU_MAX_HW_QUEUES says
+ * (profiles/r04_f_dedicated_queues.log).  k = 0: off (the default); 12 is a good value: every hardware queue reserves
+ * scratch memory for the largest kernel it has run and pool + dedicated queues beyond ~16 exhaust it.
+ * Call before the first context is created (streams are recycled); BBS_DEDICATED_QUEUES=k in the environment does the same
+ * (1 means 12).  Caveat: such streams synchronise with the legacy default stream (the runtime offers no non-blocking flag
+ * for them): a process that also runs its own kernels on stream 0 serialises them with the jobs. */
+int bbs_runtime_set_dedicated_queues(int k);
 int bbs_device_count(void);
 size_t bbs_device_free_bytes(int device_id);          /* device memory free right now (0: no such device) */
 

@@ -298,3 +298,23 @@ def test_issuer_threads(curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_issuer_budget(curve):
     pc.check_issuer_budget(curve, None)
+
+
+def test_dedicated_queues_under_the_runtimes_default_pool():
+    """A process whose HIP runtime was initialised with the default pool of 4 hardware queues (GPU_MAX_HW_QUEUES=4 here stands
+    for "torch touched the GPU before the library was loaded"): with bbs_runtime_set_dedicated_queues the job streams get
+    hardware queues of their own.  Functional check through bench.py's own loop (distinct batches in flight, one of them
+    corrupted, statuses compared on every step); the rates are in profiles/r04_f_dedicated_queues.log."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dedicated-queues", "12", "--steps", "12", "--warmup", "3", "--batch", "1024",
+                        "--inflight", "8", "--window-bits", "16", "--no-extras", "--no-cpu-baseline", "--min-region-s", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["checks"]["statuses_exact_every_step"] is True and line["config"]["dedicated_queues"] == 12 and line["config"]["hw_queues"] == 4

@@ -19,7 +19,7 @@ import sys
 
 STAGE_OF = {"PairDist<BlsCurve>": "pairing_6lane", "PvMsmPart<BlsCurve>": "pv_msm_parts", "PvChallenge<BlsCurve>": "pv_challenge",
             "PvScalars<BlsCurve>": "pv_scalars", "PvFinish": "pv_finish", "PairMillerHalf<BlsCurve>": "pair_miller",
-            "PairFinalDist<BlsCurve>": "pair_final_exp"}
+            "PairFinalDist<BlsCurve>": "pair_final_exp", "PairMillerBoth<BlsCurve>": "pair_miller_both"}
 SIMPLE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32",
           "v_mov_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32", "v_not_b32", "v_max_i32", "v_min_i32", "v_max_u32",
           "v_min_u32", "v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32", "v_mul_i32_i24", "v_mul_u32_u24", "v_bfrev_b32"}
