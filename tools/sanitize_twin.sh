@@ -44,6 +44,8 @@ for curve in ("bls12_381", "bn254"):
     pc.check_sign_verify_wire(curve, lib)
     pc.check_fixed_base_tree(curve, lib, n_pv=6)
     pc.check_issuer_mixed_lengths(curve, lib)
+    pc.check_issuer_budget(curve, lib)
+    pc.check_issuer_threads(curve, lib, threads=3, rounds=2)
     pc.check_big_batch(curve, lib, n=66, L=4, R=2, window_bits=4)
     print(curve, "ok", flush=True)
 pc.check_threads(lib, threads=3, rounds=2, n=5)

@@ -28,6 +28,8 @@ while time.time() - t0 < budget:
         if max(lens[:7]) > 6:                              # the case tampers with items 0 .. 6: the over-long item goes behind them
             lens.sort()
         pc.check_issuer_mixed_lengths(curve, None, seed=seed, lengths=tuple(lens), oracle_items=(0,))
+        if seed % 4 == 0:
+            pc.check_issuer_budget(curve, None, seed=seed)          # bounded contexts: eviction, rebuild, -43, refused configuration
         done += 1
     seed += 1
     print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
