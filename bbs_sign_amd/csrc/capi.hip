@@ -17,9 +17,9 @@ extern "C" __attribute__((visibility("default"))) int bbs_runtime_hw_queues(void
 }
 
 // Job streams with hardware queues of their own (runtime.hpp stream_create): k = 0 off, k > 0 at most k per device (at most
-// 32); takes effect for streams created afterwards (streams are pooled: call it before the first context is created).
+// 16); takes effect for streams created afterwards (streams are pooled: call it before the first context is created).
 extern "C" __attribute__((visibility("default"))) int bbs_runtime_set_dedicated_queues(int k) {
-    if (k < 0 || k > 32) return BBS_E_ARG;
+    if (k < 0 || k > 16) return BBS_E_ARG;      // beyond ~20 hardware queues in all the runtime runs out of scratch and aborts the process
 #ifndef BBS_HOST_TWIN
     rt::dedicated_queues().store(k);
 #endif

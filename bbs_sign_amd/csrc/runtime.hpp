@@ -225,7 +225,7 @@ inline int stream_create(Stream* s) {
     // 6); further streams come from the pool.  Such streams are BLOCKING with respect to the legacy default stream (the
     // runtime offers no flags for them): off unless asked for.
     int want = dedicated_queues().load();
-    if (want < 0) { const char* v = getenv("BBS_DEDICATED_QUEUES"); want = v ? atoi(v) : 0; if (want == 1) want = 12; if (want < 0) want = 0; dedicated_queues().store(want); }
+    if (want < 0) { const char* v = getenv("BBS_DEDICATED_QUEUES"); want = v ? atoi(v) : 0; if (want == 1) want = 12; if (want < 0) want = 0; if (want > 16) want = 16; dedicated_queues().store(want); }
     bool made = false;
     if (want > 0 && P.dedicated_made[current_device()] < want) {
         uint32_t mask[16];

@@ -95,8 +95,9 @@ int bbs_runtime_hw_queues(void);
  * library is loaded: the runtime's pool is then 4 hardware queues, several jobs share one, 1.30 M proof_verify/s instead
  * of 1.50 M): up to k job streams per device get a hardware queue OF THEIR OWN (streams created with an all-ones
  * compute-unit mask, which the runtime does not draw from the pool) -- 1.50 M/s whatever GPU_MAX_HW_QUEUES says
- * (profiles/r04_f_dedicated_queues.log).  k = 0: off (the default); 12 is a good value: every hardware queue reserves
- * scratch memory for the largest kernel it has run and pool + dedicated queues beyond ~16 exhaust it.
+ * (profiles/r04_f_dedicated_queues.log).  k = 0: off (the default); 12 is a good value, 16 the most accepted: every hardware
+ * queue reserves scratch memory for the largest kernel it has run, and beyond ~20 queues in all (pool + dedicated) the runtime
+ * runs out and ABORTS the process.
  * Call before the first context is created (streams are recycled); BBS_DEDICATED_QUEUES=k in the environment does the same
  * (1 means 12).  Caveat: such streams synchronise with the legacy default stream (the runtime offers no non-blocking flag
  * for them): a process that also runs its own kernels on stream 0 serialises them with the jobs. */
@@ -523,7 +524,8 @@ int bbs_issuer_proof_gen(bbs_issuer* issuer, size_t n, const uint8_t* signature_
 /* The asynchronous forms, for a serving loop that keeps several lists in flight: *_submit packs the groups, submits them and
  * returns; the inputs may be released at once, `status` and the output buffers must stay valid until bbs_issuer_job_wait,
  * which waits for every group and scatters the results into the caller's order (BBS_E_STATE if an item was left undecided).
- * bbs_issuer_job_free releases the job (after waiting for it if that has not happened).  Arguments as the synchronous calls. */
+ * bbs_issuer_job_free releases the job (after waiting for it if that has not happened); every job of an issuer must be freed
+ * before bbs_issuer_destroy (it holds the issuer's contexts).  Arguments as the synchronous calls. */
 typedef struct bbs_issuer_job bbs_issuer_job;
 int bbs_issuer_proof_verify_submit(bbs_issuer* issuer, size_t n, const uint8_t* proof_octets, const uint64_t* oct_off,
                                    const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,

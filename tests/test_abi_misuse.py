@@ -140,3 +140,17 @@ def test_rerun_of_a_submitted_job_delivers_the_new_results(twin, curve):
     assert (job.result == 0).all(), list(job.result)
     job.free()
     eng.close()
+
+
+def test_runtime_and_wait_any_arguments(twin):
+    lib = _lib.load_library(twin)
+    assert lib.bbs_runtime_set_dedicated_queues(-1) == E_ARG and lib.bbs_runtime_set_dedicated_queues(17) == E_ARG
+    assert lib.bbs_runtime_set_dedicated_queues(0) == 0
+    idx = ctypes.c_size_t(5)
+    assert lib.bbs_jobs_wait_any(None, 0, ctypes.byref(idx)) == E_ARG
+    arr = (ctypes.c_void_p * 2)(None, None)
+    assert lib.bbs_jobs_wait_any(arr, 2, None) == E_ARG
+    assert lib.bbs_jobs_wait_any(arr, 2, ctypes.byref(idx)) == E_STATE and idx.value == 5      # nothing to wait for; index untouched
+    assert lib.bbs_job_poll(None) == E_ARG
+    assert lib.bbs_ctx_table_bytes(None) == 0 and lib.bbs_issuer_table_bytes(None) == 0
+    assert lib.bbs_issuer_set_budget(None, 4, 0) == E_ARG
