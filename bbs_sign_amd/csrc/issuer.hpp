@@ -32,7 +32,8 @@ struct bbs_issuer_entry {
     uint64_t config_epoch = 0;           // the issuer configuration (keys, modes) this context was last brought up to
     size_t table_bytes = 0;
     // guarded by the issuer's mutex:
-    int pins = 0;                        // routed lists in flight on this context (+1 for ever if it was handed out by bbs_issuer_context)
+    int pins = 0;                        // routed lists in flight on this context
+    bool handed_out = false;             // bbs_issuer_context gave the raw context to the caller: never evicted
     uint64_t last_use = 0;
     bool dead = false;                   // evicted: a thread that still holds the entry must look it up again
     ~bbs_issuer_entry() { if (ctx) bbs_ctx_destroy(ctx); }
@@ -84,7 +85,7 @@ struct bbs_issuer {
         while (over()) {
             std::map<size_t, std::shared_ptr<bbs_issuer_entry>>::iterator lru = by_count.end();
             for (auto it = by_count.begin(); it != by_count.end(); ++it) {
-                if (it->second->pins > 0 || it->second.get() == keep) continue;
+                if (it->second->pins > 0 || it->second->handed_out || it->second.get() == keep) continue;
                 if (lru == by_count.end() || it->second->last_use < lru->second->last_use) lru = it;
             }
             if (lru == by_count.end()) return;               // everything left is in use
@@ -114,7 +115,8 @@ struct bbs_issuer {
             }
             if (!rc) {
                 out = it->second;
-                out->pins += forever ? (1 << 20) : 1;
+                out->pins += 1;
+                if (forever) out->handed_out = true;
                 out->last_use = ++tick;
                 snapshot(cfg);
             }
@@ -210,11 +212,14 @@ struct bbs_issuer {
         if (rc) return rc;
         std::lock_guard<std::mutex> g(e->mu);
         rc = prepare(e.get(), cfg);
-        if (rc) {
+        {
             std::lock_guard<std::mutex> g2(mu);
-            e->pins -= (1 << 20);
-            if (!e->ctx) { auto it = by_count.find(L); if (it != by_count.end() && it->second == e) { e->dead = true; by_count.erase(it); } }
-            return rc;
+            if (e->pins > 0) e->pins--;                      // (the pin only covered the build; handed_out keeps the context resident)
+            if (rc) {
+                e->handed_out = false;
+                if (!e->ctx) { auto it = by_count.find(L); if (it != by_count.end() && it->second == e && e->pins == 0) { e->dead = true; by_count.erase(it); } }
+                return rc;
+            }
         }
         *out = e->ctx;
         return BBS_OK;

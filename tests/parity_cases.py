@@ -2096,4 +2096,14 @@ def check_issuer_budget(curve, lib_path=None, seed=171):
     o_new, st_new = iss.sign([first[1][0]])
     w = bbs.sign(suite, sk + 1, first[1][0], b"")
     assert list(st_new) == [1] and o_new[0] == api.signature_to_octets(curve, Signature(w.a, w.e), lib_path)
+    # a context handed out raw (bbs_issuer_context, e.g. to warm it up) is never evicted, and does not block configuration
+    iss.warm(5)
+    iss.set_budget(1, 0)
+    assert iss.context_count() == 1                           # the warmed one; everything else was idle and left
+    iss.set_secret_key(sk + 2)
+    m5, m2 = msgs_of(5), msgs_of(2)
+    o5, st5 = iss.sign([m5, m2])
+    assert [int(x) for x in st5] == [1, -43], list(st5)       # the one slot is taken by the context that cannot leave
+    w5 = bbs.sign(suite, sk + 2, m5, b"")
+    assert o5[0] == api.signature_to_octets(curve, Signature(w5.a, w5.e), lib_path) and o5[1] == b""
     iss.close()
