@@ -29,6 +29,24 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
             j.free()
         return size * steps / (ms * 1e-3)
 
+    def rate_k_any(make, k=16, steps=128):          # k resident batches in flight, re-run in COMPLETION order (bbs_jobs_wait_any)
+        js = [make() for _ in range(k)]
+        for j in js:
+            j.run()
+        for _ in range(k):                          # warm: every job once more, whichever finishes first goes again
+            js[Job.wait_any(js)].run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            js[Job.wait_any(js)].run()
+        dt = time.perf_counter() - t0               # `steps` jobs retired (and re-submitted) in dt
+        for j in js:
+            j.wait()
+            assert (j.status() == 1).all()
+        size = js[0].n
+        for j in js:
+            j.free()
+        return size * steps / dt
+
     eng.set_latency_mode(False)        # every leg below states its form: throughput unless it says otherwise
     out = {"unit": "items/s; single = one 4096-item resident batch at a time, *_8_in_flight = eight resident batches; jobs in "
                    "the throughput form unless a leg says otherwise"}
@@ -99,6 +117,9 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     bls["proof_verify_batch_verification_16384_items"] = rate_k(
         lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 48)
     bls["verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_verify_upload(sigs, msgs), 32, 96)
+    # the same 4096-item jobs retired in completion order, as a serving loop does (round 4): jobs whose tails end early go
+    # again at once instead of waiting for an older job (profiles/r04_k_bv_paced.log)
+    bls["proof_verify_batch_verification_16_in_flight_completion_order"] = rate_k_any(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 16, 160)
     eng.set_batch_verification(False)
     eng.set_points_in_subgroup(True)
     bls["points_in_subgroup"] = {"proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed)),

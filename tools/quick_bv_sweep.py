@@ -16,7 +16,7 @@ dm = [m[:8] for m in msgs]
 eng.set_latency_mode(bool(int(os.environ.get("FORM", "0"))))
 print("latency form", os.environ.get("FORM", "0"))
 print("hw queues", eng.lib.bbs_runtime_hw_queues(), flush=True)
-for bv in (True, False):
+for bv in ((True,) if os.environ.get("BV_ONLY") else (True, False)):
     eng.set_batch_verification(bv)
     for k in ks:
         js = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(k)]
