@@ -713,6 +713,121 @@ BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<
                       g1_mul_aff_tab<C, AtHbm<C>>(p2, k2, w2));
 }
 
+// k0 P0 + k1 P1 on ONE shared doubling chain: the two-term form of g1_mul3_aff_fast (its own function so that the
+// three-term one -- proof_verify's T1, the headline path -- is compiled exactly as before).  Used by proof_gen's throughput
+// form: Bbar = (r1 r2) B - (e r1 r2) A and T1 = (r1~ r2) B + (e~ r1 r2) A (src/proof_gen.rs:254-258 restructured over A and
+// B) are two chains of ~252 doublings instead of four.  Tables in the caller's HBM buffer (2 * G1_TAB * 2N words, stride apart).
+template <class C, bool GLV = false>
+BBS_HD_NOINLINE bool g1_mul2_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
+                                       uint32_t* tabs, size_t stride, G1Jac<C>& out) {
+#ifdef BBS_G1_MUL_NAF
+    return false;
+#endif
+    constexpr int N = C::FpP::N;
+    Fp<C> zc[2];
+    const G1Aff<C>* ps[2] = {&p0, &p1};
+    bool ok = true;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        ok = ok && g1_odd_table<C>(*ps[j], tab, zc[j]);
+    }
+    if (!ok) return false;
+    // point (x, y) of table j is Jacobian (x, y, zc_j) = (x t^2, y t^3, zc_0 zc_1) with t = the other table's scale
+    const Fp<C> zall = fe_mul<FP>(zc[0], zc[1]);
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        const Fp<C> tj = zc[1 - j];
+        const Fp<C> t2 = fe_sqr<FP>(tj), t3 = fe_mul<FP>(t2, tj);
+#pragma unroll 1
+        for (int e = 0; e < G1_TAB; e++) {
+            const G1Aff<C> q = tab.ld(e);
+            tab.st(e, G1Aff<C>{fe_mul<FP>(q.x, t2), fe_mul<FP>(q.y, t3)});
+        }
+    }
+    G1Jac<C> r = g1j_inf<C>();
+    if constexpr (GLV) {
+        // terms t = 2 * table + half: (P_j, k_j mod lambda), (phi P_j, floor(k_j / lambda))
+        uint32_t u[4][4];
+        bool even[4], neg[4];
+        const uint32_t* ks[2] = {k0, k1};
+#pragma unroll 1
+        for (int j = 0; j < 2; j++) {
+            uint32_t h0[4], h1[4];
+            glv_split<C>(ks[j], h0, h1, neg[2 * j], neg[2 * j + 1]);
+            g1_recode128(h0, u[2 * j]);
+            g1_recode128(h1, u[2 * j + 1]);
+            even[2 * j] = (h0[0] & 1u) == 0;
+            even[2 * j + 1] = (h1[0] & 1u) == 0;
+        }
+        const Fp<C> beta = glv_beta<C>();
+        constexpr int STEPS = 33 * 4;
+        auto fetch = [&](int s) -> G1Aff<C> {
+            const int rd = s / 4, t = s - 4 * rd, i = 31 - rd;
+            const TabHbm<C> tab{tabs + (size_t)(t >> 1) * G1_TAB * 2 * N * stride, stride};
+            G1Aff<C> q;
+            if (i >= 0) q = g1_tab_digit<C>(tab, (u[t][i >> 3] >> (4 * (i & 7))) & 15u, neg[t]);
+            else q = even[t] ? (neg[t] ? tab.ld(0) : g1a_neg<C>(tab.ld(0))) : g1a_inf<C>();
+            return q;
+        };
+        G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+        for (int s = 0; s < STEPS; s++) {
+            G1Aff<C> q = qn;
+            if (s + 1 < STEPS) qn = fetch(s + 1);
+            if (s & 1) q.x = G1MUL<FP>(q.x, beta);      // phi (odd terms), applied after the next entry has been requested
+            const int rd = s / 4;
+            if (s == 4 * rd && rd >= 1 && rd <= 31) {
+#pragma unroll 1
+                for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+            }
+            r = g1j_add_aff<C>(r, q);
+        }
+    } else {
+        uint32_t u[2][8];
+        g1_recode(k0, u[0]); g1_recode(k1, u[1]);
+        const bool even[2] = {(k0[0] & 1u) == 0, (k1[0] & 1u) == 0};
+        // 65 rounds (digits 63 .. 0, then the even-scalar corrections) x 2 tables, flattened: step s = round * 2 + table
+        constexpr int STEPS = 65 * 2;
+        auto fetch = [&](int s) -> G1Aff<C> {
+            const int rd = s >> 1, j = s & 1, i = 63 - rd;
+            const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+            if (i >= 0) return g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
+            return even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
+        };
+        G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+        for (int s = 0; s < STEPS; s++) {
+            const G1Aff<C> q = qn;
+            if (s + 1 < STEPS) qn = fetch(s + 1);
+            const int rd = s >> 1;
+            if (s == 2 * rd && rd >= 1 && rd <= 63) {
+#pragma unroll 1
+                for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+            }
+            r = g1j_add_aff<C>(r, q);
+        }
+    }
+    r.z = fe_mul<FP>(r.z, zall);
+    out = r;
+    return true;
+}
+template <class C>
+BBS_HD G1Jac<C> g1_mul2_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
+                             uint32_t* tabs, size_t stride, bool glv = false) {
+    G1Jac<C> r;
+    if constexpr (C::K::HAS_GLV) {
+        if (glv && g1_mul2_aff_fast<C, true>(p0, k0, p1, k1, tabs, stride, r)) return r;
+    }
+    if (!glv && g1_mul2_aff_fast<C>(p0, k0, p1, k1, tabs, stride, r)) return r;
+    // a table hit an exceptional case (identity, point of small order): two separate multiplications, each of which falls
+    // back to the generic chain on its own; their tables reuse the caller's buffer
+    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    const AtHbm<C> w0{tabs, stride}, w1{tabs + TW * stride, stride};
+    return g1j_add<C, 1>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1));
+}
+
 template <class C>
 BBS_HD G1Jac<C> g1_mul_aff_glv(const G1Aff<C>& p, const uint32_t* k) { return g1_mul_aff_glv_tab<C, AtPriv<C>>(p, k, AtPriv<C>{}); }
 
