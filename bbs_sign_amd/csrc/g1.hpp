@@ -828,6 +828,63 @@ BBS_HD G1Jac<C> g1_mul2_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<
     return g1j_add<C, 1>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1));
 }
 
+// ---- comb over 64-bit pieces (round 4; proof_gen) ------------------------------------------------------------------
+// A point that is multiplied by SEVERAL scalars of the same item (proof_gen: B by four, A by three; src/proof_gen.rs:254-258
+// restructured over A and B) gets its doublings done ONCE: the sub-bases Q_j = 2^(64 j) P, j = 0 .. 3 (192 doublings), each with
+// its table of odd multiples 1, 3, .., 15 in TRUE affine form, live in HBM ([piece][entry][2N words], `stride` apart; built by
+// stage PgTables).  A scalar k = sum_j k_j 2^(64 j) then costs 60 doublings and 4 x 17 mixed additions instead of 252 and 65:
+//   k P = sum_j k_j Q_j,  k_j = sum_{i<16} d_(j,i) 16^i with odd digits d = 2 U - 15 read from u_j = (k_j >> 1) | 2^63 (the
+//   regular recoding of g1_recode, per piece; an even piece is corrected by one more addition of -Q_j)
+// and any number of (point, scalar) terms share the one chain of 60 doublings.  The additions are the complete mixed addition
+// (g1j_add_aff), so the chain is right for any table contents that are the multiples they claim to be.
+constexpr int COMB_PIECES = 4;
+constexpr size_t comb_table_words(int n_fp_limbs) { return (size_t)COMB_PIECES * G1_TAB * 2 * (size_t)n_fp_limbs; }
+struct CombTerm {
+    const uint32_t* tab;      // this point's [COMB_PIECES][G1_TAB][2N] table (word w of entry e of piece j at tab[((j * G1_TAB + e) * 2N + w) * stride])
+    uint32_t u[COMB_PIECES][2];
+    bool even[COMB_PIECES];
+    bool neg;                 // the term enters with a minus sign
+};
+BBS_HD void comb_recode(const uint32_t* k, bool neg, const uint32_t* tab, CombTerm& t) {
+    t.tab = tab; t.neg = neg;
+#pragma unroll
+    for (int j = 0; j < COMB_PIECES; j++) {
+        const uint32_t lo = k[2 * j], hi = k[2 * j + 1];
+        t.u[j][0] = (lo >> 1) | (hi << 31);
+        t.u[j][1] = (hi >> 1) | 0x80000000u;
+        t.even[j] = (lo & 1u) == 0;
+    }
+}
+template <class C, int NT>
+BBS_HD_NOINLINE void g1_comb_sum_to(const CombTerm* terms, size_t stride, G1Jac<C>& out) {
+    constexpr int N = C::FpP::N;
+    constexpr int PER_ROUND = NT * COMB_PIECES;
+    constexpr int STEPS = 17 * PER_ROUND;            // rounds 0 .. 15: digits 15 .. 0; round 16: the even-piece corrections
+    auto fetch = [&](int s) -> G1Aff<C> {
+        const int rd = s / PER_ROUND, w = s - rd * PER_ROUND, t = w / COMB_PIECES, j = w - t * COMB_PIECES, i = 15 - rd;
+        const CombTerm& T = terms[t];
+        const TabHbm<C> tab{const_cast<uint32_t*>(T.tab) + (size_t)j * G1_TAB * 2 * N * stride, stride};
+        if (i >= 0) return g1_tab_digit<C>(tab, (T.u[j][i >> 3] >> (4 * (i & 7))) & 15u, T.neg);
+        if (!T.even[j]) return g1a_inf<C>();
+        const G1Aff<C> q = tab.ld(0);
+        return T.neg ? q : g1a_neg<C>(q);            // k_j even: (k_j + 1) Q_j was summed, take Q_j off again (with the term's sign)
+    };
+    G1Jac<C> r = g1j_inf<C>();
+    G1Aff<C> qn = fetch(0);
+#pragma unroll 1
+    for (int s = 0; s < STEPS; s++) {
+        const G1Aff<C> q = qn;
+        if (s + 1 < STEPS) qn = fetch(s + 1);        // the next entry is requested before this addition (HBM latency hidden)
+        const int rd = s / PER_ROUND;
+        if (s == rd * PER_ROUND && rd >= 1 && rd <= 15) {
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) r = g1j_dbl<C>(r);
+        }
+        r = g1j_add_aff<C>(r, q);
+    }
+    out = r;
+}
+
 template <class C>
 BBS_HD G1Jac<C> g1_mul_aff_glv(const G1Aff<C>& p, const uint32_t* k) { return g1_mul_aff_glv_tab<C, AtPriv<C>>(p, k, AtPriv<C>{}); }
 

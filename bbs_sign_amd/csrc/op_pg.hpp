@@ -181,6 +181,12 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     // joint chains otherwise (14 % fewer instructions per proof)
     a.nvar = job->latency_form ? PG_NVAR : PG_NVAR_JOINT;
     a.vtab = job->template scratch<uint32_t>((size_t)2 * 2 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);
+    a.ctab = nullptr; a.comb_ok = nullptr;
+    static const bool use_comb = [] { const char* v = getenv("BBS_PG_COMB"); return !v || atoi(v) != 0; }();     // A/B: BBS_PG_COMB=0
+    if (a.nvar == PG_NVAR_JOINT && use_comb) {
+        a.ctab = job->template scratch<uint32_t>((size_t)2 * comb_table_words(N) * std::max<size_t>(n, 1), rc);
+        a.comb_ok = job->template scratch<int8_t>(2 * std::max<size_t>(n, 1), rc);
+    }
     a.out_pts = job->template scratch<uint32_t>((size_t)3 * 2 * NC * n, rc);
     a.out_sc = job->template scratch<uint32_t>((size_t)4 * 8 * n, rc);
     a.out_mhat = job->template scratch<uint32_t>((size_t)std::max(L, 1) * 8 * n, rc);
@@ -201,6 +207,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     j->stages.push_back({"pg_scalars", [j]() { return rt::launch<PgScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->stream(), j->a, j->n * NFIX); }});
     j->stages.push_back({"pg_b_combine", [j]() { return rt::launch<PgBCombine<C>>(j->stream(), j->a, j->n); }});
+    if (j->a.ctab) j->stages.push_back({"pg_tables", [j]() { return rt::launch<PgTables<C>>(j->stream(), j->a, j->n * 2); }});
     j->stages.push_back({"pg_msm_parts", [j]() { return rt::launch<PgMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
     j->stages.push_back({"pg_finalize", [j]() { return rt::launch<PgFinalize<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"pg_emit", [j]() { return rt::launch<PgEmit<C>>(j->stream(), j->a, j->n); }});

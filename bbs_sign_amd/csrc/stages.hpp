@@ -1240,6 +1240,10 @@ struct PgArgs {
     uint32_t* vscal;          // [PG_NVAR][8][n] canonical scalars of the variable-base parts
     int nvar;                 // PG_NVAR (split form) or PG_NVAR_JOINT
     uint32_t* vtab;           // joint form: [2 lanes][2 tables][G1_TAB][2N][n] window tables of the two joint chains
+    // comb form of the joint layout (g1.hpp g1_comb_sum_to): stage PgTables writes, per item, the tables of the 2^(64 j)
+    // multiples of B and A -- [base 2][piece 4][entry 8][2N][n] -- and comb_ok[base * n + i] = 1; null: not used
+    uint32_t* ctab;
+    int8_t* comb_ok;
     uint32_t* bpart;          // [NFIX][3N][n]
     uint32_t* baff;           // [2][2N][n]  B, A (Montgomery affine)
     uint32_t* partials;       // [PG_NPARTS][3N][n]
@@ -1447,6 +1451,65 @@ struct PgBCombine {
     }
 };
 
+// lane per (base, item), base 0 = B, 1 = A: the sub-bases 2^(64 j) P and their tables of odd multiples, true affine, for the comb
+// (g1.hpp).  Anything unusual -- the identity, a point of small order (they exist only outside the prime-order subgroup), a
+// degenerate step -- leaves comb_ok = 0 and the item's lanes take the joint chains instead: same group elements either way.
+template <class C>
+struct PgTables {
+    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
+    static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
+        using P = typename C::FpP;
+        constexpr int N = P::N;
+        const size_t n = a.n;
+        const int base = (int)(t / n);
+        const size_t i = t - (size_t)base * n;
+        a.comb_ok[(size_t)base * n + i] = 0;
+        if (a.status[i] != ST_PENDING) return;
+        const G1Aff<C> p0 = g1a_load_mont<C>(a.baff + (size_t)base * 2 * N * n, n, i);
+        if (g1a_is_inf<C>(p0)) return;
+        G1Jac<C> q[COMB_PIECES - 1];
+        G1Jac<C> cur = g1j_from_aff<C>(p0);
+#pragma unroll 1
+        for (int j = 0; j < COMB_PIECES - 1; j++) {
+#pragma unroll 1
+            for (int d = 0; d < 64; d++) cur = g1j_dbl<C>(cur);
+            if (g1j_is_inf<C>(cur)) return;
+            q[j] = cur;
+        }
+        G1Aff<C> sub[COMB_PIECES];
+        sub[0] = p0;
+        g1j_batch_to_aff<C, COMB_PIECES - 1>(q, sub + 1);
+        uint32_t* tb = a.ctab + (size_t)base * comb_table_words(N) * n + i;
+        Fp<C> zc[COMB_PIECES];
+        bool ok = true;
+#pragma unroll 1
+        for (int j = 0; j < COMB_PIECES; j++) {
+            TabHbm<C> tab{tb + (size_t)j * G1_TAB * 2 * N * n, n};
+            ok = ok && g1_odd_table<C>(sub[j], tab, zc[j]);
+        }
+        if (!ok) return;
+        // entries (x', y') of table j are the Jacobian points (x', y', zc_j): to true affine with ONE inversion for the four scales
+        Fp<C> pre[COMB_PIECES];
+        Fp<C> acc = fe_one<P>();
+#pragma unroll 1
+        for (int j = 0; j < COMB_PIECES; j++) { pre[j] = acc; acc = fe_mul<P>(acc, zc[j]); }
+        Fp<C> inv = fe_inv<P>(acc);
+#pragma unroll 1
+        for (int j = COMB_PIECES - 1; j >= 0; j--) {
+            const Fp<C> zi = fe_mul<P>(inv, pre[j]);
+            inv = fe_mul<P>(inv, zc[j]);
+            const Fp<C> zi2 = fe_sqr<P>(zi), zi3 = fe_mul<P>(zi2, zi);
+            TabHbm<C> tab{tb + (size_t)j * G1_TAB * 2 * N * n, n};
+#pragma unroll 1
+            for (int e = 0; e < G1_TAB; e++) {
+                const G1Aff<C> v = tab.ld(e);
+                tab.st(e, G1Aff<C>{fe_mul<P>(v.x, zi2), fe_mul<P>(v.y, zi3)});
+            }
+        }
+        a.comb_ok[(size_t)base * n + i] = 1;
+    }
+};
+
 template <class C>
 struct PgMsmPart {
     static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
@@ -1466,6 +1529,27 @@ struct PgMsmPart {
             uint32_t k[8];
             scalar(part, k);
             g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
+        } else if (a.ctab && a.comb_ok[i] && a.comb_ok[n + i]) {
+            // comb form: every multiple of B and A from the tables of their 2^(64 j) multiples, 60 doublings per chain.
+            // part 0: D = v0 B; 1: Abar = v4 A; 2: Bbar = v1 B - v5 A; 3: T1 = v2 B + v6 A; 4: T2's v3 B
+            const uint32_t* tB = a.ctab + i;
+            const uint32_t* tA = a.ctab + comb_table_words(N) * n + i;
+            uint32_t k0[8], k1[8];
+            G1Jac<C> r;
+            if (part == 2 || part == 3) {
+                scalar(part == 2 ? 1 : 2, k0);
+                scalar(part == 2 ? 5 : 6, k1);
+                CombTerm tm[2];
+                comb_recode(k0, false, tB, tm[0]);
+                comb_recode(k1, part == 2, tA, tm[1]);
+                g1_comb_sum_to<C, 2>(tm, n, r);
+            } else {
+                scalar(part == 0 ? 0 : (part == 1 ? 4 : 3), k0);
+                CombTerm tm[1];
+                comb_recode(k0, false, part == 1 ? tA : tB, tm[0]);
+                g1_comb_sum_to<C, 1>(tm, n, r);
+            }
+            g1j_store<C>(out, n, i, r);
         } else if (part == 2 || part == 3) {
             // joint form: Bbar = v1 B + v5 (-A) (part 2), T1 = v2 B + v6 A (part 3) -- one doubling chain each
             const G1Aff<C> B = g1a_load_mont<C>(a.baff, n, i);

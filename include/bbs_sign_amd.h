@@ -123,7 +123,11 @@ int bbs_ctx_set_window_bits(bbs_ctx* ctx, int bits);
 /* Subgroup vouching (off by default).  The reference's point types (ark-ec `Affine`, built by `deserialize_compressed`
  * or `Affine::new`, src/proof_gen.rs:29, src/sign.rs:18) can only hold members of the prime-order subgroup; this ABI
  * takes raw coordinates and by default computes exactly what the reference's double-and-add would for ANY on-curve
- * point.  vouched = 1 promises that every G1 point later handed to core_verify / core_proof_verify / core_proof_gen (and the generators given to
+ * point -- with ONE exception, core_proof_gen: Abar e and Abar e~ (src/proof_gen.rs:255-258) are computed as the multiples
+ * (r1 r2 e mod r) A and (r1 r2 e~ mod r) A of the signature's own point, which is the reference's value for every A in the
+ * prime-order subgroup (all that the reference's types can hold) and for the identity; for an on-curve A OUTSIDE the
+ * subgroup -- a signature that cannot verify -- the proof's Bbar, T1 and what follows from them differ from the
+ * reference's (tests: check_proof_gen_unusual_points pins what is computed instead).  vouched = 1 promises that every G1 point later handed to core_verify / core_proof_verify / core_proof_gen (and the generators given to
  * bbs_ctx_set_generators) through this context is in the subgroup (true for everything that came out of bbs_*_from_octets*, which check it): on BLS12-381
  * the variable-base multiplications of those paths then use the GLV endomorphism split (half the doublings).  Results
  * are identical for such inputs; for on-curve points outside the subgroup they are unspecified.  BN254 has cofactor 1

@@ -2107,3 +2107,64 @@ def check_issuer_budget(curve, lib_path=None, seed=171):
     w5 = bbs.sign(suite, sk + 2, m5, b"")
     assert o5[0] == api.signature_to_octets(curve, Signature(w5.a, w5.e), lib_path) and o5[1] == b""
     iss.close()
+
+
+def check_proof_gen_unusual_points(curve, lib_path=None, seed=181, L=5):
+    """core_proof_gen (src/proof_gen.rs:116-208) with signature points A that the fast paths of the variable-base parts must
+    hand to their fallbacks -- the identity, an on-curve point of order 3 (outside the prime-order subgroup; BLS12-381) --
+    beside ordinary items in the SAME batch (a wavefront then runs the comb over 64-bit pieces, the joint chains and the
+    separate multiplications side by side), and scalars whose 64-bit pieces are 0, 1 and all ones.
+    Every proof of an item whose A is in the prime-order subgroup (or the identity) equals the oracle's, which multiplies by
+    plain double-and-add in the reference's operation order.  For A OUTSIDE the subgroup the engine's documented
+    restructuring -- Abar e and Abar e~ as (r1 r2 e mod r) A and (r1 r2 e~ mod r) A -- is not the reference's
+    integer product (the point's order does not divide r); the reference's typed interface cannot hold such a point
+    (ark-serialize checks subgroup membership), and the case pins what the engine computes instead: the same formulas
+    evaluated with the oracle's group law, identical in all three layouts of the job."""
+    rng = random.Random(seed)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    api_id = suite.api_id
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    pk = bbs.sk_to_pk(suite, sk)
+    eng = make_engine(curve, gens, api_id, lib_path, sk=sk)
+    n = 7
+    msgs = [[rng.randrange(c.r) for _ in range(L)] for _ in range(n)]
+    headers = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 6]))) for _ in range(n)]
+    phs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 3]))) for _ in range(n)]
+    disclosed = [sorted(rng.sample(range(L), rng.randrange(0, L + 1))) for _ in range(n)]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs, headers)
+    assert list(st) == [1] * n
+    sigs = list(sigs)
+    sigs[1] = Signature(None, sigs[1].e)                               # A = identity
+    outside = []
+    if curve == "bls12_381":
+        assert c.g1_is_on_curve((0, 2)) and c.g1_mul((0, 2), 3) is None
+        sigs[4] = Signature((0, 2), sigs[4].e)                         # A of order 3
+        outside = [4]
+    sigs[5] = Signature(c.g1_neg(sigs[5].a), 1)                        # e = 1, another ordinary point
+    # scalars with zero and all-ones 64-bit pieces (the comb's recoding of every piece)
+    rnds[2][0] = (1 << 64)                                             # r1 = 2^64: pieces (0, 1, 0, 0)
+    rnds[2][1] = (1 << 192) + 1
+    rnds[3][2] = ((1 << 64) - 1) << 64                                 # e~ with an all-ones piece
+    rnds[6][3] = c.r - 1
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds, headers, phs)
+    assert list(st) == [1] * n, list(st)
+    for i in range(n):
+        if i in outside:
+            continue
+        want = bbs.core_proof_gen(suite, pk, bbs.Signature(sigs[i].a, sigs[i].e), headers[i], gens, phs[i], msgs[i], disclosed[i], api_id, rnds[i])
+        assert proof_eq(proofs[i], want), (curve, i)
+    for i in outside:
+        # the three points that do not depend on the challenge, by the engine's formulas with the oracle's group law
+        r1, r2 = rnds[i][0], rnds[i][1]
+        domain = bbs.calculate_domain(suite, pk, gens[0], gens[1:], headers[i], api_id)
+        B = c.g1_add(suite.p1, c.g1_mul(gens[0], domain))
+        for g, m in zip(gens[1:], msgs[i]):
+            B = c.g1_add(B, c.g1_mul(g, m))
+        A, e = sigs[i].a, sigs[i].e
+        k = r1 * r2 % c.r
+        assert proofs[i].d == c.g1_mul(B, r2) and proofs[i].a_bar == c.g1_mul(A, k)
+        assert proofs[i].b_bar == c.g1_add(c.g1_mul(B, k), c.g1_neg(c.g1_mul(A, k * e % c.r)))
+    eng.close()

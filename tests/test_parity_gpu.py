@@ -318,3 +318,14 @@ def test_dedicated_queues_under_the_runtimes_default_pool():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["checks"]["statuses_exact_every_step"] is True and line["config"]["dedicated_queues"] == 12 and line["config"]["hw_queues"] == 4
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_gen_unusual_points(curve):
+    pc.check_proof_gen_unusual_points(curve, None)
+
+
+@pytest.mark.job_form(True)
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_gen_unusual_points_latency_form(curve):
+    pc.check_proof_gen_unusual_points(curve, None)

@@ -150,3 +150,14 @@ def test_issuer_threads(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_issuer_budget(twin, curve):
     pc.check_issuer_budget(curve, twin)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_gen_unusual_points(twin, curve):
+    pc.check_proof_gen_unusual_points(curve, twin)
+
+
+@pytest.mark.job_form(True)
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_proof_gen_unusual_points_latency_form(twin, curve):
+    pc.check_proof_gen_unusual_points(curve, twin)
