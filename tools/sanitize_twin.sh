@@ -45,6 +45,7 @@ for curve in ("bls12_381", "bn254"):
     pc.check_fixed_base_tree(curve, lib, n_pv=6)
     pc.check_issuer_mixed_lengths(curve, lib)
     pc.check_issuer_budget(curve, lib)
+    pc.check_proof_gen_unusual_points(curve, lib)
     pc.check_issuer_threads(curve, lib, threads=3, rounds=2)
     pc.check_big_batch(curve, lib, n=66, L=4, R=2, window_bits=4)
     print(curve, "ok", flush=True)
