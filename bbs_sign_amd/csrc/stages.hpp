@@ -1467,15 +1467,20 @@ struct PgTables {
         if (a.status[i] != ST_PENDING) return;
         const G1Aff<C> p0 = g1a_load_mont<C>(a.baff + (size_t)base * 2 * N * n, n, i);
         if (g1a_is_inf<C>(p0)) return;
+        // sub-bases: 2^(64 j) P for j < 4 -- or, under the GLV split (points known to be in the subgroup), P and 2^64 P only:
+        // the other two are their images under the endomorphism
+        const bool glv = C::K::HAS_GLV && a.glv != 0;
+        const int n_sub = glv ? 2 : COMB_PIECES;
         G1Jac<C> q[COMB_PIECES - 1];
         G1Jac<C> cur = g1j_from_aff<C>(p0);
 #pragma unroll 1
-        for (int j = 0; j < COMB_PIECES - 1; j++) {
+        for (int j = 0; j < n_sub - 1; j++) {
 #pragma unroll 1
             for (int d = 0; d < 64; d++) cur = g1j_dbl<C>(cur);
             if (g1j_is_inf<C>(cur)) return;
             q[j] = cur;
         }
+        for (int j = n_sub - 1; j < COMB_PIECES - 1; j++) q[j] = g1j_inf<C>();
         G1Aff<C> sub[COMB_PIECES];
         sub[0] = p0;
         g1j_batch_to_aff<C, COMB_PIECES - 1>(q, sub + 1);
@@ -1483,19 +1488,19 @@ struct PgTables {
         Fp<C> zc[COMB_PIECES];
         bool ok = true;
 #pragma unroll 1
-        for (int j = 0; j < COMB_PIECES; j++) {
+        for (int j = 0; j < n_sub; j++) {
             TabHbm<C> tab{tb + (size_t)j * G1_TAB * 2 * N * n, n};
             ok = ok && g1_odd_table<C>(sub[j], tab, zc[j]);
         }
         if (!ok) return;
-        // entries (x', y') of table j are the Jacobian points (x', y', zc_j): to true affine with ONE inversion for the four scales
+        // entries (x', y') of table j are the Jacobian points (x', y', zc_j): to true affine with ONE inversion for the scales
         Fp<C> pre[COMB_PIECES];
         Fp<C> acc = fe_one<P>();
 #pragma unroll 1
-        for (int j = 0; j < COMB_PIECES; j++) { pre[j] = acc; acc = fe_mul<P>(acc, zc[j]); }
+        for (int j = 0; j < n_sub; j++) { pre[j] = acc; acc = fe_mul<P>(acc, zc[j]); }
         Fp<C> inv = fe_inv<P>(acc);
 #pragma unroll 1
-        for (int j = COMB_PIECES - 1; j >= 0; j--) {
+        for (int j = n_sub - 1; j >= 0; j--) {
             const Fp<C> zi = fe_mul<P>(inv, pre[j]);
             inv = fe_mul<P>(inv, zc[j]);
             const Fp<C> zi2 = fe_sqr<P>(zi), zi3 = fe_mul<P>(zi2, zi);
@@ -1504,6 +1509,20 @@ struct PgTables {
             for (int e = 0; e < G1_TAB; e++) {
                 const G1Aff<C> v = tab.ld(e);
                 tab.st(e, G1Aff<C>{fe_mul<P>(v.x, zi2), fe_mul<P>(v.y, zi3)});
+            }
+        }
+        if constexpr (C::K::HAS_GLV) {
+            if (glv) {                               // tables 2, 3 = phi of tables 0, 1: (beta x, y)
+                const Fp<C> beta = glv_beta<C>();
+#pragma unroll 1
+                for (int j = 0; j < 2; j++) {
+                    TabHbm<C> src{tb + (size_t)j * G1_TAB * 2 * N * n, n}, dst{tb + (size_t)(2 + j) * G1_TAB * 2 * N * n, n};
+#pragma unroll 1
+                    for (int e = 0; e < G1_TAB; e++) {
+                        const G1Aff<C> v = src.ld(e);
+                        dst.st(e, G1Aff<C>{fe_mul<P>(v.x, beta), v.y});
+                    }
+                }
             }
         }
         a.comb_ok[(size_t)base * n + i] = 1;
@@ -1540,13 +1559,20 @@ struct PgMsmPart {
                 scalar(part == 2 ? 1 : 2, k0);
                 scalar(part == 2 ? 5 : 6, k1);
                 CombTerm tm[2];
-                comb_recode(k0, false, tB, tm[0]);
-                comb_recode(k1, part == 2, tA, tm[1]);
+                bool done = false;
+                if constexpr (C::K::HAS_GLV) {
+                    if (a.glv) { comb_recode_glv<C>(k0, false, tB, tm[0]); comb_recode_glv<C>(k1, part == 2, tA, tm[1]); done = true; }
+                }
+                if (!done) { comb_recode(k0, false, tB, tm[0]); comb_recode(k1, part == 2, tA, tm[1]); }
                 g1_comb_sum_to<C, 2>(tm, n, r);
             } else {
                 scalar(part == 0 ? 0 : (part == 1 ? 4 : 3), k0);
                 CombTerm tm[1];
-                comb_recode(k0, false, part == 1 ? tA : tB, tm[0]);
+                bool done = false;
+                if constexpr (C::K::HAS_GLV) {
+                    if (a.glv) { comb_recode_glv<C>(k0, false, part == 1 ? tA : tB, tm[0]); done = true; }
+                }
+                if (!done) comb_recode(k0, false, part == 1 ? tA : tB, tm[0]);
                 g1_comb_sum_to<C, 1>(tm, n, r);
             }
             g1j_store<C>(out, n, i, r);

@@ -10,9 +10,13 @@ from bbs_sign_amd import Job
 
 ks = [int(x) for x in sys.argv[1:]] or [8, 12, 16]
 n = 4096
-suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload("bls12_381", n, 32, 8, None, 16)
+curve = os.environ.get("CURVE", "bls12_381")
+suite, eng, gens, sk, msgs, disclosed, rnds = pc.bench_workload(curve, n, 32, 8, None, 16)
+if os.environ.get("VOUCH"):
+    eng.set_points_in_subgroup(True)          # BLS12-381: the GLV split (BN254 has it always)
+print("curve", curve, "vouched", bool(os.environ.get("VOUCH")), "BBS_PG_COMB", os.environ.get("BBS_PG_COMB", "1"), flush=True)
 sigs, st = eng.core_sign_batch(msgs)
-for form, name in ((True, "split (7 chains)"), (False, "joint (5 chains)")):
+for form, name in ((False, "throughput form"),):
     eng.set_latency_mode(form)
     for k in ks:
         js = [eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds) for _ in range(k)]
