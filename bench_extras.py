@@ -246,9 +246,8 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     # proof_gen with the records delivered at wait
     def host_loop(submit, check, steps=48, depth=8):
         pend = []
-        def retire():
-            j = pend.pop(0)
-            j.wait()
+        def retire():                                  # completion order (bbs_jobs_wait_any), as bench.submit_loop
+            j = pend.pop(Job.wait_any(pend))
             check(j)
             j.free()
         for _ in range(4 * depth):                     # warm: pools (page-locked and device buffers, streams) reach their size
@@ -304,7 +303,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     def pg_submit():
         k = turn[0] % 9; turn[0] += 1
         return packed_submit(eng.lib.bbs_core_proof_gen_submit, "bbs_core_proof_gen_submit", *pgargs, u8(pf_out[k]), u8(cm_out[k]), u64(cmo_out[k]))
-    bls["proof_gen_host_inclusive"] = host_loop(pg_submit, all_true)
+    bls["proof_gen_host_inclusive"] = host_loop(pg_submit, all_true, steps=72, depth=12)       # (the comb's table stage: a proof_gen job is longer, 12 in flight fill the chip)
     assert all(int(c_[n]) == n * (L - R) for c_ in cmo_out[:8])
     # ... and to the wire: signature / proof octet strings compressed on the device
     so_out = [np.zeros(n * (eng.fpb + 32), dtype=np.uint8) for _ in range(9)]
@@ -320,7 +319,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     def pg_oct_submit():
         k = turn[0] % 9; turn[0] += 1
         return packed_submit(eng.lib.bbs_proof_gen_octets_submit, "bbs_proof_gen_octets_submit", *pgargs, u8(po_out[k]), u64(poo_out[k]))
-    bls["proof_gen_to_octets_host_inclusive"] = host_loop(pg_oct_submit, all_true)
+    bls["proof_gen_to_octets_host_inclusive"] = host_loop(pg_oct_submit, all_true, steps=72, depth=12)       # (the comb's table stage: a proof_gen job is longer, 12 in flight fill the chip)
     assert all(int(o_[n]) == n * po_len for o_ in poo_out[:8])
 
     # ---- the PUBLIC functions in one call each: raw 32-byte messages in (32 per item, hashed on the device), octet strings
@@ -344,7 +343,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         k = turn[0] % 9; turn[0] += 1
         return packed_submit(eng.lib.bbs_proof_gen_wire_submit, "bbs_proof_gen_wire_submit", u8(ob_s), u8(mb_w), u64(mbo_w), u64(mio_w),
                              u64(di_w), u64(dio_w), u8(rs_w), u64(ro_w), u8(hb_v), u64(ho_v), u8(pb_w), u64(po_w), u8(po_out[k]), u64(poo_out[k]))
-    bls["proof_gen_wire_raw_messages_host_inclusive"] = host_loop(pg_wire_submit, all_true)
+    bls["proof_gen_wire_raw_messages_host_inclusive"] = host_loop(pg_wire_submit, all_true, steps=72, depth=12)       # (the comb's table stage: a proof_gen job is longer, 12 in flight fill the chip)
     assert bytes(po_out[0][:po_len]) == octs[0]
 
     # ---- BN254 (16-bit windows) and the per-GPU share of BASELINE configs[4]
