@@ -246,8 +246,13 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     # proof_gen with the records delivered at wait
     def host_loop(submit, check, steps=48, depth=8):
         pend = []
-        def retire():                                  # completion order (bbs_jobs_wait_any), as bench.submit_loop
-            j = pend.pop(Job.wait_any(pend))
+        any_order = depth > 8                          # the deeper loops retire in completion order (bbs_jobs_wait_any), as bench.submit_loop
+        def retire():
+            if any_order:
+                j = pend.pop(Job.wait_any(pend))
+            else:
+                j = pend.pop(0)
+                j.wait()
             check(j)
             j.free()
         for _ in range(4 * depth):                     # warm: pools (page-locked and device buffers, streams) reach their size
