@@ -104,6 +104,7 @@ SIGNATURES = {
     "bbs_core_proof_gen_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p,
                                       c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_u64p, c_i8p]),
     "bbs_runtime_set_dedicated_queues": (ci, [ci]),
+    "bbs_runtime_queue_budget": (ci, [ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(sz)]),
     "bbs_device_free_bytes": (sz, [ci]),
     "bbs_ctx_table_bytes": (sz, [vp]),
     "bbs_issuer_set_budget": (ci, [vp, sz, sz]),

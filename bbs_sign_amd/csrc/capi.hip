@@ -19,10 +19,23 @@ extern "C" __attribute__((visibility("default"))) int bbs_runtime_hw_queues(void
 // Job streams with hardware queues of their own (runtime.hpp stream_create): k = 0 off, k > 0 at most k per device (at most
 // 16); takes effect for streams created afterwards (streams are pooled: call it before the first context is created).
 extern "C" __attribute__((visibility("default"))) int bbs_runtime_set_dedicated_queues(int k) {
-    if (k < 0 || k > 16) return BBS_E_ARG;      // beyond ~20 hardware queues in all the runtime runs out of scratch and aborts the process
+    if (k < 0 || k > 16) return BBS_E_ARG;
 #ifndef BBS_HOST_TWIN
-    rt::dedicated_queues().store(k);
+    rt::dedicated_queues().store(k);      // a wish: runtime.hpp stream_create grants min(k, what the scratch budget leaves beside the pool)
 #endif
+    return BBS_OK;
+}
+// The hardware-queue budget of a device (runtime.hpp): scratch bytes per lane of the library's largest kernel frame, the
+// number of hardware queues (pooled + dedicated) that frame allows, the runtime's pool as the environment has it, and the
+// dedicated queues that fit beside the pool.  Any pointer may be null.
+extern "C" __attribute__((visibility("default"))) int bbs_runtime_queue_budget(int device_id, int* total, int* pool, int* dedicated_cap, size_t* scratch_bytes_per_lane) {
+    if (device_id < 0 || device_id >= rt::device_count()) return BBS_E_NO_DEVICE;
+    if (rt::set_device(device_id)) return BBS_E_HIP;
+    const rt::QueueBudget b = rt::queue_budget(device_id);
+    if (total) *total = b.total;
+    if (pool) *pool = b.pool;
+    if (dedicated_cap) *dedicated_cap = b.dedicated_cap;
+    if (scratch_bytes_per_lane) *scratch_bytes_per_lane = b.scratch;
     return BBS_OK;
 }
 
@@ -419,7 +432,7 @@ int bbs_job_run_timed(bbs_job* job, int reps, float* total_ms, float* kernel_ms,
     rt::EventList ev((size_t)reps * per_rep);
     if (rt::sync(job->stream())) return BBS_E_HIP;
     for (int r = 0; r < reps; r++) if (job->run_recorded(&ev)) return BBS_E_HIP;
-    if (ev.finish(job->stream()) || rt::sync(job->stream_aux())) return BBS_E_HIP;
+    if (ev.finish(job->stream()) || job->sync_aux()) return BBS_E_HIP;
     // the last stage of a rep is on the main stream: total = first event .. last stop
     if (total_ms) *total_ms = ev.ms(0, (size_t)reps * per_rep - 1);
     if (kernel_ms) {
@@ -449,7 +462,7 @@ int bbs_jobs_run_timed(bbs_job** jobs, int njobs, int steps, float* total_ms, fl
     for (int k = 0; k < steps; k++) if (jobs[k % njobs]->run_recorded(&ev)) return BBS_E_HIP;
     for (int j = 0; j < njobs; j++) {
         if (rt::sync(jobs[j]->stream())) return BBS_E_HIP;
-        if (rt::sync(jobs[j]->stream_aux())) return BBS_E_HIP;
+        if (jobs[j]->sync_aux()) return BBS_E_HIP;
     }
     if (total_ms) {
         // the steps end in different orders on different streams: take the latest last-stage stop
@@ -480,6 +493,31 @@ int bbs_job_stage_times(bbs_job* job, float* total_ms, float* kernel_ms, int cap
 
 // upload (one asynchronous H2D copy + the ingest kernel) -> kernels -> asynchronous copy of the statuses to page-locked
 // memory; nothing waits for the device.  bbs_job_wait delivers the statuses to `status`.
+// The ONE submit epilogue of every *_submit entry point: run the stages, enqueue the copy of the statuses (sign / proof_gen:
+// and of the produced records) to page-locked memory behind them, arm the completion notification behind that, and only
+// then let the job know where bbs_job_wait has to deliver.  On any failure the job is freed and nothing is handed out.
+// (bbs_job_wait refuses with BBS_E_STATE if an item was left undecided: fail closed, tested for every entry point.)
+static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out) {
+    job->hold_arm = true;
+    int rc = job->run();
+    job->hold_arm = false;
+    if (!rc) rc = job->enqueue_status_fetch();
+    if (!rc && (o1 || o2 || o3)) rc = job->enqueue_result_fetch();
+    if (!rc) rc = job->arm_completion();
+    if (rc) { delete job; return rc; }
+    job->deliver_to = status;
+    job->results_wanted = o1 || o2 || o3;
+    job->set_result_targets(o1, o2, o3);
+    *job_out = job;
+    return BBS_OK;
+}
+// the *_batch forms: submit, wait, free
+static int wait_and_free(int rc_submit, bbs_job* const& job) {      // by reference: read after the submit call has set it
+    if (rc_submit) return rc_submit;
+    const int rc = job->wait();
+    delete job;
+    return rc;
+}
 int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
                                  const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                  const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status,
@@ -488,25 +526,13 @@ int bbs_core_proof_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* pf, cons
     bbs_job* job = nullptr;
     int rc = bbs_core_proof_verify_upload(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, &job);
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 int bbs_core_proof_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* pf, const uint8_t* cm, const uint64_t* cmo,
                                 const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_core_proof_verify_submit(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_core_proof_verify_submit(ctx, n, pf, cm, cmo, dm, dmo, di, dio, h, ho, ph, pho, status, &job), job);
 }
 // proof_verify from proof OCTET strings: decoding (square roots, subgroup checks) on the device, then the same pipeline
 int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
@@ -518,15 +544,7 @@ int bbs_proof_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, c
     int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr),
                       pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, dm, dmo, di, dio, h, ho, ph, pho, &job, oct, oct_off, nullptr, nullptr));
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 // the public proof_verify of the reference for a fixed number of messages, in one call: proof octets AND the disclosed
 // messages as raw bytes (msg_to_scalars on the device in front of the ingest stage)
@@ -545,36 +563,20 @@ int bbs_proof_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* oct, con
     int rc = DISPATCH(ctx, pv_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off),
                       pv_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, nullptr, nullptr, msg_item_off, di, dio, h, ho, ph, pho, &job, oct, oct_off, msg_bytes, msg_byte_off));
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 int bbs_proof_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
                                 const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
                                 const uint64_t* di, const uint64_t* dio,
                                 const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_proof_verify_wire_submit(ctx, n, oct, oct_off, msg_bytes, msg_byte_off, msg_item_off, di, dio, h, ho, ph, pho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_proof_verify_wire_submit(ctx, n, oct, oct_off, msg_bytes, msg_byte_off, msg_item_off, di, dio, h, ho, ph, pho, status, &job), job);
 }
 int bbs_proof_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* oct, const uint64_t* oct_off,
                                   const uint8_t* dm, const uint64_t* dmo, const uint64_t* di, const uint64_t* dio,
                                   const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_proof_verify_octets_submit(ctx, n, oct, oct_off, dm, dmo, di, dio, h, ho, ph, pho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_proof_verify_octets_submit(ctx, n, oct, oct_off, dm, dmo, di, dio, h, ho, ph, pho, status, &job), job);
 }
 int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                            const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
@@ -582,15 +584,7 @@ int bbs_core_verify_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const ui
     bbs_job* job = nullptr;
     int rc = bbs_core_verify_upload(ctx, n, sigs, m, mo, h, ho, &job);
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 // verify from the wire: signature octet strings (compress(A) || e) decoded and checked on the device in front of
 // core_verify; statuses as bbs_signature_from_octets followed by core_verify would give them
@@ -601,29 +595,16 @@ int bbs_verify_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, 
     int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr),
                       vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, m, mo, h, ho, &job, sig_octets, nullptr, nullptr));
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 int bbs_verify_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* m, const uint64_t* mo,
                             const uint8_t* h, const uint64_t* ho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_verify_octets_submit(ctx, n, sig_octets, m, mo, h, ho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_verify_octets_submit(ctx, n, sig_octets, m, mo, h, ho, status, &job), job);
 }
 // the reference's PUBLIC verify / sign for a context's number of messages, in one call: raw messages in (msg_to_scalars on
 // the device), signatures as octet strings in (verify) / out (sign)
 static const uint64_t BBS_ZERO_OFF[1] = {0};
-static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out);
 int bbs_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
                            const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status, bbs_job** job_out) {
     if (!ctx || !status || !job_out || (n && (!sig_octets || !msg_item_off))) return BBS_E_ARG;
@@ -635,24 +616,12 @@ int bbs_verify_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, co
     int rc = DISPATCH(ctx, vf_upload<BlsCurve>(AS_BLS(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off),
                       vf_upload<BnCurve>(AS_BN(ctx), n, nullptr, nullptr, msg_item_off, h, ho, &job, sig_octets, msg_bytes, msg_byte_off));
     if (rc) return rc;
-    job->hold_arm = true;
-    rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    *job_out = job;
-    return BBS_OK;
+    return submit_with_results(job, status, nullptr, nullptr, nullptr, job_out);
 }
 int bbs_verify_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
                           const uint64_t* msg_item_off, const uint8_t* h, const uint64_t* ho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_verify_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, h, ho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_verify_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, h, ho, status, &job), job);
 }
 int bbs_sign_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
                          const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status, bbs_job** job_out) {
@@ -671,36 +640,12 @@ int bbs_sign_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const
 int bbs_sign_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* msg_bytes, const uint64_t* msg_byte_off, const uint64_t* msg_item_off,
                         const uint8_t* h, const uint64_t* ho, uint8_t* sig_octets_out, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_sign_wire_submit(ctx, n, msg_bytes, msg_byte_off, msg_item_off, h, ho, sig_octets_out, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_sign_wire_submit(ctx, n, msg_bytes, msg_byte_off, msg_item_off, h, ho, sig_octets_out, status, &job), job);
 }
 int bbs_core_verify_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                           const uint8_t* h, const uint64_t* ho, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_core_verify_submit(ctx, n, sigs, m, mo, h, ho, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
-}
-// sign / proof_gen in the submit form: the records follow the statuses to page-locked memory behind the last stage and
-// bbs_job_wait unpacks them into the caller's buffers (which must stay valid until then)
-static int submit_with_results(bbs_job* job, int8_t* status, uint8_t* o1, uint8_t* o2, uint64_t* o3, bbs_job** job_out) {
-    job->hold_arm = true;
-    int rc = job->run();
-    job->hold_arm = false;
-    if (!rc) rc = job->enqueue_status_fetch();
-    if (!rc && (o1 || o2 || o3)) rc = job->enqueue_result_fetch();
-    if (!rc) rc = job->arm_completion();
-    if (rc) { delete job; return rc; }
-    job->deliver_to = status;
-    job->results_wanted = o1 || o2 || o3;
-    job->set_result_targets(o1, o2, o3);
-    *job_out = job;
-    return BBS_OK;
+    return wait_and_free(bbs_core_verify_submit(ctx, n, sigs, m, mo, h, ho, status, &job), job);
 }
 int bbs_core_sign_submit(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
                          uint8_t* sigs_out, int8_t* status, bbs_job** job_out) {
@@ -733,11 +678,7 @@ int bbs_sign_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint6
 int bbs_sign_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
                           uint8_t* sig_octets_out, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_sign_octets_submit(ctx, n, m, mo, h, ho, sig_octets_out, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_sign_octets_submit(ctx, n, m, mo, h, ho, sig_octets_out, status, &job), job);
 }
 int bbs_proof_gen_octets_submit(bbs_ctx* ctx, size_t n, const uint8_t* sigs, const uint8_t* m, const uint64_t* mo,
                                 const uint64_t* di, const uint64_t* dio, const uint8_t* rnd, const uint64_t* rno,
@@ -755,11 +696,7 @@ int bbs_proof_gen_octets_batch(bbs_ctx* ctx, size_t n, const uint8_t* sigs, cons
                                const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
                                uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_proof_gen_octets_submit(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, octets_out, oct_off_out, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_proof_gen_octets_submit(ctx, n, sigs, m, mo, di, dio, rnd, rno, h, ho, ph, pho, octets_out, oct_off_out, status, &job), job);
 }
 // the reference's PUBLIC proof_gen (src/proof_gen.rs:78-113) in one call: signature octets and raw messages in, proof octets out
 int bbs_proof_gen_wire_submit(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, const uint8_t* msg_bytes, const uint64_t* msg_byte_off,
@@ -783,12 +720,8 @@ int bbs_proof_gen_wire_batch(bbs_ctx* ctx, size_t n, const uint8_t* sig_octets, 
                              const uint8_t* h, const uint64_t* ho, const uint8_t* ph, const uint64_t* pho,
                              uint8_t* octets_out, uint64_t* oct_off_out, int8_t* status) {
     bbs_job* job = nullptr;
-    int rc = bbs_proof_gen_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho,
-                                       octets_out, oct_off_out, status, &job);
-    if (rc) return rc;
-    rc = job->wait();
-    delete job;
-    return rc;
+    return wait_and_free(bbs_proof_gen_wire_submit(ctx, n, sig_octets, msg_bytes, msg_byte_off, msg_item_off, di, dio, rnd, rno, h, ho, ph, pho,
+                                       octets_out, oct_off_out, status, &job), job);
 }
 int bbs_core_sign_batch(bbs_ctx* ctx, size_t n, const uint8_t* m, const uint64_t* mo, const uint8_t* h, const uint64_t* ho,
                         uint8_t* sigs_out, int8_t* status) {
@@ -1095,27 +1028,31 @@ void bbs_issuer_destroy(bbs_issuer* is) { delete is; }
 int bbs_issuer_set_public_key(bbs_issuer* is, const uint8_t* pk_affine, int is_identity) {
     if (!is || (!is_identity && !pk_affine)) return BBS_E_ARG;
     if (int rc = is->curve == BBS_CURVE_BLS12_381 ? pk_validate<BlsCurve>(pk_affine, is_identity) : pk_validate<BnCurve>(pk_affine, is_identity)) return rc;
-    std::lock_guard<std::mutex> g(is->mu);
-    if (is->configuration_locked()) return BBS_E_STATE;       // a routed list is in flight: its jobs read the contexts' keys
-    const size_t fpb = bbs_fp_bytes(is->curve);
-    is->pk.assign(4 * fpb, 0);
-    if (!is_identity) std::memcpy(is->pk.data(), pk_affine, 4 * fpb);
-    is->pk_inf = is_identity ? 1 : 0;
-    is->pk_set = true; is->sk_set = false;
-    volatile uint8_t* s = is->sk;
-    for (int k = 0; k < 32; k++) s[k] = 0;
-    is->epoch++;
-    return BBS_OK;
+    {
+        std::lock_guard<std::mutex> g(is->mu);
+        if (is->configuration_locked()) return BBS_E_STATE;   // a routed list is in flight: its jobs read the contexts' keys
+        const size_t fpb = bbs_fp_bytes(is->curve);
+        is->pk.assign(4 * fpb, 0);
+        if (!is_identity) std::memcpy(is->pk.data(), pk_affine, 4 * fpb);
+        is->pk_inf = is_identity ? 1 : 0;
+        is->pk_set = true; is->sk_set = false;
+        volatile uint8_t* s = is->sk;
+        for (int k = 0; k < 32; k++) s[k] = 0;
+        is->epoch++;
+    }
+    return issuer_refresh_handed_out(is);                     // contexts the caller drives directly get the key now
 }
 int bbs_issuer_set_secret_key(bbs_issuer* is, const uint8_t* sk32) {
     if (!is || !sk32) return BBS_E_ARG;
     if (!(is->curve == BBS_CURVE_BLS12_381 ? sk_in_range<BlsCurve>(sk32) : sk_in_range<BnCurve>(sk32))) return BBS_E_ARG;
-    std::lock_guard<std::mutex> g(is->mu);
-    if (is->configuration_locked()) return BBS_E_STATE;
-    std::memcpy(is->sk, sk32, 32);
-    is->sk_set = true; is->pk_set = true;
-    is->epoch++;
-    return BBS_OK;
+    {
+        std::lock_guard<std::mutex> g(is->mu);
+        if (is->configuration_locked()) return BBS_E_STATE;
+        std::memcpy(is->sk, sk32, 32);
+        is->sk_set = true; is->pk_set = true;
+        is->epoch++;
+    }
+    return issuer_refresh_handed_out(is);
 }
 int bbs_issuer_set_limits(bbs_issuer* is, size_t max_messages, int window_bits) {
     if (!is || (window_bits != 0 && (window_bits < 4 || window_bits > 22))) return BBS_E_ARG;
@@ -1135,11 +1072,13 @@ int bbs_issuer_set_budget(bbs_issuer* is, size_t max_contexts, size_t max_table_
 }
 int bbs_issuer_set_modes(bbs_issuer* is, int latency_mode, int batch_verification, int points_in_subgroup) {
     if (!is || latency_mode < 0 || latency_mode > 2) return BBS_E_ARG;
-    std::lock_guard<std::mutex> g(is->mu);
-    if (is->configuration_locked()) return BBS_E_STATE;
-    is->latency_mode = latency_mode; is->batch_verify = batch_verification != 0; is->in_subgroup = points_in_subgroup != 0;
-    is->epoch++;
-    return BBS_OK;
+    {
+        std::lock_guard<std::mutex> g(is->mu);
+        if (is->configuration_locked()) return BBS_E_STATE;
+        is->latency_mode = latency_mode; is->batch_verify = batch_verification != 0; is->in_subgroup = points_in_subgroup != 0;
+        is->epoch++;
+    }
+    return issuer_refresh_handed_out(is);
 }
 int bbs_issuer_context(bbs_issuer* is, size_t message_count, bbs_ctx** out) {
     if (!is || !out) return BBS_E_ARG;

@@ -6,6 +6,7 @@
 // /root/reference/src/sign.rs:120-130, verify.rs:81-86, proof_gen.rs:249-263,
 // proof_verify.rs:163-182.
 #pragma once
+#include <type_traits>
 #include "tower.hpp"
 
 namespace bbs {
@@ -312,8 +313,10 @@ BBS_HD G1Aff<C> g1_tab_digit(const T& tab, uint32_t U, bool flip = false) {     
 // (the table lives where the caller says: AtPriv = the lane's private memory, AtHbm = a caller-provided buffer)
 // (result through `out`, the running point a plain local: as a named return value it is the caller's memory and every
 // doubling of the loop then starts with a scratch round trip -- DESIGN.md 5 rule 7b)
+// (_inl: the body, for a kernel that is nothing but this multiplication -- stage PvVarMul -- where a call would only add the
+// callee's frame and its saved registers to the kernel's scratch; everyone else calls the non-inlined wrapper below)
 template <class C, class W>
-BBS_HD_NOINLINE void g1_mul_aff_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
+BBS_HD void g1_mul_aff_tab_inl(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
 #ifdef BBS_G1_MUL_NAF
     out = g1_mul_aff_naf<C>(p, k);
     return;
@@ -345,6 +348,8 @@ BBS_HD_NOINLINE void g1_mul_aff_tab_to(const G1Aff<C>& p, const uint32_t* k, con
     r.z = fe_mul<FP>(r.z, zc);
     out = r;
 }
+template <class C, class W>
+BBS_HD_NOINLINE void g1_mul_aff_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) { g1_mul_aff_tab_inl<C, W>(p, k, where, out); }
 template <class C, class W>
 BBS_HD G1Jac<C> g1_mul_aff_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
     G1Jac<C> r;
@@ -548,7 +553,7 @@ BBS_HD Fp<C> glv_beta() {
 
 // k * P for P in the prime-order subgroup: two 128-bit halves on one doubling chain (see above)
 template <class C, class W>
-BBS_HD_NOINLINE void g1_mul_aff_glv_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
+BBS_HD void g1_mul_aff_glv_tab_inl(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) {
     typename W::Tab tab;
     where.init(tab);
     Fp<C> zc;
@@ -587,6 +592,8 @@ BBS_HD_NOINLINE void g1_mul_aff_glv_tab_to(const G1Aff<C>& p, const uint32_t* k,
     out = r;
 }
 template <class C, class W>
+BBS_HD_NOINLINE void g1_mul_aff_glv_tab_to(const G1Aff<C>& p, const uint32_t* k, const W where, G1Jac<C>& out) { g1_mul_aff_glv_tab_inl<C, W>(p, k, where, out); }
+template <class C, class W>
 BBS_HD G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k, const W where) {
     G1Jac<C> r;
     g1_mul_aff_glv_tab_to<C, W>(p, k, where, r);
@@ -595,34 +602,42 @@ BBS_HD G1Jac<C> g1_mul_aff_glv_tab(const G1Aff<C>& p, const uint32_t* k, const W
 
 // k0 P0 + k1 P1 + k2 P2 on ONE shared doubling chain (Straus): the three tables are brought to one common curve
 // (scale of table j times the other two tables' scales), ~252 doublings + 3 * 64 mixed additions.
-// The tables live in the caller's HBM buffer `tabs` (3 * G1_TAB * 2N words, stride apart).
-// Returns false (out untouched) when a table hit an exceptional case: the caller then sums three separate
-// multiplications (done there, not here, so that the rare path does not deepen this function's stack).
+// The tables live in the caller's HBM buffer `tabs` (3 * G1_TAB * 2N words, stride apart); ENTRY 0 OF TABLE j HOLDS P_j ON
+// ENTRY (stored there by the caller: the points are then no memory objects of this function).
+// Returns false (out untouched) when a table hit an exceptional case (identity, point of small order): the caller then
+// takes three separate multiplications.
 // GLV = true (points in the prime-order subgroup, BLS12-381): six 128-bit halves, ~124 doublings + 6 * 33 additions.
+// Round 5: INLINED into its one device caller (stage PvT1Chain, a kernel of its own), loops over the tables rolled and free
+// of indexed locals.  As one non-inlined function it held the points, the scalars, the tables' scales and its callee-saved
+// registers in a 1264-byte frame below a 1456-byte kernel frame: 2.7 KB of scratch per lane, and scratch x hardware queues
+// is a budget (DESIGN.md 5 rule 6).
 template <class C, bool GLV = false>
-BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
-                                       const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, G1Jac<C>& out) {
+BBS_HD bool g1_mul3_tabs_fast(const uint32_t* k0, const uint32_t* k1, const uint32_t* k2, uint32_t* tabs, size_t stride, G1Jac<C>& out) {
 #ifdef BBS_G1_MUL_NAF
     return false;
 #endif
     constexpr int N = C::FpP::N;
-    Fp<C> zc[3];
-    const G1Aff<C>* ps[3] = {&p0, &p1, &p2};
+    constexpr size_t TW = (size_t)G1_TAB * 2 * N;
+    Fp<C> zc0 = fe_one<FP>(), zc1 = zc0, zc2 = zc0;
     bool ok = true;
 #pragma unroll 1
     for (int j = 0; j < 3; j++) {
-        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-        ok = ok && g1_odd_table<C>(*ps[j], tab, zc[j]);
+        TabHbm<C> tab{tabs + (size_t)j * TW * stride, stride};
+        Fp<C> z = fe_one<FP>();
+        ok = g1_odd_table<C>(tab.ld(0), tab, z) && ok;
+        zc0 = fe_select<FP>(j == 0, z, zc0);
+        zc1 = fe_select<FP>(j == 1, z, zc1);
+        zc2 = fe_select<FP>(j == 2, z, zc2);
     }
     if (!ok) return false;
     // point (x, y) of table j is Jacobian (x, y, zc_j) = (x t^2, y t^3, zc_0 zc_1 zc_2) with t = product of the other two
-    const Fp<C> z01 = fe_mul<FP>(zc[0], zc[1]);
-    const Fp<C> t[3] = {fe_mul<FP>(zc[1], zc[2]), fe_mul<FP>(zc[0], zc[2]), z01};
-    const Fp<C> zall = fe_mul<FP>(z01, zc[2]);
+    const Fp<C> z01 = fe_mul<FP>(zc0, zc1), z12 = fe_mul<FP>(zc1, zc2), z02 = fe_mul<FP>(zc0, zc2);
+    const Fp<C> zall = fe_mul<FP>(z01, zc2);
 #pragma unroll 1
     for (int j = 0; j < 3; j++) {
-        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-        const Fp<C> t2 = fe_sqr<FP>(t[j]), t3 = fe_mul<FP>(t2, t[j]);
+        TabHbm<C> tab{tabs + (size_t)j * TW * stride, stride};
+        const Fp<C> tj = fe_select<FP>(j == 0, z12, fe_select<FP>(j == 1, z02, z01));
+        const Fp<C> t2 = fe_sqr<FP>(tj), t3 = fe_mul<FP>(t2, tj);
 #pragma unroll 1
         for (int e = 0; e < G1_TAB; e++) {
             const G1Aff<C> q = tab.ld(e);
@@ -635,7 +650,7 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
         uint32_t u[6][4];
         bool even[6], neg[6];
         const uint32_t* ks[3] = {k0, k1, k2};
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             uint32_t h0[4], h1[4];
             glv_split<C>(ks[j], h0, h1, neg[2 * j], neg[2 * j + 1]);
@@ -648,7 +663,7 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
         constexpr int STEPS = 33 * 6;
         auto fetch = [&](int s) -> G1Aff<C> {
             const int rd = s / 6, t = s - 6 * rd, i = 31 - rd;
-            const TabHbm<C> tab{tabs + (size_t)(t >> 1) * G1_TAB * 2 * N * stride, stride};
+            const TabHbm<C> tab{tabs + (size_t)(t >> 1) * TW * stride, stride};
             G1Aff<C> q;
             if (i >= 0) q = g1_tab_digit<C>(tab, (u[t][i >> 3] >> (4 * (i & 7))) & 15u, neg[t]);
             else q = even[t] ? (neg[t] ? tab.ld(0) : g1a_neg<C>(tab.ld(0))) : g1a_inf<C>();
@@ -676,7 +691,7 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
         constexpr int STEPS = 65 * 3;
         auto fetch = [&](int s) -> G1Aff<C> {
             const int rd = s / 3, j = s - 3 * rd, i = 63 - rd;
-            const TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
+            const TabHbm<C> tab{tabs + (size_t)j * TW * stride, stride};
             if (i >= 0) return g1_tab_digit<C>(tab, (u[j][i >> 3] >> (4 * (i & 7))) & 15u);
             return even[j] ? g1a_neg<C>(tab.ld(0)) : g1a_inf<C>();
         };
@@ -697,17 +712,20 @@ BBS_HD_NOINLINE bool g1_mul3_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
     out = r;
     return true;
 }
+// host self-test form (bbs_selftest_mul3): the joint chain, or -- a table hit an exceptional case -- the sum of three
+// separate multiplications, each of which falls back to the generic chain on its own (tables in the caller's buffer).
+// The device does the same split across stages: PvT1Chain stores the three products, PvChallenge sums them.
 template <class C>
 BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
                              const G1Aff<C>& p2, const uint32_t* k2, uint32_t* tabs, size_t stride, bool glv = false) {
+    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    { TabHbm<C> t0{tabs, stride}, t1{tabs + TW * stride, stride}, t2{tabs + 2 * TW * stride, stride};
+      t0.st(0, p0); t1.st(0, p1); t2.st(0, p2); }
     G1Jac<C> r;
     if constexpr (C::K::HAS_GLV) {
-        if (glv && g1_mul3_aff_fast<C, true>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
+        if (glv && g1_mul3_tabs_fast<C, true>(k0, k1, k2, tabs, stride, r)) return r;
     }
-    if (!glv && g1_mul3_aff_fast<C>(p0, k0, p1, k1, p2, k2, tabs, stride, r)) return r;
-    // a table hit an exceptional case (identity, point of small order): three separate multiplications, each of
-    // which falls back to the generic chain on its own; their tables reuse the caller's buffer
-    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    if (!glv && g1_mul3_tabs_fast<C>(k0, k1, k2, tabs, stride, r)) return r;
     const AtHbm<C> w0{tabs, stride}, w1{tabs + TW * stride, stride}, w2{tabs + 2 * TW * stride, stride};
     return g1j_add<C, 1>(g1j_add<C, 1>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1)),
                       g1_mul_aff_tab<C, AtHbm<C>>(p2, k2, w2));
@@ -911,6 +929,14 @@ BBS_HD G1Jac<C> g1_mul_aff_sel(const G1Aff<C>& p, const uint32_t* k, bool glv) {
         if (glv) return g1_mul_aff_glv<C>(p, k);
     }
     return g1_mul_aff<C>(p, k);
+}
+// inlined form of g1_mul_aff_sel_hbm (result through `out`)
+template <class C>
+BBS_HD void g1_mul_aff_sel_hbm_inl(const G1Aff<C>& p, const uint32_t* k, bool glv, uint32_t* tab, size_t stride, G1Jac<C>& out) {
+    if constexpr (C::K::HAS_GLV) {
+        if (glv) { g1_mul_aff_glv_tab_inl<C, AtHbm<C>>(p, k, AtHbm<C>{tab, stride}, out); return; }
+    }
+    g1_mul_aff_tab_inl<C, AtHbm<C>>(p, k, AtHbm<C>{tab, stride}, out);
 }
 // the same with the window table in a caller-provided HBM buffer (G1_TAB * 2N words, stride apart)
 template <class C>

@@ -97,7 +97,7 @@ struct bbs_issuer {
     }
     // Pins the entry of message count L (created empty if new; BBS_E_NOMEM if the context limit is reached and nothing is
     // idle) and returns the configuration to bring it up to.
-    int acquire(size_t L, std::shared_ptr<bbs_issuer_entry>& out, Config& cfg, bool forever = false) {
+    int acquire(size_t L, std::shared_ptr<bbs_issuer_entry>& out, Config& cfg, bool forever = false, bool* newly_handed_out = nullptr) {
         std::vector<std::shared_ptr<bbs_issuer_entry>> victims;
         int rc = BBS_OK;
         {
@@ -116,7 +116,7 @@ struct bbs_issuer {
             if (!rc) {
                 out = it->second;
                 out->pins += 1;
-                if (forever) out->handed_out = true;
+                if (forever) { if (newly_handed_out) *newly_handed_out = !out->handed_out; out->handed_out = true; }
                 out->last_use = ++tick;
                 snapshot(cfg);
             }
@@ -136,9 +136,9 @@ struct bbs_issuer {
         if (fresh) {
             bbs_ctx* c = nullptr;
             if ((rc = bbs_ctx_create(curve, device, &c))) return rc;
-            if (max_table_bytes == 0) {                      // first context of the issuer: the byte budget
+            {                                                // first context of the issuer: the byte budget
                 const size_t fr = bbs_device_free_bytes(device);
-                std::lock_guard<std::mutex> g(mu);
+                std::lock_guard<std::mutex> g(mu);           // (bbs_issuer_set_budget writes it under the same lock)
                 if (max_table_bytes == 0) max_table_bytes = std::max<size_t>(fr / 2, (size_t)64 << 20);
             }
             const size_t fpb = bbs_fp_bytes(curve);
@@ -148,7 +148,6 @@ struct bbs_issuer {
             if (!rc) rc = bbs_ctx_set_generators(c, gens.data(), e->L + 1, api_id.data(), api_id.size());
             if (rc) { bbs_ctx_destroy(c); return rc; }
             e->ctx = c;
-            e->table_bytes = bbs_ctx_table_bytes(c);
             e->config_epoch = 0;
         }
         if (e->config_epoch != cfg.epoch) {
@@ -162,8 +161,10 @@ struct bbs_issuer {
             e->config_epoch = cfg.epoch;
         }
         if (fresh) {
-            // account for the new tables; make room among the idle contexts if the budget is exceeded
+            // account for the new tables (measured now that the keys are in: everything the context holds on the device);
+            // make room among the idle contexts if the budget is exceeded
             std::vector<std::shared_ptr<bbs_issuer_entry>> victims;
+            e->table_bytes = bbs_ctx_table_bytes(e->ctx);
             {
                 std::lock_guard<std::mutex> g(mu);
                 table_bytes += e->table_bytes;
@@ -182,6 +183,7 @@ struct bbs_issuer {
             Config cfg;
             int rc = acquire(L, e, cfg);
             if (rc) return rc;
+            bool built = false;
             {
                 std::lock_guard<std::mutex> g(e->mu);
                 bool dead;
@@ -189,10 +191,11 @@ struct bbs_issuer {
                 if (dead) { release(e); continue; }          // evicted between the look-up and the lock (it was idle then)
                 rc = prepare(e.get(), cfg);
                 if (!rc) rc = fn(e->ctx);
+                built = e->ctx != nullptr;                   // read while the entry is locked (another pinned thread may be building it)
             }
             if (rc) {
                 release(e);
-                if (!e->ctx) {                               // never built: do not keep the empty slot
+                if (!built) {                                // never built: do not keep the empty slot
                     std::lock_guard<std::mutex> g(mu);
                     auto it = by_count.find(L);
                     if (it != by_count.end() && it->second == e && e->pins == 0) { e->dead = true; by_count.erase(it); }
@@ -208,7 +211,8 @@ struct bbs_issuer {
     int context(size_t L, bbs_ctx** out) {
         std::shared_ptr<bbs_issuer_entry> e;
         Config cfg;
-        int rc = acquire(L, e, cfg, true);
+        bool newly = false;
+        int rc = acquire(L, e, cfg, true, &newly);
         if (rc) return rc;
         std::lock_guard<std::mutex> g(e->mu);
         rc = prepare(e.get(), cfg);
@@ -216,7 +220,7 @@ struct bbs_issuer {
             std::lock_guard<std::mutex> g2(mu);
             if (e->pins > 0) e->pins--;                      // (the pin only covered the build; handed_out keeps the context resident)
             if (rc) {
-                e->handed_out = false;
+                if (newly) e->handed_out = false;            // an EARLIER caller may hold this context: only this call's own mark is taken back
                 if (!e->ctx) { auto it = by_count.find(L); if (it != by_count.end() && it->second == e && e->pins == 0) { e->dead = true; by_count.erase(it); } }
                 return rc;
             }
@@ -225,6 +229,28 @@ struct bbs_issuer {
         return BBS_OK;
     }
 };
+
+// Contexts that bbs_issuer_context handed out are driven by the caller directly, so nothing "uses" them through the issuer
+// and the lazy, by-epoch update of prepare() would never reach them: after a key rotation such a context would go on
+// verifying (or signing) with the OLD key.  The configuration calls therefore bring them up to the new epoch at once.
+// Called WITHOUT the issuer's lock (prepare takes the entry's lock first, then the issuer's).
+inline int issuer_refresh_handed_out(bbs_issuer* is) {
+    std::vector<std::shared_ptr<bbs_issuer_entry>> held;
+    {
+        std::lock_guard<std::mutex> g(is->mu);
+        for (auto& kv : is->by_count) if (kv.second->handed_out) held.push_back(kv.second);
+    }
+    int rc = BBS_OK;
+    for (auto& e : held) {
+        std::lock_guard<std::mutex> g(e->mu);
+        bbs_issuer::Config cfg;
+        { std::lock_guard<std::mutex> g2(is->mu); if (e->dead) continue; is->snapshot(cfg); }
+        if (!e->ctx) continue;
+        const int r = is->prepare(e.get(), cfg);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
 
 namespace issuer_detail {
 

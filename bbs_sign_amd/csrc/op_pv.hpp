@@ -4,6 +4,13 @@
 #include "runtime.hpp"
 
 // ---- proof_verify ----------------------------------------------------------------------------
+// where a job's doubling chains run (see pv_upload): 3 / 2 / 1; BBS_PV_MSM_LAYOUT overrides (A/B), read once.
+// one_queue: the job is meant to own ONE hardware queue (batch verification's throughput form keeps many jobs alive)
+inline int pv_msm_layout(bool one_queue) {
+    static const int forced = []() { const char* v = getenv("BBS_PV_MSM_LAYOUT"); const int k = v ? atoi(v) : 0; return (k >= 1 && k <= 3) ? k : 0; }();
+    if (forced) return forced;
+    return one_queue ? 1 : 3;
+}
 template <class C>
 struct PvJob : JobBase<C> {
     using JobBase<C>::JobBase;
@@ -136,10 +143,23 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     // (measured: letting the fixed-base lanes compute their own scalars and dropping the pv_scalars launch costs more than
     // the launch -- the hash and the Fr products land in the register-critical MSM kernel: 5.14 -> 5.33 ms, scratch 2.7 -> 3.1 KB)
     a.bv_dig = nullptr; a.bv_ppts = nullptr; a.bv_n_pad = 0;
-    auto msm_chain = [j]() {
+    // The multi-scalar multiplication as separate kernels (stages.hpp, round 5).  The fixed-base chunks follow the scalars on
+    // the main stream; where the doubling chains go is `layout`:
+    //   3 : T1's chain on the job's second side stream, the single multiplications in front of the scalars on the main stream
+    //       (two launches, each with its own budget; the main stream joins the side stream before the challenge stage)
+    //   2 : all chains as ONE launch on the second side stream
+    //   1 : all chains as one launch on the main stream behind the fixed-base chunks (a job that owns one hardware queue:
+    //       batch verification's throughput form)
+    auto msm_chain = [j](int layout) {
+        if (layout == 3) j->stages.push_back({"pv_t1_chain", [j]() { return rt::launch<PvT1Chain<C>>(j->stream_aux(2), j->a, j->n); }, 2, 0});
+        if (layout == 2) j->stages.push_back({"pv_chains", [j]() { return rt::launch<PvChains<C>>(j->stream_aux(2), j->a, j->n * PvChains<C>::units(j->a)); }, 2, 0});
+        if (layout == 3) j->stages.push_back({"pv_var_mul", [j]() { return rt::launch<PvVarMul<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar - PvVarMul<C>::first_part(j->a))); }});
         j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
-        j->stages.push_back({"pv_msm_parts", [j]() { return rt::launch<PvMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
+        if (j->a.fixwk.pts0) j->stages.push_back({"pv_fixed_tree", [j]() { return rt::launch<PvFixedTree<C>>(j->stream(), j->a, j->n); }});
+        else j->stages.push_back({"pv_fixed_chunks", [j]() { return rt::launch<PvFixedChunk<C>>(j->stream(), j->a, j->n * (size_t)NFIX); }});
+        if (layout == 1) j->stages.push_back({"pv_chains", [j]() { return rt::launch<PvChains<C>>(j->stream(), j->a, j->n * PvChains<C>::units(j->a)); }});
     };
+    const int join_chains = 2;      // Stage::join bit of the second side stream (ignored where nothing was forked onto it)
     if (!ctx->batch_verify) {
         // every item its own pairing product, on the job's second stream concurrently with the MSM / challenge
         // stages: it needs only the proof's own points (canonical, converted in the kernel) and the flag the ingest stage
@@ -149,8 +169,8 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         // chain it oversubscribes the 1024 SIMDs and the queued wavefronts cost more than the split saves (measured
         // 5.1 ms split vs 4.4 ms fused, profiles/r03_j_latency_form_split.log)
         add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane", false, 0, false);
-        msm_chain();
-        j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
+        msm_chain(pv_msm_layout(false));
+        j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
         // batch verification (pippenger.hpp): combined pairing checks instead of n products; if one fails, the per-item
@@ -163,12 +183,12 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         const int aux = job->latency_form ? 1 : 0;
         if (aux && (rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
                                                   job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1, true))) return rc;
-        msm_chain();
+        msm_chain(pv_msm_layout(!aux));
         if (aux) {
-            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }});
+            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
         } else {
-            // (a_bar, b_bar in Montgomery form were stored by PvMsmPart; the challenge stage writes digits and points)
-            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallengeBv<C>>(j->stream(), j->a, j->n); }});
+            // (a_bar, b_bar in Montgomery form were stored by PvT1Chain; the challenge stage writes digits and points)
+            j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallengeBv<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
             if ((rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.aff, a.aff + (size_t)2 * N * n, 0, a.status, ST_PAIRING, 1, 0, false))) return rc;
             a.bv_dig = j->bv.prep.dig; a.bv_ppts = j->bv.prep.ppts; a.bv_n_pad = j->bv.prep.n_pad;
             std::memcpy(a.bv_seed, j->bv.prep.seed, sizeof(a.bv_seed));

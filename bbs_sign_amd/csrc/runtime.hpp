@@ -40,6 +40,8 @@ inline int set_device(int) { return 0; }
 inline int device_count() { return 1; }
 inline int stream_create(Stream*) { return 0; }
 inline void stream_destroy(Stream&) {}
+struct QueueBudget { int total = 0, pool = 0, dedicated_cap = 0; size_t scratch = 0; };
+inline QueueBudget queue_budget(int) { return QueueBudget{}; }
 inline size_t size_class(size_t b) { return b; }
 inline int dmalloc(void** p, size_t b) { *p = std::calloc(b ? b : 1, 1); return *p ? 0 : -1; }
 inline void dfree(void* p, size_t, int) { std::free(p); }
@@ -103,6 +105,8 @@ struct Pools {
     size_t pinned_bytes = 0;
     std::map<int, std::vector<hipEvent_t>> timing_events;      // events WITH timing (stage timers), recycled
     std::map<int, int> dedicated_made;                         // streams with a hardware queue of their own, per device
+    std::map<int, int> pooled_made;                            // streams drawn from the runtime's GPU_MAX_HW_QUEUES pool, per device (alive or recycled here)
+    std::set<hipStream_t> dedicated;                           // which of the recycled streams are the dedicated ones
     static Pools& get() { static Pools* p = new Pools(); return *p; }      // lives as long as the process
 };
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -208,32 +212,103 @@ inline void hfree(void* p, size_t b) {
 inline int sync(Stream& s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 inline size_t mem_free_bytes() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? f : 0; }
 using Event = hipEvent_t;
+// ---- hardware queues x scratch: ONE budget, checked (round 5; DESIGN.md 5 rule 6) ---------------------------------------
+// The runtime reserves scratch per hardware queue for every wave slot of the chip, sized for the largest kernel frame the
+// queue has run: bytes per lane x 64 lanes x wave slots (8192 on MI355X).  Measured (profiles/r03_q_*, r04_g_*): up to
+// queues x bytes/lane ~ 48 k everything runs, from ~ 50 k the runtime starts reclaiming scratch between dispatches and every
+// rate collapses, from ~ 56 k it ABORTS THE PROCESS (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  The library therefore knows its own
+// largest kernel frame -- every kernel registers itself when the library is loaded, hipFuncGetAttributes gives the frame
+// -- and never lets (pooled + dedicated) hardware queues x that frame exceed SCRATCH_POOL_FRACTION of the device's memory:
+// dedicated queues beyond the budget are not created (the stream comes from the pool), and if the POOL alone is over budget
+// (an explicit GPU_MAX_HW_QUEUES=32) the library stops creating streams at the budget -- a job that gets no stream of its
+// own shares its context's stream (JobBase::stream) or runs its side streams' work on its main stream.  Slower, never an abort.
+struct KernelRegistry {
+    std::mutex mu;
+    std::vector<const void*> fns;
+    static KernelRegistry& get() { static KernelRegistry* r = new KernelRegistry(); return *r; }      // lives as long as the process
+};
+inline int register_kernel(const void* f) {
+    KernelRegistry& r = KernelRegistry::get();
+    std::lock_guard<std::mutex> g(r.mu);
+    r.fns.push_back(f);
+    return (int)r.fns.size();
+}
+// largest private segment (scratch bytes per lane) of any kernel of this library; once, after the runtime is up
+inline size_t library_max_scratch() {
+    static const size_t v = []() {
+        KernelRegistry& r = KernelRegistry::get();
+        std::lock_guard<std::mutex> g(r.mu);
+        size_t m = 0;
+        for (const void* f : r.fns) {
+            hipFuncAttributes a;
+            if (hipFuncGetAttributes(&a, f) == hipSuccess) m = std::max(m, (size_t)a.localSizeBytes);
+            else (void)hipGetLastError();
+        }
+        return m;
+    }();
+    return v;
+}
+constexpr double SCRATCH_POOL_FRACTION = 0.085;       // of the device's memory: 26 GB of 288 GiB = 47 k (queues x bytes per lane)
+struct QueueBudget {
+    int total = 0;            // hardware queues (pooled + dedicated) the scratch budget allows
+    int pool = 0;             // the runtime's pool: GPU_MAX_HW_QUEUES as the environment has it, 4 when unset
+    int dedicated_cap = 0;    // dedicated queues the budget leaves room for: max(0, total - pool)
+    size_t scratch = 0;       // bytes per lane of the library's largest kernel frame
+};
+inline QueueBudget queue_budget(int dev) {
+    static std::mutex mu;
+    static std::map<int, QueueBudget> cache;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    QueueBudget b;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return b; }
+    b.scratch = library_max_scratch();
+    const size_t wave_slots = (size_t)p.multiProcessorCount * (size_t)std::max(1, p.maxThreadsPerMultiProcessor / 64);
+    const double per_queue = (double)std::max<size_t>(b.scratch, 64) * 64.0 * (double)wave_slots;
+    b.total = (int)std::min(64.0, std::max(1.0, (double)p.totalGlobalMem * SCRATCH_POOL_FRACTION / per_queue));
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    b.pool = v && atoi(v) > 0 ? atoi(v) : 4;
+    b.dedicated_cap = std::max(0, b.total - b.pool);
+    cache[dev] = b;
+    return b;
+}
 // -1: not decided yet (the environment is read at the first stream); 0: off; k > 0: up to k job streams per device
 inline std::atomic<int>& dedicated_queues() { static std::atomic<int> v{-1}; return v; }
+// 0: a stream; -1: the runtime failed; -2: no stream left within the queue budget (the caller shares one it has)
 inline int stream_create(Stream* s) {
     Pools& P = Pools::get();
+    const int dev = current_device();
+    const QueueBudget qb = queue_budget(dev);           // (takes its own lock; hipFuncGetAttributes on first use)
     std::lock_guard<std::mutex> g(P.mu);
-    auto& v = P.streams[current_device()];
+    auto& v = P.streams[dev];
     if (!v.empty()) { *s = v.begin()->second; v.erase(v.begin()); return 0; }
     // Dedicated hardware queues (bbs_runtime_set_dedicated_queues / BBS_DEDICATED_QUEUES=k): the runtime gives a stream
     // created with a compute-unit mask (here: all ones, no restriction) a hardware queue of its own instead of a share of
     // the GPU_MAX_HW_QUEUES pool.  For a process whose first HIP call came BEFORE this library was loaded (any torch user):
     // the pool is then fixed at the runtime's default of 4, several jobs share a queue and a long narrow kernel blocks the
     // others (measured: 1.30 M proof_verify/s instead of 1.50 M; with dedicated queues 1.50 M whatever the pool,
-    // profiles/r04_f_dedicated_queues.log).  At most k streams per device are created this way (default cap 12: every
-    // queue reserves scratch for the largest kernel it has run, and queues x bytes per lane is a budget, DESIGN.md 5 rule
-    // 6); further streams come from the pool.  Such streams are BLOCKING with respect to the legacy default stream (the
-    // runtime offers no flags for them): off unless asked for.
+    // profiles/r04_f_dedicated_queues.log).  At most min(k, what the scratch budget leaves beside the pool) streams per
+    // device are created this way; further streams come from the pool.  Such streams are BLOCKING with respect to the legacy
+    // default stream (the runtime offers no flags for them): off unless asked for.
     int want = dedicated_queues().load();
-    if (want < 0) { const char* v = getenv("BBS_DEDICATED_QUEUES"); want = v ? atoi(v) : 0; if (want == 1) want = 12; if (want < 0) want = 0; if (want > 16) want = 16; dedicated_queues().store(want); }
+    if (want < 0) { const char* e = getenv("BBS_DEDICATED_QUEUES"); want = e ? atoi(e) : 0; if (want == 1) want = 12; if (want < 0) want = 0; if (want > 16) want = 16; dedicated_queues().store(want); }
+    if (qb.total > 0) want = std::min(want, qb.dedicated_cap);
     bool made = false;
-    if (want > 0 && P.dedicated_made[current_device()] < want) {
+    if (want > 0 && P.dedicated_made[dev] < want) {
         uint32_t mask[16];
         for (auto& m : mask) m = 0xFFFFFFFFu;
-        if (hipExtStreamCreateWithCUMask(s, 16, mask) == hipSuccess) { made = true; P.dedicated_made[current_device()]++; }
+        if (hipExtStreamCreateWithCUMask(s, 16, mask) == hipSuccess) { made = true; P.dedicated_made[dev]++; P.dedicated.insert(*s); }
         else (void)hipGetLastError();
     }
-    if (!made && hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!made) {
+        // the pool alone may be over budget (an explicit GPU_MAX_HW_QUEUES): streams map onto its queues round robin, so the
+        // number of pooled streams this library creates bounds the number of pooled queues it touches
+        if (qb.total > 0 && qb.pool > qb.total - P.dedicated_made[dev] && P.pooled_made[dev] >= std::max(1, qb.total - P.dedicated_made[dev])) return -2;
+        if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        P.pooled_made[dev]++;
+    }
     P.stream_index[*s] = P.next_stream_index++;
     return 0;
 }
@@ -244,6 +319,7 @@ inline void stream_destroy(Stream& s) {                  // callers synchronise 
     auto it = P.stream_index.find(s);
     if (it != P.stream_index.end() && v.size() < 256) { v.insert({it->second, s}); return; }
     if (it != P.stream_index.end()) P.stream_index.erase(it);
+    if (P.dedicated.erase(s)) P.dedicated_made[current_device()]--; else P.pooled_made[current_device()]--;
     (void)hipStreamDestroy(s);
 }
 inline int event_create(Event* e) {
@@ -274,9 +350,13 @@ __global__ void __launch_bounds__(64, waves_of<F>::v) k_stage(A a, size_t nthrea
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t < nthreads) F::run(a, t);
 }
+// every kernel of the library is known when the library has been loaded (queue budget above)
+template <class F, class A> struct KernelEntry { static const int token; };
+template <class F, class A> const int KernelEntry<F, A>::token = register_kernel(reinterpret_cast<const void*>(&k_stage<F, A>));
 template <class F, class A>
 inline int launch(Stream& s, const A& a, size_t nthreads) {
     if (!nthreads) return 0;
+    (void)&KernelEntry<F, A>::token;
     const unsigned blocks = (unsigned)((nthreads + 63) / 64);
     hipLaunchKernelGGL((k_stage<F, A>), dim3(blocks), dim3(64), 0, s, a, nthreads);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -448,6 +528,7 @@ struct Ctx : bbs_ctx {
     static constexpr int FPB = 4 * C::FpP::NC;   // bytes of a canonical field element
     int device = 0;
     rt::Stream stream{};
+    bool stream_ready = false;
     int win_bits = 8;                // width of the tables that are built
     int win_bits_requested = 0;      // bbs_ctx_set_window_bits; 0 (the default) = choose at set_generators from the free device memory
     // host state
@@ -507,7 +588,8 @@ struct Ctx : bbs_ctx {
     int init(int dev) {
         device = dev;
         if (rt::set_device(dev)) return BBS_E_NO_DEVICE;
-        if (rt::stream_create(&stream)) return BBS_E_HIP;
+        if (const int src = rt::stream_create(&stream)) return src == -2 ? BBS_E_NO_RESOURCES : BBS_E_HIP;
+        stream_ready = true;
         std::memset(&hc, 0, sizeof(hc));
         for (int j = 0; j < N; j++) { hc.p1.x.v[j] = C::K::P1X_M[j]; hc.p1.y.v[j] = C::K::P1Y_M[j]; }
         for (int k = 0; k < 3; k++) for (int m = 0; m < 6; m++) for (int c2 = 0; c2 < 2; c2++)
@@ -520,7 +602,8 @@ struct Ctx : bbs_ctx {
         return BBS_OK;
     }
     ~Ctx() override {
-        (void)rt::set_device(device); (void)rt::sync(stream); rt::stream_destroy(stream);
+        (void)rt::set_device(device);
+        if (stream_ready) { (void)rt::sync(stream); rt::stream_destroy(stream); }
         volatile uint32_t* s = sk;                       // do not leave the secret key in freed host memory
         for (int k = 0; k < 8; k++) s[k] = 0;
     }
@@ -641,30 +724,53 @@ struct bbs_job {
         j->fired.fetch_add(1, std::memory_order_release);
         h.cv.notify_all();
     }
-    // behind what has been enqueued on the main stream so far (the main stream joins the second one before its last stage)
+    // A run that could not be enqueued completely (a launch failed, the notification could not be placed): the job counts as
+    // FINISHED WITH AN ERROR -- bbs_job_poll says 1, bbs_jobs_wait_any hands it out at once, and bbs_job_wait / wait_any
+    // return BBS_E_HIP for it instead of delivering anything.  Without this a notification that was counted but never placed
+    // left the job "running" for ever (wait_any slept on it), and a re-run that failed before arming left the PREVIOUS run's
+    // completion standing, i.e. stale results reported as this run's.  Cleared when the next run starts.
+    std::atomic<bool> failed{false};
+    void mark_failed(bool take_back_arm) {
+        CompletionHub& h = CompletionHub::get();
+        std::lock_guard<std::mutex> g(h.mu);
+        if (take_back_arm) armed.fetch_sub(1, std::memory_order_relaxed);
+        failed.store(true, std::memory_order_release);
+        h.cv.notify_all();
+    }
+    // behind what has been enqueued on the main stream so far (the main stream joins the side streams before its last stage).
+    // Counted BEFORE the host function is placed (it may fire before hipLaunchHostFunc returns: counting afterwards could lose
+    // the wake-up); taken back if it could not be placed.
     int arm_completion() {
         armed.fetch_add(1, std::memory_order_relaxed);
 #ifdef BBS_HOST_TWIN
         on_complete(this);
         return BBS_OK;
 #else
-        if (use()) return BBS_E_HIP;
-        return hipLaunchHostFunc(stream(), &bbs_job::on_complete, this) == hipSuccess ? BBS_OK : BBS_E_HIP;
+        if (!use() && hipLaunchHostFunc(stream(), &bbs_job::on_complete, this) == hipSuccess) return BBS_OK;
+        (void)hipGetLastError();
+        mark_failed(true);
+        return BBS_E_HIP;
 #endif
     }
     bool hold_arm = false;                       // the submit functions arm once, behind their own copies (not run())
-    bool ever_run() const { return armed.load(std::memory_order_relaxed) != 0; }
-    bool completed() const { const uint32_t a = armed.load(std::memory_order_relaxed); return a != 0 && fired.load(std::memory_order_acquire) == a; }
-    // aux = 1: the stage runs on the job's second stream, concurrently with the main-stream stages
-    // that follow the fork point (start of the run); join = 1: the main stream first waits for
-    // everything issued on the second stream
+    bool ever_run() const { return armed.load(std::memory_order_relaxed) != 0 || failed.load(std::memory_order_acquire); }
+    bool completed() const {
+        if (failed.load(std::memory_order_acquire)) return true;
+        const uint32_t a = armed.load(std::memory_order_relaxed);
+        return a != 0 && fired.load(std::memory_order_acquire) == a;
+    }
+    // aux = k > 0: the stage runs on the job's k-th side stream (k = 1, 2), concurrently with the main-stream stages
+    // that follow the fork point (the place of the first stage of that stream in the list); join: bit k - 1 set = the main
+    // stream first waits for everything issued on side stream k (1: the first, 2: the second, 3: both)
+    static constexpr int N_AUX = 2;
     struct Stage { const char* name; std::function<int()> launch; int aux = 0; int join = 0; };
     std::vector<Stage> stages;
     virtual int use() = 0;
     virtual rt::Stream& stream() = 0;
-    virtual rt::Stream& stream_aux() = 0;
-    virtual int fork_aux() = 0;                  // aux stream waits for what the main stream has issued
-    virtual int join_aux() = 0;                  // main stream waits for what the aux stream has issued
+    virtual rt::Stream& stream_aux(int k = 1) = 0;
+    virtual int fork_aux(int k = 1) = 0;         // side stream k waits for what the main stream has issued
+    virtual int join_aux(int k = 1) = 0;         // main stream waits for what side stream k has issued
+    virtual int sync_aux() = 0;                  // host waits for every side stream that exists
     virtual int reset() = 0;                     // restore the pre-run status so the job can run again
     virtual int fetch_status(int8_t*) = 0;
     // submit form (bbs_core_*_submit): the statuses are copied to page-locked memory behind the last stage, and
@@ -685,11 +791,13 @@ struct bbs_job {
     int run_recorded(rt::EventList* ev) {
         if (reset()) return BBS_E_HIP;
         if (ev && ev->record(stream())) return BBS_E_HIP;
-        bool forked = false;
+        unsigned forked = 0;
         for (auto& s : stages) {
-            if (s.aux && !forked) { if (fork_aux()) return BBS_E_HIP; forked = true; }
-            if (s.join && forked) { if (join_aux()) return BBS_E_HIP; }
-            rt::Stream& st = s.aux ? stream_aux() : stream();
+            if (s.aux < 0 || s.aux > N_AUX) return BBS_E_STATE;
+            if (s.aux && !((forked >> s.aux) & 1u)) { if (fork_aux(s.aux)) return BBS_E_HIP; forked |= 1u << s.aux; }
+            for (int k = 1; k <= N_AUX; k++)
+                if (((s.join >> (k - 1)) & 1) && ((forked >> k) & 1u)) { if (join_aux(k)) return BBS_E_HIP; }
+            rt::Stream& st = s.aux ? stream_aux(s.aux) : stream();
             if (ev && ev->record(st)) return BBS_E_HIP;
             if (s.launch()) return BBS_E_HIP;
             if (ev && ev->record(st)) return BBS_E_HIP;
@@ -700,7 +808,8 @@ struct bbs_job {
     std::unique_ptr<rt::EventList> tev;          // events of the LAST run (timed jobs)
     bool results_wanted = false;                 // submit form of sign / proof_gen: the records follow the statuses
     int run() {
-        if (use()) return BBS_E_HIP;
+        failed.store(false, std::memory_order_release);
+        if (use()) { mark_failed(false); return BBS_E_HIP; }
         if (timed) tev.reset(new rt::EventList(1 + 2 * stages.size()));
         int rc = run_recorded(timed ? tev.get() : nullptr);
         // a submit-form job that is run AGAIN (bbs_job_run): what bbs_job_wait delivers must be this run's statuses and
@@ -710,6 +819,7 @@ struct bbs_job {
             if (!rc && results_wanted) rc = enqueue_result_fetch();
         }
         if (!rc && !hold_arm) rc = arm_completion();
+        else if (rc) mark_failed(false);
         return rc;
     }
     // stage durations of the last run of a timed job; call after wait()
@@ -717,13 +827,14 @@ struct bbs_job {
         const int ns = (int)stages.size();
         if (n_stages) *n_stages = ns;
         if (!timed || !tev || tev->used != 1 + 2 * (size_t)ns) return BBS_E_STATE;
-        if (use() || rt::sync(stream()) || rt::sync(stream_aux())) return BBS_E_HIP;
+        if (use() || rt::sync(stream()) || sync_aux()) return BBS_E_HIP;
         if (total_ms) *total_ms = tev->ms(0, 2 * (size_t)ns);
         for (int k = 0; kernel_ms && k < ns && k < cap; k++) kernel_ms[k] = tev->ms(1 + 2 * (size_t)k, 2 + 2 * (size_t)k);
         return BBS_OK;
     }
     int wait() {
         if (use() || rt::sync(stream())) return BBS_E_HIP;
+        if (failed.load(std::memory_order_acquire)) return BBS_E_HIP;     // the last run was not enqueued completely: nothing to deliver
         return deliver_to ? deliver() : BBS_OK;
     }
 };
@@ -741,9 +852,10 @@ struct JobBase : bbs_job {
     std::vector<std::pair<void*, size_t>> zero_on_reset;   // device arrays cleared before every run (fail closed)
     std::vector<std::unique_ptr<DevBuf>> bufs;
     // every job owns its streams: independent jobs (batches) of one context overlap on the GPU
-    rt::Stream main{}, aux{};
-    rt::Event ev_fork{}, ev_join{};
-    bool main_ready = false, aux_ready = false;
+    rt::Stream main{}, aux[bbs_job::N_AUX]{};
+    rt::Event ev_fork[bbs_job::N_AUX]{}, ev_join[bbs_job::N_AUX]{};
+    bool main_ready = false, aux_ready[bbs_job::N_AUX] = {false, false};
+    bool aux_shared[bbs_job::N_AUX] = {false, false};      // the queue budget left no stream for this side stream: its stages run on the main stream
     bool latency_form = false;       // decided when the job is created (Ctx::latency_form_now)
     explicit JobBase(Ctx<C>* c) : ctx(c) {
         main_ready = (ctx->use() == 0) && (rt::stream_create(&main) == 0); timed = c->stage_timing;
@@ -755,7 +867,8 @@ struct JobBase : bbs_job {
         ctx->live_jobs.fetch_sub(1);
         device_live_jobs(ctx->device).fetch_sub(1);
         (void)ctx->use();            // streams and buffers go back to this device's pools
-        if (aux_ready) { rt::sync(aux); rt::event_destroy(ev_fork); rt::event_destroy(ev_join); rt::stream_destroy(aux); }
+        for (int k = 0; k < bbs_job::N_AUX; k++)
+            if (aux_ready[k]) { rt::sync(aux[k]); rt::event_destroy(ev_fork[k]); rt::event_destroy(ev_join[k]); rt::stream_destroy(aux[k]); }
         if (main_ready) { rt::sync(main); rt::stream_destroy(main); }
     }
     int use() override { return ctx->use(); }
@@ -767,19 +880,32 @@ struct JobBase : bbs_job {
         return t;
     }
     rt::Stream& stream() override { return main_ready ? main : ctx->stream; }
-    int ensure_aux() {
-        if (aux_ready) return 0;
-        if (rt::stream_create(&aux) || rt::event_create(&ev_fork) || rt::event_create(&ev_join)) return -1;
-        aux_ready = true;
+    int ensure_aux(int k) {                      // k = 1 .. N_AUX
+        if (k < 1 || k > bbs_job::N_AUX) return -1;
+        if (aux_ready[k - 1] || aux_shared[k - 1]) return 0;
+        const int rc = rt::stream_create(&aux[k - 1]);
+        if (rc == -2) { aux_shared[k - 1] = true; return 0; }     // over the queue budget: share the main stream (in order, no fork / join)
+        if (rc) return -1;
+        if (rt::event_create(&ev_fork[k - 1])) { rt::stream_destroy(aux[k - 1]); return -1; }
+        if (rt::event_create(&ev_join[k - 1])) { rt::event_destroy(ev_fork[k - 1]); rt::stream_destroy(aux[k - 1]); return -1; }
+        aux_ready[k - 1] = true;
         return 0;
     }
-    rt::Stream& stream_aux() override { ensure_aux(); return aux; }
-    int fork_aux() override {
-        if (ensure_aux()) return -1;
-        return (rt::event_record(ev_fork, stream()) || rt::stream_wait(aux, ev_fork)) ? -1 : 0;
+    rt::Stream& stream_aux(int k = 1) override { ensure_aux(k); return (k >= 1 && k <= bbs_job::N_AUX && aux_ready[k - 1]) ? aux[k - 1] : stream(); }
+    int fork_aux(int k = 1) override {
+        if (ensure_aux(k)) return -1;
+        if (!aux_ready[k - 1]) return 0;
+        return (rt::event_record(ev_fork[k - 1], stream()) || rt::stream_wait(aux[k - 1], ev_fork[k - 1])) ? -1 : 0;
     }
-    int join_aux() override {
-        return (rt::event_record(ev_join, aux) || rt::stream_wait(stream(), ev_join)) ? -1 : 0;
+    int join_aux(int k = 1) override {
+        if (ensure_aux(k)) return -1;
+        if (!aux_ready[k - 1]) return 0;
+        return (rt::event_record(ev_join[k - 1], aux[k - 1]) || rt::stream_wait(stream(), ev_join[k - 1])) ? -1 : 0;
+    }
+    int sync_aux() override {
+        int rc = 0;
+        for (int k = 0; k < bbs_job::N_AUX; k++) if (aux_ready[k] && rt::sync(aux[k])) rc = -1;
+        return rc;
     }
     // device-to-device, asynchronous: back-to-back runs of one job never wait for the host
     int reset() override {
@@ -927,9 +1053,12 @@ struct BvState {
 
 #if !defined(BBS_HOST_TWIN)
 namespace rt {
+template <class C> struct PipKernelEntry { static const int token; };
+template <class C> const int PipKernelEntry<C>::token = register_kernel(reinterpret_cast<const void*>(&k_pip_window<C>));
 template <class C>
 inline int launch_pip_windows(Stream& s, const PipCoopArgs<C>& a) {
     const size_t units = (size_t)a.M * a.NW * a.n_tiles;
+    (void)&PipKernelEntry<C>::token;
     if (!units || !a.n) return 0;
     hipLaunchKernelGGL((k_pip_window<C>), dim3((unsigned)units), dim3(PIP_WG), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;

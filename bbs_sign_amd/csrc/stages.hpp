@@ -438,6 +438,11 @@ constexpr int PV_NVAR = 2;                    // (c*Bbar + e^*Abar + r1^*D) join
 constexpr int PV_NVAR_SPLIT = 4;              // latency mode: c*Bbar, e^*Abar, r1^*D, r3^*D each on its own lane
 constexpr int PV_NPARTS = PV_NVAR + NFIX;
 constexpr int PV_NPARTS_MAX = PV_NVAR_SPLIT + NFIX;
+// throughput form only (nvar = PV_NVAR): two more terms of T1, behind the fixed-base chunks.  Identity unless the joint chain
+// of an item could not be used (a proof point that is the identity or of small order): then T1's three products are computed
+// one by one and land in slots 0, PV_T1_EXTRA, PV_T1_EXTRA + 1; PvChallenge adds them up in either case.
+constexpr int PV_T1_EXTRA = PV_NVAR + NFIX;
+static_assert(PV_T1_EXTRA + 2 <= PV_NPARTS_MAX, "partial-sum slots");
 
 template <class C>
 struct PvArgs {
@@ -587,58 +592,134 @@ struct PvScalars {
     }
 };
 
-// stage 2 (lane per (part, item)): MSM parts
+// stage 2: the multi-scalar multiplication, as THREE kernels with their own register and scratch budgets (round 5; one
+// kernel with four branch bodies -- 428 registers, 2.7 KB of scratch per lane -- charged that budget to the 512 of its 640
+// wavefronts that only look up table entries and add them).  Every part writes its Jacobian partial sum to
+// partials[part], part = 0: T1's chain, 1 .. nvar-1: single variable-base multiplications, nvar + f: fixed-base chunk f.
+//
+// stage 2a (lane per item): the on-curve checks of the proof's three points, their Montgomery copies, and -- throughput form
+// -- T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain.  (Latency form: T1's three terms are
+// parts 0 .. 2 of PvVarMul, summed by PvChallenge, and this stage only checks and converts.)  The only stage that can decide
+// -41 (a point off the curve); the other two may run beside it on other streams and need not see that verdict: what they
+// compute for such an item is never read (PvChallenge runs behind all three and skips it).
 template <class C>
-struct PvMsmPart {
-    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
+struct PvT1Chain {
+    static BBS_HD void run(const PvArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        constexpr int NC = C::FpP::NC;
+        constexpr size_t TW = (size_t)G1_TAB * 2 * N;
+        const size_t n = a.n;
+        if (a.status[i] != ST_PENDING) return;
+        const bool joint = a.nvar == PV_NVAR;
+        {
+            // Abar, Bbar, D: on the curve?  Montgomery copies for the challenge stage (and batch verification); in the
+            // throughput form also entry 0 of their window tables (tables 1, 0, 2: the chain's order is Bbar, Abar, D)
+            bool on = true;
+#pragma unroll 1
+            for (int k = 0; k < 3; k++) {
+                const G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)k * 2 * NC * n, n, i);
+                on = g1a_on_curve<C>(p) && on;
+                g1a_store_mont<C>(a.aff + (size_t)k * 2 * N * n, n, i, p);
+                if (joint) TabHbm<C>{a.vtab + (size_t)(k == 0 ? 1 : (k == 1 ? 0 : 2)) * TW * n + i, n}.st(0, p);
+            }
+            if (!on) { a.status[i] = -41; return; }
+        }
+        if (!joint) return;
+        uint32_t kc[8], ke[8], k1[8];
+        soa_ld<8>(a.sc + (size_t)3 * 8 * n, n, i, kc);
+        soa_ld<8>(a.sc, n, i, ke);
+        soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
+        uint32_t* const x0 = a.partials + (size_t)PV_T1_EXTRA * 3 * N * n;
+        uint32_t* const x1 = a.partials + (size_t)(PV_T1_EXTRA + 1) * 3 * N * n;
+        G1Jac<C> r;
+        bool done = false;
+        if constexpr (C::K::HAS_GLV) {
+            if (a.glv) done = g1_mul3_tabs_fast<C, true>(kc, ke, k1, a.vtab + i, n, r);
+        }
+        if (!a.glv) done = g1_mul3_tabs_fast<C, false>(kc, ke, k1, a.vtab + i, n, r);
+        if (done) {
+            g1j_store<C>(a.partials, n, i, r);
+            r = g1j_inf<C>();
+            g1j_store<C>(x0, n, i, r);
+            g1j_store<C>(x1, n, i, r);
+        } else {
+            // a table hit an exceptional case (a proof point that is the identity or of small order, i.e. outside the
+            // prime-order subgroup): the three products one by one on the generic double-and-add chain, which is right for
+            // any on-curve point; PvChallenge sums the three slots.  Rare by construction, so its speed is of no concern,
+            // but its frame is: a windowed multiplication here would add 0.9 KB to the kernel's scratch.
+#pragma unroll 1
+            for (int k = 0; k < 3; k++) {
+                const G1Aff<C> p = g1a_load_mont<C>(a.aff + (size_t)(k == 0 ? 1 : (k == 1 ? 0 : 2)) * 2 * N * n, n, i);
+                const uint32_t* kk = k == 0 ? kc : (k == 1 ? ke : k1);
+                g1j_store<C>(k == 0 ? a.partials : (k == 1 ? x0 : x1), n, i, g1_mul_aff_naf<C>(p, kk));
+            }
+        }
+    }
+};
+// stage 2b (lane per (part, item)): single variable-base multiplications -- r3^*D, the variable-base term of T2
+// (proof_verify.rs:175-182), always (part nvar - 1); in the latency form also T1's three terms c*Bbar, e^*Abar, r1^*D (parts
+// 0, 1, 2).  Window tables in HBM (a private table is 0.9 KB of scratch per lane of the whole kernel, and scratch x hardware
+// queues is a budget: DESIGN.md 5 rule 6).  Reads the points in canonical form, as the ingest stage left them.
+template <class C>
+struct PvVarMul {
+    static __host__ __device__ int first_part(const PvArgs<C>& a) { return a.nvar == PV_NVAR ? 1 : 0; }
+    static BBS_HD void run(const PvArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        constexpr int NC = C::FpP::NC;
+        const size_t n = a.n;
+        const int rel = (int)(t / n);
+        const int part = first_part(a) + rel;
+        const size_t i = t - (size_t)rel * n;
+        if (a.status[i] != ST_PENDING) return;
+        const bool last = part == a.nvar - 1;
+        const int pt = last ? 2 : (part == 0 ? 1 : (part == 1 ? 0 : 2));   // point: D | Bbar, Abar, D
+        const int sc = last ? 2 : (part == 0 ? 3 : (part == 1 ? 0 : 1));   // scalar: r3^ | c, e^, r1^
+        G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * NC * n, n, i);
+        uint32_t k[8];
+        soa_ld<8>(a.sc + (size_t)sc * 8 * n, n, i, k);
+        const int slot = last ? 3 : part;                                   // vtab slot 3 is D * r3^ in both forms
+        G1Jac<C> r;
+        g1_mul_aff_sel_hbm_inl<C>(p, k, a.glv != 0, a.vtab + (size_t)slot * G1_TAB * 2 * N * n + i, n, r);
+        g1j_store<C>(a.partials + (size_t)part * 3 * N * n, n, i, r);
+    }
+};
+// stages 2a + 2b as ONE launch (lane per (unit, item); unit 0 = stage 2a, the others stage 2b): for a job that keeps
+// everything on one stream (batch verification's throughput form), where two launches would run one after the other
+template <class C>
+struct PvChains {
+    static __host__ __device__ size_t units(const PvArgs<C>& a) { return (size_t)1 + (size_t)(a.nvar - PvVarMul<C>::first_part(a)); }
+    static BBS_HD void run(const PvArgs<C>& a, size_t t) {
+        if (t < a.n) PvT1Chain<C>::run(a, t);
+        else PvVarMul<C>::run(a, t - a.n);
+    }
+};
+// stage 2c (lane per (chunk, item)): the NFIX chunks of the fixed-base sum over {P1, Q1, H_*}: table look-ups and mixed
+// additions with inlined multipliers, nothing else -- no scratch, two wavefronts per SIMD.
+template <class C>
+struct PvFixedChunk {
     static __host__ __device__ void run(const PvArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        const int part = (int)(t / n);
-        const size_t i = t - (size_t)part * n;
+        const int chunk = (int)(t / n);
+        const size_t i = t - (size_t)chunk * n;
         if (a.status[i] != ST_PENDING) return;
-        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
-        constexpr int NC = C::FpP::NC;
-        if (part == 0) {
-            // on-curve checks of the proof's three points and their Montgomery copies, once per item
-            G1Aff<C> pa = g1a_load_canon_to_mont<C>(a.pts, n, i);
-            G1Aff<C> pb = g1a_load_canon_to_mont<C>(a.pts + (size_t)2 * NC * n, n, i);
-            G1Aff<C> pd = g1a_load_canon_to_mont<C>(a.pts + (size_t)4 * NC * n, n, i);
-            if (!g1a_on_curve<C>(pa) || !g1a_on_curve<C>(pb) || !g1a_on_curve<C>(pd)) { a.status[i] = -41; return; }
-            g1a_store_mont<C>(a.aff, n, i, pa);
-            g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, pb);
-            g1a_store_mont<C>(a.aff + (size_t)4 * N * n, n, i, pd);
-            uint32_t kc[8];
-            soa_ld<8>(a.sc + (size_t)3 * 8 * n, n, i, kc);
-            if (a.nvar == PV_NVAR) {
-                // T1 = c*Bbar + e^*Abar + r1^*D (proof_verify.rs:163-164) on one shared doubling chain
-                uint32_t ke[8], k1[8];
-                soa_ld<8>(a.sc, n, i, ke);
-                soa_ld<8>(a.sc + (size_t)1 * 8 * n, n, i, k1);
-                g1j_store<C>(out, n, i, g1_mul3_aff<C>(pb, kc, pa, ke, pd, k1, a.vtab + i, n, a.glv != 0));
-            } else {
-                // latency mode: c*Bbar alone; e^*Abar and r1^*D are parts 1 and 2 (summed by PvChallenge)
-                g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(pb, kc, a.glv != 0, a.vtab + i, n));
-            }
-        } else if (part < a.nvar) {
-            // single variable-base multiplications: r3^*D, the variable-base term of T2 (proof_verify.rs:175-182), always;
-            // in latency mode also e^*Abar (part 1) and r1^*D (part 2).  Window tables in HBM (a private table is 0.9 KB of
-            // scratch per lane of the whole kernel, and scratch x hardware queues limits the number of queues: DESIGN.md 5 rule 6)
-            const bool last = part == a.nvar - 1;
-            const int pt = last ? 2 : (part == 1 ? 0 : 2);                     // point: D, Abar, D
-            const int sc = last ? 2 : (part == 1 ? 0 : 1);                     // scalar: r3^, e^, r1^
-            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.pts + (size_t)pt * 2 * NC * n, n, i);
-            uint32_t k[8];
-            soa_ld<8>(a.sc + (size_t)sc * 8 * n, n, i, k);
-            const int slot = last ? 3 : part;                                   // vtab slot 3 is D * r3^ in both modes
-            g1j_store<C>(out, n, i, g1_mul_aff_sel_hbm<C>(p, k, a.glv != 0, a.vtab + (size_t)slot * G1_TAB * 2 * N * n + i, n));
-        } else if (a.fixwk.pts0) {
-            G1Jac<C> r = g1j_inf<C>();
-            if (part == a.nvar) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.L + 2, a.fixwk, r);
-            g1j_store<C>(out, n, i, r);
-        } else {
-            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - a.nvar));
-        }
+        G1Jac<C> r;
+        fixed_msm_chunk_to<C>(*a.cc, a.fscal, n, i, a.L + 2, chunk, r);
+        g1j_store<C>(a.partials + (size_t)(a.nvar + chunk) * 3 * N * n, n, i, r);
+    }
+};
+// the same sum as ONE tree of affine additions per item (bbs_ctx_set_fixed_base_tree; lane per item): the result is chunk 0's
+// partial sum, the other chunks are the identity
+template <class C>
+struct PvFixedTree {
+    static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] != ST_PENDING) return;
+        G1Jac<C> r = g1j_inf<C>();
+        for (int f = 1; f < NFIX; f++) g1j_store<C>(a.partials + (size_t)(a.nvar + f) * 3 * N * n, n, i, r);
+        fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.L + 2, a.fixwk, r);
+        g1j_store<C>(a.partials + (size_t)a.nvar * 3 * N * n, n, i, r);
     }
 };
 
@@ -652,6 +733,10 @@ struct PvChallenge {
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> t1 = part(0);
         for (int p = 1; p < a.nvar - 1; p++) t1 = g1j_add<C>(t1, part(p));       // latency mode: the three terms of T1
+        if (a.nvar == PV_NVAR) {                                                  // throughput form: identities unless the joint chain was not usable
+            t1 = g1j_add<C>(t1, part(PV_T1_EXTRA));
+            t1 = g1j_add<C>(t1, part(PV_T1_EXTRA + 1));
+        }
         G1Jac<C> t2 = part(a.nvar - 1);
         for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(a.nvar + f));
         G1Aff<C> T1, T2;

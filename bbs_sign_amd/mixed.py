@@ -119,35 +119,107 @@ def run_rank(batches: List[PackedBatch], inflight: int = 8) -> Dict[str, np.ndar
     return pipe.collect(pipe.submit_list())
 
 
-def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> np.ndarray:
-    """One all_gather of int8 statuses (each rank's share in plan order, padded to the largest share), then
-    sharding.merge_status.  dist=None: single process."""
-    world = len(plan)
-    curves = sorted({c for p in plan for c in p})
-    flat = np.concatenate([np.asarray(mine.get(c, np.zeros(0, dtype=np.int8)), dtype=np.int8) for c in curves]) \
-        if curves else np.zeros(0, dtype=np.int8)
-    sizes = [sum(len(p.get(c, [])) for c in curves) for p in plan]
-    assert len(flat) == sizes[rank], (len(flat), sizes[rank])
-    if dist is None:
-        gathered = [flat]
-    else:
-        import torch
-        pad = max(sizes)
-        buf = np.full(pad, -128, dtype=np.int8)          # padding = the internal "undecided" value, never a result
+class StatusExchange:
+    """The ONE collective of the path -- an all_gather of int8 statuses per list (each rank's share in plan order, padded to
+    the largest share) followed by sharding.merge_status -- taken OFF the submitting thread.
+
+    Round 4 ran it synchronously between two lists: pageable copy to the device, blocking all_gather, `.cpu()`.  With the
+    chip full of one-wavefront-per-SIMD kernels that run for milliseconds, the collective's own kernel waits for a free slot
+    and the thread that should be retiring and submitting jobs sleeps on it -- 8 % of a rank's step with ONE rank
+    (5.29 vs 4.90 ms per 8192-item list, profiles/r04_u_mixed_rccl_world1.json), and with eight ranks it would also sleep
+    until the slowest rank arrives.  Now: start() only ENQUEUES -- page-locked staging buffer, copy, all_gather
+    (async_op=True) and the copy back, all on a side stream of torch's -- and returns a handle; finish() is called one list
+    LATER, when the exchange has long completed, and merges.  Nothing on the submitting thread waits for a collective in
+    steady state.  Every rank starts its exchanges in list order, so the collectives match up.
+
+    dist=None: single process (start / finish only reorder).  CPU process groups (gloo, the world-2 / world-4 tests): the
+    same protocol with async work handles."""
+
+    def __init__(self, plan, rank: int, n_items: int, dist=None, device="cpu", slots: int = 4):
+        self.plan, self.rank, self.n_items, self.dist, self.device = plan, rank, n_items, dist, device
+        self.world = len(plan)
+        self.curves = sorted({c for p in plan for c in p})
+        self.sizes = [sum(len(p.get(c, [])) for c in self.curves) for p in plan]
+        self.pad = max(self.sizes) if self.sizes else 0
+        self.on_gpu = dist is not None and str(device).startswith("cuda")
+        self.free_slots, self.side = [], None
+        if dist is not None:
+            import torch
+            self.torch = torch
+            if self.on_gpu:
+                self.side = torch.cuda.Stream(device=device)
+            for _ in range(max(1, slots)):
+                self.free_slots.append(self._new_slot())
+
+    def _new_slot(self):
+        torch = self.torch
+        pin = self.on_gpu
+        slot = {"in_host": torch.empty(max(1, self.pad), dtype=torch.int8, pin_memory=pin),
+                "out_host": torch.empty(max(1, self.pad) * self.world, dtype=torch.int8, pin_memory=pin)}
+        if self.on_gpu:
+            slot["in_dev"] = torch.empty(max(1, self.pad), dtype=torch.int8, device=self.device)
+            slot["out_dev"] = torch.empty(max(1, self.pad) * self.world, dtype=torch.int8, device=self.device)
+            slot["done"] = torch.cuda.Event()
+        return slot
+
+    def _flat(self, mine):
+        flat = np.concatenate([np.asarray(mine.get(c, np.zeros(0, dtype=np.int8)), dtype=np.int8) for c in self.curves]) \
+            if self.curves else np.zeros(0, dtype=np.int8)
+        assert len(flat) == self.sizes[self.rank], (len(flat), self.sizes[self.rank])
+        return flat
+
+    def start(self, mine: Dict[str, np.ndarray]):
+        """Enqueue the exchange of this rank's statuses of one list; returns a handle for finish()."""
+        flat = self._flat(mine)
+        if self.dist is None:
+            return {"local": flat}
+        torch, dist = self.torch, self.dist
+        slot = self.free_slots.pop() if self.free_slots else self._new_slot()
+        buf = slot["in_host"].numpy()
+        buf[:] = -128                                       # padding = the internal "undecided" value, never a result
         buf[:len(flat)] = flat
-        t = torch.from_numpy(buf).to(device)
-        outs = [torch.empty(pad, dtype=torch.int8, device=device) for _ in range(world)]
-        dist.all_gather(outs, t)
-        gathered = [o.cpu().numpy()[:sizes[r]] for r, o in enumerate(outs)]
-    per_rank = []
-    for r, p in enumerate(plan):
-        d, at = {}, 0
-        for c in curves:
-            k = len(p.get(c, []))
-            d[c] = gathered[r][at:at + k]
-            at += k
-        per_rank.append(d)
-    return merge_status(plan, per_rank, n_items)
+        if self.on_gpu:
+            with torch.cuda.stream(self.side):
+                slot["in_dev"].copy_(slot["in_host"], non_blocking=True)
+                work = dist.all_gather_into_tensor(slot["out_dev"], slot["in_dev"], async_op=True)
+                work.wait()                                 # RCCL: orders the side stream behind the collective, does not block the host
+                slot["out_host"].copy_(slot["out_dev"], non_blocking=True)
+                slot["done"].record(self.side)
+            slot["work"] = None
+        else:
+            outs = list(slot["out_host"].view(self.world, -1).unbind(0))
+            slot["work"] = dist.all_gather(outs, slot["in_host"], async_op=True)
+        return slot
+
+    def finish(self, handle) -> np.ndarray:
+        """Wait for the exchange started as `handle` (normally long complete) and merge -> statuses of the whole list."""
+        if "local" in handle:
+            gathered = [handle["local"]]
+        else:
+            if self.on_gpu:
+                handle["done"].synchronize()
+            else:
+                handle["work"].wait()
+            rows = handle["out_host"].numpy().reshape(self.world, -1)
+            gathered = [rows[r, :self.sizes[r]].copy() for r in range(self.world)]
+            handle["work"] = None
+            self.free_slots.append(handle)
+        per_rank = []
+        for r, p in enumerate(self.plan):
+            d, at = {}, 0
+            for c in self.curves:
+                k = len(p.get(c, []))
+                d[c] = gathered[r][at:at + k]
+                at += k
+            per_rank.append(d)
+        return merge_status(self.plan, per_rank, self.n_items)
+
+
+def gather_statuses(plan, rank: int, mine: Dict[str, np.ndarray], n_items: int, dist=None, device="cpu") -> np.ndarray:
+    """One all_gather of int8 statuses, then sharding.merge_status, start to finish (a caller with ONE list; a loop over
+    lists keeps a StatusExchange and finishes every exchange one list late).  dist=None: single process."""
+    x = StatusExchange(plan, rank, n_items, dist, device, slots=1)
+    return x.finish(x.start(mine))
 
 
 def proof_verify_mixed(engines, curve_of_item: Sequence[str], fetch_items, world: int = 1, rank: int = 0, dist=None,

@@ -59,16 +59,30 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
     pipe = mixed.ListPipeline(batches, depth)
     ahead = getattr(args, "lists_in_flight", None) or pipe.lists_in_flight_for(max(depth, 8))     # measured: 8192-item share 7.3 / 5.2 / 5.0 / 4.9 ms per list at 1 / 2 / 3 / 4 lists ahead (profiles/r04_b_*)
 
+    exch = mixed.StatusExchange(plan, rank, total, dist, red_dev)
+
     def run_lists(count):
-        """`count` passes over the list, `ahead` of them submitted before the oldest is collected: while the statuses of
-        list k are gathered (one all_gather) and merged, the jobs of lists k + 1 .. k + ahead - 1 keep the device busy."""
-        out, handles = [], []
+        """`count` passes over the list, `ahead` of them submitted before the oldest is collected.  The statuses of list k
+        are exchanged (ONE all_gather of int8) asynchronously: started when the list's jobs have delivered, finished and
+        merged one list later -- the submitting thread goes on retiring and submitting, it never sleeps on the collective
+        (mixed.StatusExchange).  Merged statuses come back in list order."""
+        out, handles, exchange = [], [], None
+
+        def collected(h):
+            nonlocal exchange
+            started = exch.start(pipe.collect(h))
+            if exchange is not None:
+                out.append(exch.finish(exchange))
+            exchange = started
+
         for k in range(count):
             handles.append(pipe.submit_list())
             if len(handles) >= ahead:
-                out.append(mixed.gather_statuses(plan, rank, pipe.collect(handles.pop(0)), total, dist, red_dev))
+                collected(handles.pop(0))
         while handles:
-            out.append(mixed.gather_statuses(plan, rank, pipe.collect(handles.pop(0)), total, dist, red_dev))
+            collected(handles.pop(0))
+        if exchange is not None:
+            out.append(exch.finish(exchange))
         return out
 
     if args.warmup < 0 or args.steps < 1:
@@ -100,7 +114,8 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
                        "batches_per_rank": len(batches), "batch_sizes_rank0": sorted({b.n for b in batches}, reverse=True),
                        "items_per_rank": sum(b.n for b in batches), "batches_in_flight": depth, "lists_in_flight": ahead,
                        "retire_order": "completion (bbs_jobs_wait_any)",
-                       "backend": args.backend if world > 1 else None,
+                       "status_exchange": "asynchronous: one all_gather of int8 per list on a side stream, merged one list later",
+                       "backend": args.backend if (world > 1 or dist is not None) else None,
                        "fixed_base_window_bits": {"bls12_381": args.window_bits, "bn254": min(args.window_bits, 16)}},
             "checks": {"merged_statuses_exact_every_step": True, "corrupted": "every 16th global item"},
             "prepare_s_rank0": t_prep}))

@@ -73,6 +73,7 @@ extern "C" {
 #define BBS_E_NO_DEVICE (-104)
 #define BBS_E_NOMEM (-105)
 #define BBS_E_UNSUPPORTED (-106) /* reserved: operation not available for this curve */
+#define BBS_E_NO_RESOURCES (-107)/* the hardware-queue budget of the device is spent (bbs_runtime_queue_budget): nothing was created */
 
 typedef struct bbs_ctx bbs_ctx;
 typedef struct bbs_job bbs_job;
@@ -95,13 +96,25 @@ int bbs_runtime_hw_queues(void);
  * library is loaded: the runtime's pool is then 4 hardware queues, several jobs share one, 1.30 M proof_verify/s instead
  * of 1.50 M): up to k job streams per device get a hardware queue OF THEIR OWN (streams created with an all-ones
  * compute-unit mask, which the runtime does not draw from the pool) -- 1.50 M/s whatever GPU_MAX_HW_QUEUES says
- * (profiles/r04_f_dedicated_queues.log).  k = 0: off (the default); 12 is a good value, 16 the most accepted: every hardware
- * queue reserves scratch memory for the largest kernel it has run, and beyond ~20 queues in all (pool + dedicated) the runtime
- * runs out and ABORTS the process.
+ * (profiles/r04_f_dedicated_queues.log).  k = 0: off (the default); 12 is a good value, 16 the most accepted.  k is a WISH:
+ * every hardware queue reserves scratch memory for the largest kernel frame it has run, pool + dedicated queues x that frame
+ * is a budget, and past it the runtime first collapses and then ABORTS the process -- so the library grants
+ * min(k, bbs_runtime_queue_budget's dedicated_cap) and serves further streams from the pool (round 5; before that, 16 on top of
+ * a pool of 14 could abort).
  * Call before the first context is created (streams are recycled); BBS_DEDICATED_QUEUES=k in the environment does the same
  * (1 means 12).  Caveat: such streams synchronise with the legacy default stream (the runtime offers no non-blocking flag
- * for them): a process that also runs its own kernels on stream 0 serialises them with the jobs. */
+ * for them): a process that also runs its own kernels on stream 0 -- torch and RCCL work on the default stream -- serialises
+ * them with the jobs. */
 int bbs_runtime_set_dedicated_queues(int k);
+/* The hardware-queue budget of a device, as the library enforces it: *scratch_bytes_per_lane = the largest kernel frame of
+ * this library (every kernel is asked at start-up), *total = hardware queues (pooled + dedicated) that frame allows within
+ * 8.5 % of the device's memory (queues x bytes per lane x 64 lanes x wave slots; 25 on MI355X at 1.8 KB), *pool =
+ * GPU_MAX_HW_QUEUES as the environment has it (4 when unset), *dedicated_cap = max(0, total - pool).  If the POOL alone exceeds
+ * the budget (an explicit GPU_MAX_HW_QUEUES=32) the library creates at most `total` streams: a job that gets none of its own
+ * shares its context's stream and runs its side-stream stages in order on it, and bbs_ctx_create fails with
+ * BBS_E_NO_RESOURCES once even the context's stream cannot be had -- slower or refused, never the runtime's abort.  Any
+ * pointer may be NULL.  BBS_E_NO_DEVICE for a device that does not exist. */
+int bbs_runtime_queue_budget(int device_id, int* total, int* pool, int* dedicated_cap, size_t* scratch_bytes_per_lane);
 int bbs_device_count(void);
 size_t bbs_device_free_bytes(int device_id);          /* device memory free right now (0: no such device) */
 
@@ -391,13 +404,18 @@ int bbs_job_run(bbs_job* job);                       /* asynchronous */
 int bbs_job_wait(bbs_job* job);
 /* Completion-order retire for a serving loop that keeps several batches in flight (the reference has no counterpart: its
  * calls are synchronous, src/proof_verify.rs:19-61).  Jobs submitted together do not finish in submission order -- they
- * share the chip -- and a loop that always waits for its OLDEST job runs in convoys (profiles/r03_pt_pipeline_trace_k20.log).
+ * share the chip.  What completion order buys is measured: it matters where jobs differ in length or belong to different
+ * lists (pipelined lists of BASELINE configs[4]: 7.3 -> 4.9 ms per list, an issuer's groups); on a loop of UNIFORM jobs, the
+ * headline loop, it changes nothing (1.42 - 1.44 M/s either way, profiles/r04_b_bench_{any,fifo}_*.json: the convoys are
+ * made on the GPU).
  * bbs_jobs_wait_any sleeps until ONE of jobs[0 .. n) -- entries may be NULL; jobs that were never run are ignored -- has
  * finished everything enqueued for it, then does what bbs_job_wait does for that job (delivers statuses / records of the
  * submit forms, BBS_E_STATE if an item was left undecided) and stores its position in *index_out; if several have
  * finished, the one that finished first.  The caller then frees or re-runs that job and calls again with the rest.
  * Event-driven: a host function placed on the job's stream behind its last operation wakes the waiter; nothing polls the
  * device.  BBS_E_STATE if no job of the set has been run.  Jobs of different contexts, curves and devices may be mixed.
+ * A job whose last bbs_job_run could not be enqueued completely counts as finished WITH AN ERROR: it is handed out at once
+ * (*index_out set) and the call -- like bbs_job_wait on it -- returns BBS_E_HIP and delivers nothing (it never blocks a set).
  * bbs_job_poll: 1 if the job has finished everything enqueued for it (bbs_job_wait will not block), 0 if not. */
 int bbs_jobs_wait_any(bbs_job* const* jobs, size_t n, size_t* index_out);
 int bbs_job_poll(const bbs_job* job);
@@ -498,8 +516,9 @@ size_t bbs_issuer_table_bytes(bbs_issuer* issuer);
  * context of the issuer, present and future */
 int bbs_issuer_set_modes(bbs_issuer* issuer, int latency_mode, int batch_verification, int points_in_subgroup);
 /* the context serving items of `message_count` messages (created if needed), e.g. to warm it up before traffic arrives, or
- * to drive it directly (one call at a time, and not while the issuer routes lists to it).  A context handed out this way
- * is never evicted. */
+ * to drive it directly (one call at a time, and not while the issuer routes lists to it or a bbs_issuer_set_* call is made).
+ * A context handed out this way is never evicted, and bbs_issuer_set_public_key / _set_secret_key / _set_modes bring it up to
+ * the new configuration BEFORE they return (the other contexts pick it up at their next use). */
 int bbs_issuer_context(bbs_issuer* issuer, size_t message_count, bbs_ctx** out);
 size_t bbs_issuer_context_count(bbs_issuer* issuer);
 /* proof_verify (src/proof_verify.rs:19-61); message count of item i = (its proof's commitments) + (its disclosed indexes) */

@@ -878,7 +878,13 @@ def check_mixed_curves_in_flight(lib_path=None, n=1024, per_curve=3, rounds=4):
 
 def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, curve="bls12_381"):
     """EVERY item of a BASELINE-shaped batch against the plain-C oracle (oracle/c), bit for bit:
-    signatures, proofs and proof_verify booleans incl. corrupted items."""
+    signatures, proofs and proof_verify booleans incl. corrupted items.  Two kinds of corrupted proofs: every 7th fails
+    BEFORE the pairing (r1^ changed: the challenge no longer matches, src/proof_verify.rs:108-110), and a handful are
+    self-consistent proofs of FORGED signatures (A + P1): their challenge matches and only the PER-ITEM pairing product can
+    reject them (:112-115).  Those sit where a lane mapping could go wrong: last / first six-lane group of neighbouring
+    pairing wavefronts (items 9 | 10 -- ten items per wavefront), last / first lane of neighbouring MSM wavefronts (63 | 64),
+    the last full pairing wavefront's last group and the ragged last wavefront's first and last group (n - 7, n - 6, n - 1:
+    4089, 4090, 4095 at n = 4096)."""
     import concurrent.futures as cf
     import os
     from oracle import c_port
@@ -892,9 +898,17 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, c
     proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
     assert (st == 1).all()
     dm = [m[:R] for m in msgs]
+    planted = sorted({k for k in (9, 10, 63, 64, n // 2 - 1, n - 7, n - 6, n - 1) if 0 <= k < n})
+    fsig = {k: Signature(c.g1_add(sigs[k].a, c.g1), sigs[k].e) for k in planted}
+    fps, fst = eng.core_proof_gen_batch([fsig[k] for k in planted], [msgs[k] for k in planted], [disclosed[k] for k in planted],
+                                        [rnds[k] for k in planted])
+    assert (fst == 1).all()
+    for k, fp in zip(planted, fps):
+        proofs[k] = fp
     for i in range(0, n, 7):
-        proofs[i].r1_cap = (proofs[i].r1_cap + 1) % c.r
-    st = eng.core_proof_verify_batch(proofs, dm, disclosed)
+        if i not in fsig:
+            proofs[i].r1_cap = (proofs[i].r1_cap + 1) % c.r
+    st = eng.core_proof_verify_batch(proofs, dm, disclosed)              # per-item mode: every item its own pairing product
     # core_verify (src/verify.rs:53-93) of every item, every 7th signature forged (A + P1 / e + 1 alternating)
     vsigs = list(sigs)
     for i in range(0, n, 7):
@@ -903,13 +917,13 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, c
 
     def one(i):
         s = c_port.core_sign(sk, gens, b"", msgs[i], api_id)
-        good = bbs.Signature(sigs[i].a, sigs[i].e)
+        good = bbs.Signature(fsig[i].a, fsig[i].e) if i in fsig else bbs.Signature(sigs[i].a, sigs[i].e)   # the signature the proof was made from
         vf = c_port.core_verify(pk, bbs.Signature(vsigs[i].a, vsigs[i].e), gens, b"", msgs[i], api_id)
         p = c_port.core_proof_gen(pk, good, b"", gens, b"", msgs[i], disclosed[i], api_id, rnds[i])
         mine = bbs.Proof(proofs[i].a_bar, proofs[i].b_bar, proofs[i].d, proofs[i].e_cap, proofs[i].r1_cap, proofs[i].r3_cap,
                          proofs[i].commitments, proofs[i].challenge)
         v = c_port.core_proof_verify(pk, mine, gens, b"", b"", dm[i], disclosed[i], api_id)
-        if i % 7 == 0:
+        if i % 7 == 0 and i not in fsig:
             p.r1_cap = (p.r1_cap + 1) % c.r
         return (s.a, s.e) == (sigs[i].a, sigs[i].e), p == mine, int(v) == int(st[i]), int(vf) == int(vst[i])
 
@@ -919,7 +933,7 @@ def check_batch_vs_c_oracle(lib_path=None, n=512, L=32, R=8, window_bits=None, c
     assert all(r[1] for r in res), "proof_gen mismatch"
     assert all(r[2] for r in res), "proof_verify mismatch"
     assert all(r[3] for r in res), "verify mismatch"
-    assert [int(x) for x in st] == [0 if i % 7 == 0 else 1 for i in range(n)]
+    assert [int(x) for x in st] == [0 if (i % 7 == 0 or i in fsig) else 1 for i in range(n)]
     assert [int(x) for x in vst] == [0 if i % 7 == 0 else 1 for i in range(n)]
     # the opt-in batch-verification mode returns the same booleans on the same (partly corrupted) batch
     eng.set_batch_verification(True)
