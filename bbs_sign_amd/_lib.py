@@ -168,7 +168,11 @@ def load_library(path=None):
             "%s not found: the HIP extension is not built; there is no CPU fallback "
             "(build it with __graft_entry__.build())" % path)
     lib = ctypes.CDLL(path)
+    # (A/B against an OLDER build of the library, development override only: symbols that build does not have yet)
+    optional = set(filter(None, os.environ.get("BBS_SIGN_AMD_LIB_OPTIONAL", "").split(","))) if os.environ.get("BBS_SIGN_AMD_LIB") else set()
     for name, (res, args) in SIGNATURES.items():
+        if name in optional and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

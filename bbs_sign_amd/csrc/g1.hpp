@@ -158,8 +158,15 @@ BBS_HD uint32_t limb_bit(const uint32_t* s, int i) {
 // non-adjacent form of k (digits in {-1,0,1}: digit_{i-1} = bit_i(3k) - bit_i(k)), mixed additions
 // of +-P.  ~256 doublings + ~85 additions; the group element equals ark-ec's
 // `Projective::mul_bigint` result (plain double-and-add in the reference).
+// (INLINED, round 5.  As a called function it was reached from two places of one kernel -- stage PvChains: the fall-back of
+// T1's joint chain and the fall-back of the single multiplications, both inlined into the kernel, both in divergent code -- and
+// that kernel then computed wrong sums for EVERY lane of a wavefront in which one lane took the call (MI355X, ROCm 7.2: all
+// items of tests/parity_cases.py::check_batch_verification's identity-point batch read "challenge mismatch"; the kernels with
+// one such call site each, and the form that reaches it through g1_mul_aff_tab_to, were right).  No undefined behaviour was
+// found in the source, the ISA at the call sites looks orderly; inlining removes the call and the difference
+// (profiles/r05_b_pvchains_identity_point.log).  The body is one doubling and one mixed addition in a rolled loop.)
 template <class C>
-BBS_HD_NOINLINE G1Jac<C> g1_mul_aff_naf(const G1Aff<C>& p, const uint32_t* k) {
+BBS_HD G1Jac<C> g1_mul_aff_naf(const G1Aff<C>& p, const uint32_t* k) {
     uint32_t h[9];
     uint64_t c = 0;
 #pragma unroll
