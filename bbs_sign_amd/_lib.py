@@ -19,6 +19,15 @@ vp = ctypes.c_void_p
 sz = ctypes.c_size_t
 ci = ctypes.c_int
 
+class PvList(ctypes.Structure):
+    """struct bbs_pv_list of include/bbs_sign_amd.h: the items of one curve of a list (bbs_pool_proof_verify)"""
+    _fields_ = [("curve", ctypes.c_int), ("n", ctypes.c_size_t),
+                ("proofs_fixed", c_u8p), ("commitments", c_u8p), ("commit_off", c_u64p),
+                ("disclosed_msgs", c_u8p), ("dmsg_off", c_u64p), ("disclosed_idx", c_u64p), ("didx_off", c_u64p),
+                ("headers", c_u8p), ("hdr_off", c_u64p), ("ph", c_u8p), ("ph_off", c_u64p),
+                ("global_index", c_u64p), ("status", c_i8p)]
+
+
 # name -> (restype, argtypes); every symbol include/bbs_sign_amd.h declares
 SIGNATURES = {
     "bbs_fp_bytes": (sz, [ci]),
@@ -104,6 +113,15 @@ SIGNATURES = {
     "bbs_core_proof_gen_batch": (ci, [vp, sz, c_u8p, c_u8p, c_u64p, c_u64p, c_u64p, c_u8p, c_u64p,
                                       c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_u64p, c_i8p]),
     "bbs_runtime_set_dedicated_queues": (ci, [ci]),
+    "bbs_pool_create": (ci, [ctypes.POINTER(ci), sz, ctypes.POINTER(vp)]),
+    "bbs_pool_destroy": (None, [vp]),
+    "bbs_pool_device_count": (sz, [vp]),
+    "bbs_pool_set_window_bits": (ci, [vp, ci, ci]),
+    "bbs_pool_set_generators": (ci, [vp, ci, c_u8p, sz, c_u8p, sz]),
+    "bbs_pool_set_public_key": (ci, [vp, ci, c_u8p, ci]),
+    "bbs_pool_set_inflight": (ci, [vp, ci]),
+    "bbs_pool_context": (ci, [vp, ci, sz, ctypes.POINTER(vp)]),
+    "bbs_pool_proof_verify": (ci, [vp, ctypes.POINTER(PvList), sz, sz]),
     "bbs_runtime_queue_budget": (ci, [ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(sz)]),
     "bbs_device_free_bytes": (sz, [ci]),
     "bbs_ctx_table_bytes": (sz, [vp]),

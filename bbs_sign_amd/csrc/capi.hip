@@ -3,12 +3,16 @@
 #include "host_h2c.hpp"
 #include "host_codec.hpp"
 #include "issuer.hpp"
+#include "pool.hpp"
 
-// Many independent batches are kept in flight, one HIP stream pair each.  The HIP runtime maps the streams of a
-// process onto 4 hardware queues unless told otherwise, and a long narrow kernel then blocks the streams sharing
-// its queue (measured on MI355X: 645k -> 780k proof_verify/s; 14: DESIGN.md 5 rule 6).  Takes effect only if this library
-// is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
-__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "14", 0); }
+// Many independent batches are kept in flight, every job on streams of its own (proof_verify: three -- the fixed-base chain,
+// T1's doubling chain, the pairing).  The HIP runtime maps the streams of a process onto 4 hardware queues unless told
+// otherwise, and a long narrow kernel then blocks the streams sharing its queue (measured on MI355X: 645k -> 780k
+// proof_verify/s in round 1).  20 (round 5; 14 before): six jobs in flight are 18 streams, and with the largest kernel frame of
+// the library at 1.8 KB the scratch budget allows 25 hardware queues (runtime.hpp queue_budget; DESIGN.md 5 rule 6) --
+// 1.48 / 1.53 / 1.55 / 1.53 M proof_verify/s at 14 / 18 / 20 / 24 (profiles/r05_a_ab_split_msm_layouts.log).  Takes effect only if
+// this library is loaded before the process makes its first HIP call; an explicit setting in the environment wins.
+__attribute__((constructor)) static void bbs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
 // what the process environment says now (0 = unset): a service can log it at start-up and, when it reads 4 or was set
 // after the first HIP call, prefer larger batches (two 16384-item batches in flight fill the chip: DESIGN.md 6a)
 extern "C" __attribute__((visibility("default"))) int bbs_runtime_hw_queues(void) {
@@ -1343,4 +1347,44 @@ int bbs_pairing_product2_is_one_batch(bbs_ctx* ctx, size_t n, const uint8_t* pa,
 }
 
 }  // extern "C"
+// ---- pool: a list of proofs over several GPUs (pool.hpp) ----------------------------------------
+int bbs_pool_create(const int* device_ids, size_t n_devices, bbs_pool** out) {
+    if (!device_ids || !n_devices || n_devices > 64 || !out) return BBS_E_ARG;
+    const int have = rt::device_count();
+    for (size_t d = 0; d < n_devices; d++) if (device_ids[d] < 0 || device_ids[d] >= have) return BBS_E_NO_DEVICE;
+    auto p = std::unique_ptr<bbs_pool>(new bbs_pool());
+    p->devices.assign(device_ids, device_ids + n_devices);
+    *out = p.release();
+    return BBS_OK;
+}
+void bbs_pool_destroy(bbs_pool* pool) { delete pool; }
+size_t bbs_pool_device_count(const bbs_pool* pool) { return pool ? pool->devices.size() : 0; }
+int bbs_pool_set_window_bits(bbs_pool* pool, int curve, int bits) {
+    if (!pool) return BBS_E_ARG;
+    return pool->each(curve, [&](bbs_ctx* c) { return bbs_ctx_set_window_bits(c, bits); });
+}
+int bbs_pool_set_generators(bbs_pool* pool, int curve, const uint8_t* g, size_t count, const uint8_t* api_id, size_t api_id_len) {
+    if (!pool) return BBS_E_ARG;
+    return pool->each(curve, [&](bbs_ctx* c) { return bbs_ctx_set_generators(c, g, count, api_id, api_id_len); });
+}
+int bbs_pool_set_public_key(bbs_pool* pool, int curve, const uint8_t* pk, int is_identity) {
+    if (!pool) return BBS_E_ARG;
+    return pool->each(curve, [&](bbs_ctx* c) { return bbs_ctx_set_public_key(c, pk, is_identity); });
+}
+int bbs_pool_set_inflight(bbs_pool* pool, int jobs_per_member) {
+    if (!pool || jobs_per_member < 1 || jobs_per_member > 64) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(pool->mu);
+    pool->inflight = jobs_per_member;
+    return BBS_OK;
+}
+int bbs_pool_context(bbs_pool* pool, int curve, size_t member, bbs_ctx** out) {
+    if (!pool || !out || member >= pool->devices.size()) return BBS_E_ARG;
+    std::lock_guard<std::mutex> g(pool->mu);
+    if (int rc = pool->ensure(curve)) return rc;
+    *out = pool->ctx[bbs_pool::curve_slot(curve)][member];
+    return BBS_OK;
+}
+int bbs_pool_proof_verify(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch) {
+    return pool_proof_verify(pool, lists, n_lists, max_batch);
+}
 #pragma GCC visibility pop

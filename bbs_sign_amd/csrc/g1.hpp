@@ -112,8 +112,10 @@ BBS_HD G1Jac<C> g1j_add_aff(const G1Jac<C>& p, const G1Aff<C>& q) {
 // add-2007-bl: Jacobian + Jacobian, 11M + 5S, with the exceptional cases resolved
 // TAG: a separate instance for callers that live in register-capped kernels (the register budget of a device function is
 // the loosest one among the kernels that reach it, and the kernel is charged the maximum over everything it can reach)
-template <class C, int TAG = 0>
-BBS_HD_NOINLINE G1Jac<C> g1j_add(const G1Jac<C>& p, const G1Jac<C>& q) {
+// (_i: the body, inlined -- for the lane-per-item stages that sum a handful of partial sums: a call hands both operands and
+// the result through the caller's frame, 624 bytes of the callee's frame on top; the multipliers inside stay calls)
+template <class C>
+BBS_HD G1Jac<C> g1j_add_i(const G1Jac<C>& p, const G1Jac<C>& q) {
     if (g1j_is_inf<C>(q)) return p;
     if (g1j_is_inf<C>(p)) return q;
     Fp<C> Z1Z1 = fe_sqr<FP>(p.z);
@@ -138,6 +140,8 @@ BBS_HD_NOINLINE G1Jac<C> g1j_add(const G1Jac<C>& p, const G1Jac<C>& q) {
     r.z = fe_mul<FP>(fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(fe_add<FP>(p.z, q.z)), Z1Z1), Z2Z2), H);
     return r;
 }
+template <class C, int TAG = 0>
+BBS_HD_NOINLINE G1Jac<C> g1j_add(const G1Jac<C>& p, const G1Jac<C>& q) { return g1j_add_i<C>(p, q); }
 
 template <class C>
 BBS_HD_NOINLINE G1Aff<C> g1j_to_aff(const G1Jac<C>& p) {
@@ -738,32 +742,35 @@ BBS_HD G1Jac<C> g1_mul3_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<
                       g1_mul_aff_tab<C, AtHbm<C>>(p2, k2, w2));
 }
 
-// k0 P0 + k1 P1 on ONE shared doubling chain: the two-term form of g1_mul3_aff_fast (its own function so that the
-// three-term one -- proof_verify's T1, the headline path -- is compiled exactly as before).  Used by proof_gen's throughput
+// k0 P0 + k1 P1 on ONE shared doubling chain: the two-term form of g1_mul3_tabs_fast.  Used by proof_gen's throughput
 // form: Bbar = (r1 r2) B - (e r1 r2) A and T1 = (r1~ r2) B + (e~ r1 r2) A (src/proof_gen.rs:254-258 restructured over A and
-// B) are two chains of ~252 doublings instead of four.  Tables in the caller's HBM buffer (2 * G1_TAB * 2N words, stride apart).
+// B) are two chains of ~252 doublings instead of four.  Tables in the caller's HBM buffer (2 * G1_TAB * 2N words, stride apart);
+// ENTRY 0 OF TABLE j HOLDS P_j ON ENTRY.  Inlined into its one device caller (stage PgVarPart), loops over the tables rolled
+// and free of indexed locals, as g1_mul3_tabs_fast (round 5: its frame was 1216 bytes below the kernel's).
 template <class C, bool GLV = false>
-BBS_HD_NOINLINE bool g1_mul2_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
-                                       uint32_t* tabs, size_t stride, G1Jac<C>& out) {
+BBS_HD bool g1_mul2_tabs_fast(const uint32_t* k0, const uint32_t* k1, uint32_t* tabs, size_t stride, G1Jac<C>& out) {
 #ifdef BBS_G1_MUL_NAF
     return false;
 #endif
     constexpr int N = C::FpP::N;
-    Fp<C> zc[2];
-    const G1Aff<C>* ps[2] = {&p0, &p1};
+    constexpr size_t TW = (size_t)G1_TAB * 2 * N;
+    Fp<C> zc0 = fe_one<FP>(), zc1 = zc0;
     bool ok = true;
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
-        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-        ok = ok && g1_odd_table<C>(*ps[j], tab, zc[j]);
+        TabHbm<C> tab{tabs + (size_t)j * TW * stride, stride};
+        Fp<C> z = fe_one<FP>();
+        ok = g1_odd_table<C>(tab.ld(0), tab, z) && ok;
+        zc0 = fe_select<FP>(j == 0, z, zc0);
+        zc1 = fe_select<FP>(j == 1, z, zc1);
     }
     if (!ok) return false;
     // point (x, y) of table j is Jacobian (x, y, zc_j) = (x t^2, y t^3, zc_0 zc_1) with t = the other table's scale
-    const Fp<C> zall = fe_mul<FP>(zc[0], zc[1]);
+    const Fp<C> zall = fe_mul<FP>(zc0, zc1);
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
-        TabHbm<C> tab{tabs + (size_t)j * G1_TAB * 2 * N * stride, stride};
-        const Fp<C> tj = zc[1 - j];
+        TabHbm<C> tab{tabs + (size_t)j * TW * stride, stride};
+        const Fp<C> tj = fe_select<FP>(j == 0, zc1, zc0);
         const Fp<C> t2 = fe_sqr<FP>(tj), t3 = fe_mul<FP>(t2, tj);
 #pragma unroll 1
         for (int e = 0; e < G1_TAB; e++) {
@@ -838,17 +845,17 @@ BBS_HD_NOINLINE bool g1_mul2_aff_fast(const G1Aff<C>& p0, const uint32_t* k0, co
     out = r;
     return true;
 }
+// host self-test / reference form: the joint chain, or two separate multiplications when a table hit an exceptional case
 template <class C>
 BBS_HD G1Jac<C> g1_mul2_aff(const G1Aff<C>& p0, const uint32_t* k0, const G1Aff<C>& p1, const uint32_t* k1,
                              uint32_t* tabs, size_t stride, bool glv = false) {
+    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    { TabHbm<C> t0{tabs, stride}, t1{tabs + TW * stride, stride}; t0.st(0, p0); t1.st(0, p1); }
     G1Jac<C> r;
     if constexpr (C::K::HAS_GLV) {
-        if (glv && g1_mul2_aff_fast<C, true>(p0, k0, p1, k1, tabs, stride, r)) return r;
+        if (glv && g1_mul2_tabs_fast<C, true>(k0, k1, tabs, stride, r)) return r;
     }
-    if (!glv && g1_mul2_aff_fast<C>(p0, k0, p1, k1, tabs, stride, r)) return r;
-    // a table hit an exceptional case (identity, point of small order): two separate multiplications, each of which falls
-    // back to the generic chain on its own; their tables reuse the caller's buffer
-    constexpr size_t TW = (size_t)G1_TAB * 2 * C::FpP::N;
+    if (!glv && g1_mul2_tabs_fast<C>(k0, k1, tabs, stride, r)) return r;
     const AtHbm<C> w0{tabs, stride}, w1{tabs + TW * stride, stride};
     return g1j_add<C, 1>(g1_mul_aff_tab<C, AtHbm<C>>(p0, k0, w0), g1_mul_aff_tab<C, AtHbm<C>>(p1, k1, w1));
 }

@@ -180,7 +180,7 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     // the variable-base parts: one lane per multiplication for a job that is alone (shortest longest lane), Bbar and T1 as
     // joint chains otherwise (14 % fewer instructions per proof)
     a.nvar = job->latency_form ? PG_NVAR : PG_NVAR_JOINT;
-    a.vtab = job->template scratch<uint32_t>((size_t)2 * 2 * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);
+    a.vtab = job->template scratch<uint32_t>((size_t)PG_NVAR * G1_TAB * 2 * N * std::max<size_t>(n, 1), rc);
     a.ctab = nullptr; a.comb_ok = nullptr;
     static const bool use_comb = [] { const char* v = getenv("BBS_PG_COMB"); return !v || atoi(v) != 0; }();     // A/B: BBS_PG_COMB=0
     // (where the GLV split is on -- BN254 always, BLS12-381 for vouched or decoded points -- the comb runs over the 64-bit halves
@@ -208,10 +208,10 @@ int pg_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     if (rt::launch<PgIngest<C>>(job->stream(), ia, n)) return BBS_E_HIP;
     PgJob<C>* j = job.get();
     j->stages.push_back({"pg_scalars", [j]() { return rt::launch<PgScalars<C>>(j->stream(), j->a, j->n); }});
-    j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->stream(), j->a, j->n * NFIX); }});
+    j->stages.push_back({"pg_b_parts", [j]() { return rt::launch<PgBPart<C>>(j->stream(), j->a, j->n * (size_t)(2 * NFIX)); }});
     j->stages.push_back({"pg_b_combine", [j]() { return rt::launch<PgBCombine<C>>(j->stream(), j->a, j->n); }});
     if (j->a.ctab) j->stages.push_back({"pg_tables", [j]() { return rt::launch<PgTables<C>>(j->stream(), j->a, j->n * 2); }});
-    j->stages.push_back({"pg_msm_parts", [j]() { return rt::launch<PgMsmPart<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar + NFIX)); }});
+    j->stages.push_back({"pg_var_parts", [j]() { return rt::launch<PgVarPart<C>>(j->stream(), j->a, j->n * (size_t)j->a.nvar); }});
     j->stages.push_back({"pg_finalize", [j]() { return rt::launch<PgFinalize<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"pg_emit", [j]() { return rt::launch<PgEmit<C>>(j->stream(), j->a, j->n); }});
     *out = job.release();

@@ -133,7 +133,12 @@ int msm_batch(Ctx<C>* ctx, size_t n, const uint8_t* fs, size_t nf, const uint8_t
             dW2.alloc(std::max<size_t>(T / 2, 1) * N * n * 4)) return BBS_E_NOMEM;
         a.fixwk = FixTreeWork<C>{dW0.as<uint32_t>(), dW1.as<uint32_t>(), dW2.as<uint32_t>()};
     }
-    if (rt::launch<MsmPart<C>>(ctx->stream, a, n * (nv + NFIX)) || rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
+    DevBuf dTab;
+    if (dTab.alloc(std::max<size_t>(nv, 1) * G1_TAB * 2 * N * std::max<size_t>(n, 1) * 4)) return BBS_E_NOMEM;
+    a.vtab = dTab.as<uint32_t>();
+    if (rt::launch<MsmVarMul<C>>(ctx->stream, a, n * nv)) return BBS_E_HIP;
+    if (a.fixwk.pts0 ? rt::launch<MsmFixedTree<C>>(ctx->stream, a, n) : rt::launch<MsmFixedChunk<C>>(ctx->stream, a, n * NFIX)) return BBS_E_HIP;
+    if (rt::launch<MsmCombine<C>>(ctx->stream, a, n) || rt::sync(ctx->stream)) return BBS_E_HIP;
     std::vector<uint32_t> w((size_t)2 * NC * n);
     if (rt::d2h(w.data(), dOut.p, w.size() * 4, ctx->stream) || rt::d2h(status, dSt.p, n, ctx->stream)) return BBS_E_HIP;
     if (!statuses_final(status, n)) return BBS_E_STATE;

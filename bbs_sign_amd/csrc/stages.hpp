@@ -732,13 +732,13 @@ struct PvChallenge {
         if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> t1 = part(0);
-        for (int p = 1; p < a.nvar - 1; p++) t1 = g1j_add<C>(t1, part(p));       // latency mode: the three terms of T1
+        for (int p = 1; p < a.nvar - 1; p++) t1 = g1j_add_i<C>(t1, part(p));       // latency mode: the three terms of T1
         if (a.nvar == PV_NVAR) {                                                  // throughput form: identities unless the joint chain was not usable
-            t1 = g1j_add<C>(t1, part(PV_T1_EXTRA));
-            t1 = g1j_add<C>(t1, part(PV_T1_EXTRA + 1));
+            t1 = g1j_add_i<C>(t1, part(PV_T1_EXTRA));
+            t1 = g1j_add_i<C>(t1, part(PV_T1_EXTRA + 1));
         }
         G1Jac<C> t2 = part(a.nvar - 1);
-        for (int f = 0; f < NFIX; f++) t2 = g1j_add<C>(t2, part(a.nvar + f));
+        for (int f = 0; f < NFIX; f++) t2 = g1j_add_i<C>(t2, part(a.nvar + f));
         G1Aff<C> T1, T2;
         g1j_to_aff2<C>(t1, t2, T1, T2);
         // challenge (proof_gen.rs:272-328)
@@ -909,8 +909,9 @@ struct PairFinal {
 };
 
 // n-point batch normalisation (one inversion), identities preserved
-template <class C, int K>
-__host__ __device__ inline void g1j_batch_to_aff(const G1Jac<C>* in, G1Aff<C>* out) {
+// emit(k, affine point k), k = K-1 .. 0 (one shared inversion; a caller that stores the points elsewhere needs no array of them)
+template <class C, int K, class Emit>
+__host__ __device__ inline void g1j_batch_to_aff_emit(const G1Jac<C>* in, Emit emit) {
     using P = typename C::FpP;
     Fp<C> pre[K];
     Fp<C> acc = fe_one<P>();
@@ -920,12 +921,16 @@ __host__ __device__ inline void g1j_batch_to_aff(const G1Jac<C>* in, G1Aff<C>* o
     }
     Fp<C> inv = fe_inv<P>(acc);
     for (int k = K - 1; k >= 0; k--) {
-        if (g1j_is_inf<C>(in[k])) { out[k] = g1a_inf<C>(); continue; }
+        if (g1j_is_inf<C>(in[k])) { emit(k, g1a_inf<C>()); continue; }
         Fp<C> zi = fe_mul<P>(inv, pre[k]);
         inv = fe_mul<P>(inv, in[k].z);
         Fp<C> zi2 = fe_sqr<P>(zi);
-        out[k] = {fe_mul<P>(in[k].x, zi2), fe_mul<P>(fe_mul<P>(in[k].y, zi2), zi)};
+        emit(k, G1Aff<C>{fe_mul<P>(in[k].x, zi2), fe_mul<P>(fe_mul<P>(in[k].y, zi2), zi)});
     }
+}
+template <class C, int K>
+__host__ __device__ inline void g1j_batch_to_aff(const G1Jac<C>* in, G1Aff<C>* out) {
+    g1j_batch_to_aff_emit<C, K>(in, [&](int k, const G1Aff<C>& p) { out[k] = p; });
 }
 
 // =============================================================================================
@@ -998,6 +1003,7 @@ struct VfArgs {
     uint32_t* partials;       // [VF_NPARTS][3N][n]
     uint32_t* aff;            // [2][2N][n] : A, e*A - B  (Montgomery)
     uint32_t* fmiller;
+    uint32_t* vtab;           // [G1_TAB][2N][n] window table of e * A (g1.hpp TabHbm)
 };
 
 // 32 big-endian bytes (any alignment) -> 8 little-endian words
@@ -1143,26 +1149,35 @@ struct VfScalars {
     }
 };
 
+// the multi-scalar multiplication as two kernels with their own budgets (round 5, as for proof_verify: PvVarMul / PvFixedChunk)
+// lane per item: A on the curve?, its Montgomery copy, e * A (window table in HBM) -> partials[0]
 template <class C>
-struct VfMsmPart {
-    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
+struct VfVarMul {
+    static BBS_HD void run(const VfArgs<C>& a, size_t i) {
+        const size_t n = a.n;
+        if (a.status[i] != ST_PENDING) return;
+        G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
+        if (!g1a_on_curve<C>(A)) { a.status[i] = -41; return; }
+        g1a_store_mont<C>(a.aff, n, i, A);
+        uint32_t k[8];
+        soa_ld<8>(a.sig_e, n, i, k);
+        G1Jac<C> r;
+        g1_mul_aff_sel_hbm_inl<C>(A, k, a.glv != 0, a.vtab + i, n, r);
+        g1j_store<C>(a.partials, n, i, r);
+    }
+};
+// lane per (chunk, item): the fixed-base sum B over {P1, Q1, H_*} -> partials[1 + chunk]
+template <class C>
+struct VfFixedChunk {
     static __host__ __device__ void run(const VfArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        const int part = (int)(t / n);
-        const size_t i = t - (size_t)part * n;
+        const int chunk = (int)(t / n);
+        const size_t i = t - (size_t)chunk * n;
         if (a.status[i] != ST_PENDING) return;
-        uint32_t* out = a.partials + (size_t)part * 3 * N * n;
-        if (part == 0) {
-            G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
-            if (!g1a_on_curve<C>(A)) { a.status[i] = -41; return; }
-            g1a_store_mont<C>(a.aff, n, i, A);
-            uint32_t k[8];
-            soa_ld<8>(a.sig_e, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(A, k, a.glv != 0));
-        } else {
-            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part - 1));
-        }
+        G1Jac<C> r;
+        fixed_msm_chunk_to<C>(*a.cc, a.fscal, n, i, a.L + 2, chunk, r);
+        g1j_store<C>(a.partials + (size_t)(1 + chunk) * 3 * N * n, n, i, r);
     }
 };
 
@@ -1174,8 +1189,8 @@ struct VfCombine {
         if (a.status[i] != ST_PENDING) return;
         auto part = [&](int p) { return g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i); };
         G1Jac<C> b = part(1);
-        for (int f = 1; f < NFIX; f++) b = g1j_add<C>(b, part(1 + f));
-        G1Jac<C> x = g1j_add<C>(part(0), g1j_neg<C>(b));          // e*A - B
+        for (int f = 1; f < NFIX; f++) b = g1j_add_i<C>(b, part(1 + f));
+        G1Jac<C> x = g1j_add_i<C>(part(0), g1j_neg<C>(b));          // e*A - B
         g1a_store_mont<C>(a.aff + (size_t)2 * N * n, n, i, g1j_to_aff<C>(x));
         a.status[i] = ST_PAIRING;
     }
@@ -1260,7 +1275,7 @@ struct SgCombine {
         const size_t n = a.n;
         if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_load<C>(a.partials, n, i);
-        for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)f * 3 * N * n, n, i));
+        for (int f = 1; f < NFIX; f++) acc = g1j_add_i<C>(acc, g1j_load<C>(a.partials + (size_t)f * 3 * N * n, n, i));
         g1a_store_canon<C>(a.out_a, n, i, g1j_to_aff<C>(acc));
         a.status[i] = 1;
     }
@@ -1324,7 +1339,8 @@ struct PgArgs {
     uint32_t* fscal2;         // [L+2][8][n]  (0, 0, m~_j)
     uint32_t* vscal;          // [PG_NVAR][8][n] canonical scalars of the variable-base parts
     int nvar;                 // PG_NVAR (split form) or PG_NVAR_JOINT
-    uint32_t* vtab;           // joint form: [2 lanes][2 tables][G1_TAB][2N][n] window tables of the two joint chains
+    uint32_t* vtab;           // [PG_NVAR][G1_TAB][2N][n] window tables of the variable-base parts: split form table k = part k;
+                              // joint form tables 0, 1 = Bbar's chain (B, -A), 2, 3 = T1's (B, A), 4, 5, 6 = parts 0, 1, 4
     // comb form of the joint layout (g1.hpp g1_comb_sum_to): stage PgTables writes, per item, the tables of the 2^(64 j)
     // multiples of B and A -- [base 2][piece 4][entry 8][2N][n] -- and comb_ok[base * n + i] = 1; null: not used
     uint32_t* ctab;
@@ -1507,17 +1523,23 @@ struct PgScalars {
 };
 
 // lane per (chunk, item): B = P1 + Q1*domain + sum H_j m_j
+// lane per (sum, chunk, item): BOTH fixed-base sums of an item over {P1, Q1, H_*} -- B = P1 + Q1 domain + sum H_j m_j
+// (scalars fscal; chunks -> bpart, summed by PgBCombine) and T2's sum H_j m~_j (scalars fscal2; chunks -> partials[nvar + f],
+// summed by PgFinalize).  Both depend on the scalar stage only, so the second sum no longer rides in the kernel of the
+// doubling chains (round 5): table look-ups and mixed additions, 246 registers, no scratch, two wavefronts per SIMD.
 template <class C>
 struct PgBPart {
-    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
     static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
-        const int part = (int)(t / n);
+        const int part = (int)(t / n);                        // 0 .. NFIX-1: B;  NFIX .. 2 NFIX-1: T2's sum
         const size_t i = t - (size_t)part * n;
         if (a.status[i] != ST_PENDING) return;
-        g1j_store<C>(a.bpart + (size_t)part * 3 * N * n, n, i,
-                     fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.L + 2, part));
+        const bool second = part >= NFIX;
+        const int chunk = second ? part - NFIX : part;
+        G1Jac<C> r;
+        fixed_msm_chunk_to<C>(*a.cc, second ? a.fscal2 : a.fscal, n, i, a.L + 2, chunk, r);
+        g1j_store<C>((second ? a.partials + (size_t)a.nvar * 3 * N * n : a.bpart) + (size_t)chunk * 3 * N * n, n, i, r);
     }
 };
 
@@ -1528,7 +1550,7 @@ struct PgBCombine {
         const size_t n = a.n;
         if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_load<C>(a.bpart, n, i);
-        for (int f = 1; f < NFIX; f++) acc = g1j_add<C>(acc, g1j_load<C>(a.bpart + (size_t)f * 3 * N * n, n, i));
+        for (int f = 1; f < NFIX; f++) acc = g1j_add_i<C>(acc, g1j_load<C>(a.bpart + (size_t)f * 3 * N * n, n, i));
         g1a_store_mont<C>(a.baff, n, i, g1j_to_aff<C>(acc));
         G1Aff<C> A = g1a_load_canon_to_mont<C>(a.sig_a, n, i);
         if (!g1a_on_curve<C>(A)) { a.status[i] = -41; return; }
@@ -1566,16 +1588,17 @@ struct PgTables {
             q[j] = cur;
         }
         for (int j = n_sub - 1; j < COMB_PIECES - 1; j++) q[j] = g1j_inf<C>();
-        G1Aff<C> sub[COMB_PIECES];
-        sub[0] = p0;
-        g1j_batch_to_aff<C, COMB_PIECES - 1>(q, sub + 1);
+        // the sub-bases in affine form go straight to entry 0 of their tables (HBM), where the table builder picks them up:
+        // no array of them in this lane's frame (scratch x hardware queues is a budget, DESIGN.md 5 rule 6)
         uint32_t* tb = a.ctab + (size_t)base * comb_table_words(N) * n + i;
+        TabHbm<C>{tb, n}.st(0, p0);
+        g1j_batch_to_aff_emit<C, COMB_PIECES - 1>(q, [&](int k, const G1Aff<C>& s) { TabHbm<C>{tb + (size_t)(k + 1) * G1_TAB * 2 * N * n, n}.st(0, s); });
         Fp<C> zc[COMB_PIECES];
         bool ok = true;
 #pragma unroll 1
         for (int j = 0; j < n_sub; j++) {
             TabHbm<C> tab{tb + (size_t)j * G1_TAB * 2 * N * n, n};
-            ok = ok && g1_odd_table<C>(sub[j], tab, zc[j]);
+            ok = g1_odd_table<C>(tab.ld(0), tab, zc[j]) && ok;
         }
         if (!ok) return;
         // entries (x', y') of table j are the Jacobian points (x', y', zc_j): to true affine with ONE inversion for the scales
@@ -1614,32 +1637,32 @@ struct PgTables {
     }
 };
 
+// lane per (part < nvar, item): the variable-base parts -- multiples of B and of the signature point A.  A kernel of its own
+// (round 5: the fixed-base chunks are in PgBPart), window tables in HBM, the multiplication routines inlined.
 template <class C>
-struct PgMsmPart {
-    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
-    static __host__ __device__ void run(const PgArgs<C>& a, size_t t) {
+struct PgVarPart {
+    static BBS_HD void run(const PgArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
+        constexpr size_t TW = (size_t)G1_TAB * 2 * N;
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
         if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
         auto scalar = [&](int k, uint32_t* dst) { soa_ld<8>(a.vscal + (size_t)k * 8 * n, n, i, dst); };
-        if (part >= a.nvar) {
-            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal2, n, i, a.L + 2, part - a.nvar));
-        } else if (a.nvar == PG_NVAR) {
+        G1Jac<C> r;
+        if (a.nvar == PG_NVAR) {
             // split form: part k multiplies B (k < 4) or A by scalar k
-            G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part < 4 ? 0 : 1) * 2 * N * n, n, i);
+            const G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part < 4 ? 0 : 1) * 2 * N * n, n, i);
             uint32_t k[8];
             scalar(part, k);
-            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
+            g1_mul_aff_sel_hbm_inl<C>(p, k, a.glv != 0, a.vtab + (size_t)part * TW * n + i, n, r);
         } else if (a.ctab && a.comb_ok[i] && a.comb_ok[n + i]) {
             // comb form: every multiple of B and A from the tables of their 2^(64 j) multiples, 60 doublings per chain.
             // part 0: D = v0 B; 1: Abar = v4 A; 2: Bbar = v1 B - v5 A; 3: T1 = v2 B + v6 A; 4: T2's v3 B
             const uint32_t* tB = a.ctab + i;
             const uint32_t* tA = a.ctab + comb_table_words(N) * n + i;
             uint32_t k0[8], k1[8];
-            G1Jac<C> r;
             if (part == 2 || part == 3) {
                 scalar(part == 2 ? 1 : 2, k0);
                 scalar(part == 2 ? 5 : 6, k1);
@@ -1660,24 +1683,36 @@ struct PgMsmPart {
                 if (!done) comb_recode(k0, false, part == 1 ? tA : tB, tm[0]);
                 g1_comb_sum_to<C, 1>(tm, n, r);
             }
-            g1j_store<C>(out, n, i, r);
         } else if (part == 2 || part == 3) {
-            // joint form: Bbar = v1 B + v5 (-A) (part 2), T1 = v2 B + v6 A (part 3) -- one doubling chain each
+            // joint form: Bbar = v1 B + v5 (-A) (part 2), T1 = v2 B + v6 A (part 3) -- one doubling chain each; if a table hits an
+            // exceptional case (B or A the identity or of small order) the two products one by one on the generic chain
             const G1Aff<C> B = g1a_load_mont<C>(a.baff, n, i);
             G1Aff<C> A = g1a_load_mont<C>(a.baff + (size_t)2 * N * n, n, i);
             if (part == 2) A = g1a_neg<C>(A);
             uint32_t kb[8], ka[8];
             scalar(part == 2 ? 1 : 2, kb);
             scalar(part == 2 ? 5 : 6, ka);
-            uint32_t* tabs = a.vtab + (size_t)(part - 2) * 2 * G1_TAB * 2 * N * n + i;
-            g1j_store<C>(out, n, i, g1_mul2_aff<C>(B, kb, A, ka, tabs, n, a.glv != 0));
+            uint32_t* tabs = a.vtab + (size_t)(part - 2) * 2 * TW * n + i;
+            TabHbm<C>{tabs, n}.st(0, B);
+            TabHbm<C>{tabs + TW * n, n}.st(0, A);
+            bool done = false;
+            if constexpr (C::K::HAS_GLV) {
+                if (a.glv) done = g1_mul2_tabs_fast<C, true>(kb, ka, tabs, n, r);
+            }
+            if (!a.glv) done = g1_mul2_tabs_fast<C, false>(kb, ka, tabs, n, r);
+            if (!done) {
+                const G1Jac<C> x = g1_mul_aff_naf<C>(B, kb);
+                r = g1j_add_i<C>(x, g1_mul_aff_naf<C>(A, ka));
+            }
         } else {
             // joint form, single multiplications: D = v0 B (part 0), Abar = v4 A (part 1), T2's v3 B (part 4)
-            G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part == 1 ? 1 : 0) * 2 * N * n, n, i);
+            const G1Aff<C> p = g1a_load_mont<C>(a.baff + (size_t)(part == 1 ? 1 : 0) * 2 * N * n, n, i);
             uint32_t k[8];
             scalar(part == 0 ? 0 : (part == 1 ? 4 : 3), k);
-            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
+            const int slot = part == 0 ? 4 : (part == 1 ? 5 : 6);
+            g1_mul_aff_sel_hbm_inl<C>(p, k, a.glv != 0, a.vtab + (size_t)slot * TW * n + i, n, r);
         }
+        g1j_store<C>(out, n, i, r);
     }
 };
 
@@ -1692,14 +1727,14 @@ struct PgFinalize {
         G1Jac<C> pj[5];
         if (a.nvar == PG_NVAR) {
             pj[0] = part(4);                                              // Abar
-            pj[1] = g1j_add<C>(part(1), g1j_neg<C>(part(5)));             // Bbar = r1r2 B - e r1r2 A
+            pj[1] = g1j_add_i<C>(part(1), g1j_neg<C>(part(5)));             // Bbar = r1r2 B - e r1r2 A
             pj[2] = part(0);                                              // D
-            pj[3] = g1j_add<C>(part(6), part(2));                         // T1
+            pj[3] = g1j_add_i<C>(part(6), part(2));                         // T1
             pj[4] = part(3);                                              // T2
         } else {
             pj[0] = part(1); pj[1] = part(2); pj[2] = part(0); pj[3] = part(3); pj[4] = part(4);      // the joint chains' own sums
         }
-        for (int f = 0; f < NFIX; f++) pj[4] = g1j_add<C>(pj[4], part(a.nvar + f));
+        for (int f = 0; f < NFIX; f++) pj[4] = g1j_add_i<C>(pj[4], part(a.nvar + f));
         G1Aff<C> pa[5];
         g1j_batch_to_aff<C, 5>(pj, pa);
         // challenge (proof_gen.rs:272-328), disclosed indexes sorted + deduplicated (:151-161)
@@ -1842,31 +1877,53 @@ struct MsmArgs {
     uint32_t* partials;       // [n_var + NFIX][3N][n]
     uint32_t* out;            // [2NC][n] canonical
     FixTreeWork<C> fixwk;     // see PvArgs
+    uint32_t* vtab;           // [n_var][G1_TAB][2N][n] window tables of the variable-base terms
 };
 
+// lane per (variable-base term, item)
 template <class C>
-struct MsmPart {
-    static constexpr int WAVES_PER_EU = BBS_MSM_WAVES;
-    static __host__ __device__ void run(const MsmArgs<C>& a, size_t t) {
+struct MsmVarMul {
+    static BBS_HD void run(const MsmArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
         const int part = (int)(t / n);
         const size_t i = t - (size_t)part * n;
         if (a.status[i] != ST_PENDING) return;
         uint32_t* out = a.partials + (size_t)part * 3 * N * n;
-        if (part < a.n_var) {
-            G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * C::FpP::NC * n, n, i);
-            if (!g1a_on_curve<C>(p)) { a.status[i] = -41; g1j_store<C>(out, n, i, g1j_inf<C>()); return; }
-            uint32_t k[8];
-            soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
-            g1j_store<C>(out, n, i, g1_mul_aff_sel<C>(p, k, a.glv != 0));
-        } else if (a.fixwk.pts0) {
-            G1Jac<C> r = g1j_inf<C>();
-            if (part == a.n_var) fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.n_fixed, a.fixwk, r);
-            g1j_store<C>(out, n, i, r);
-        } else {
-            g1j_store<C>(out, n, i, fixed_msm_chunk<C>(*a.cc, a.fscal, n, i, a.n_fixed, part - a.n_var));
-        }
+        G1Aff<C> p = g1a_load_canon_to_mont<C>(a.vpts + (size_t)part * 2 * C::FpP::NC * n, n, i);
+        G1Jac<C> r = g1j_inf<C>();
+        if (!g1a_on_curve<C>(p)) { a.status[i] = -41; g1j_store<C>(out, n, i, r); return; }
+        uint32_t k[8];
+        soa_ld<8>(a.vscal + (size_t)part * 8 * n, n, i, k);
+        g1_mul_aff_sel_hbm_inl<C>(p, k, a.glv != 0, a.vtab + (size_t)part * G1_TAB * 2 * N * n + i, n, r);
+        g1j_store<C>(out, n, i, r);
+    }
+};
+// lane per (chunk, item)
+template <class C>
+struct MsmFixedChunk {
+    static __host__ __device__ void run(const MsmArgs<C>& a, size_t t) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        const int chunk = (int)(t / n);
+        const size_t i = t - (size_t)chunk * n;
+        if (a.status[i] != ST_PENDING) return;
+        G1Jac<C> r;
+        fixed_msm_chunk_to<C>(*a.cc, a.fscal, n, i, a.n_fixed, chunk, r);
+        g1j_store<C>(a.partials + (size_t)(a.n_var + chunk) * 3 * N * n, n, i, r);
+    }
+};
+// the fixed-base sum as one tree of affine additions per item (bbs_ctx_set_fixed_base_tree; lane per item)
+template <class C>
+struct MsmFixedTree {
+    static __host__ __device__ void run(const MsmArgs<C>& a, size_t i) {
+        constexpr int N = C::FpP::N;
+        const size_t n = a.n;
+        if (a.status[i] != ST_PENDING) return;
+        G1Jac<C> r = g1j_inf<C>();
+        for (int f = 1; f < NFIX; f++) g1j_store<C>(a.partials + (size_t)(a.n_var + f) * 3 * N * n, n, i, r);
+        fixed_msm_tree_to<C>(*a.cc, a.fscal, n, i, a.n_fixed, a.fixwk, r);
+        g1j_store<C>(a.partials + (size_t)a.n_var * 3 * N * n, n, i, r);
     }
 };
 
@@ -1877,7 +1934,7 @@ struct MsmCombine {
         const size_t n = a.n;
         if (a.status[i] != ST_PENDING) return;
         G1Jac<C> acc = g1j_inf<C>();
-        for (int p = 0; p < a.n_var + NFIX; p++) acc = g1j_add<C>(acc, g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i));
+        for (int p = 0; p < a.n_var + NFIX; p++) acc = g1j_add_i<C>(acc, g1j_load<C>(a.partials + (size_t)p * 3 * N * n, n, i));
         g1a_store_canon<C>(a.out, n, i, g1j_to_aff<C>(acc));
         a.status[i] = 1;
     }

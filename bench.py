@@ -23,11 +23,12 @@ timed region.  Prints ONE JSON line (rank 0).
 """
 import os
 
-# The engine keeps many independent batches in flight, one HIP stream pair per batch.  The HIP runtime maps all
-# streams of a process onto 4 hardware queues by default, so a long, narrow kernel (a batch's tail) blocks the
-# streams that share its queue (DESIGN.md 5 rule 6).  Must be set before the first HIP call of the process (torch
-# initialises HIP before the engine is loaded); the library's own constructor does the same when it is loaded first.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
+# The engine keeps many independent batches in flight, every batch on streams of its own (three per proof_verify job since
+# round 5).  The HIP runtime maps all streams of a process onto 4 hardware queues by default, so a long, narrow kernel (a
+# batch's tail) blocks the streams that share its queue (DESIGN.md 5 rule 6).  Must be set before the first HIP call of the
+# process (torch initialises HIP before the engine is loaded); the library's own constructor does the same when it is
+# loaded first (20: what its scratch budget allows with room to spare, bbs_runtime_queue_budget).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 import argparse
 import json
 import sys
@@ -180,8 +181,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--window-bits", type=int, default=20)
     ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU (distinct data in every slot).  6 = the measured "
-                    "optimum: a job owns two streams and the runtime has 14 hardware queues -- 4 / 6 in flight 1.51 / 1.52 M/s, 7 / 8 in "
-                    "flight (14 / 16 streams) 1.48 / 1.44 M/s (profiles/r03_x_inflight_sweep.log)")
+                    "optimum of rounds 3 - 4 (two streams per job on 14 hardware queues: 4 / 6 / 7 / 8 in flight 1.51 / 1.52 / 1.48 / 1.44 M/s, "
+                    "profiles/r03_x_inflight_sweep.log); round 5: three streams per job on 20 queues, 6 in flight 1.55 M/s "
+                    "(profiles/r05_a_ab_split_msm_layouts.log)")
     ap.add_argument("--config", default="proof_verify_4096", choices=["proof_verify_4096", "mixed65536"])
     ap.add_argument("--total", type=int, default=65536, help="mixed65536 only: length of the list (8192 = one rank's share "
                     "of the 65 536-item list at 8 GPUs, to rehearse the strong-scaling regime on one GPU)")

@@ -88,7 +88,7 @@ const char* bbs_version(void);
 /* Hash of the sources (every file under bbs_sign_amd/csrc and this header) the library was built from; bbs_sign_amd/build.py rebuilds
  * when it differs from the tree's (a prebuilt library travels with the tree: staleness is judged by content). */
 const char* bbs_source_hash(void);
-/* GPU_MAX_HW_QUEUES as the process environment has it (0 = unset).  The library sets 14 when it is loaded unless the
+/* GPU_MAX_HW_QUEUES as the process environment has it (0 = unset).  The library sets 20 when it is loaded unless the
  * variable is already set; the HIP runtime reads it at its own initialisation, so the setting only takes effect if
  * this library was loaded before the process's first HIP call ("Build / deployment"). */
 int bbs_runtime_hw_queues(void);
@@ -659,6 +659,52 @@ int bbs_selftest_f2dot(int curve, size_t n_terms, const uint8_t* a, const uint8_
  * accumulator registers): must equal bbs_selftest_f2dot limb for limb. */
 int bbs_selftest_f2dot2(int curve, size_t n_terms, const uint8_t* a, const uint8_t* b, const uint8_t* weights,
                         uint8_t* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Pool: core_proof_verify over a LIST of proofs, fanned out over SEVERAL GPUs behind this ABI ("multi-GPU
+ * fan-out is internal"; 8(e): split by curve, contiguous ranges per GPU, tables replicated, no data-path collective).
+ * The reference verifies one proof per call (src/proof_verify.rs:19-61, core form :64-116); a caller with a list loops over
+ * it.  A pool owns one context per (curve, member device) with the same generators and issuer key on every member; a list
+ * is handed over as one section per curve in the layout of bbs_core_proof_verify_batch.  Every section is cut into
+ * contiguous shares of ceil(n / members) items, every share into jobs of at most max_batch items, and the jobs of a member
+ * run from ONE submitting thread per member through bbs_core_proof_verify_submit (completion-order retire, curves
+ * alternating).  The statuses land in the caller's array in the caller's order: one process drives every GPU, so no
+ * exchange between processes exists on this path (the one-process-per-GPU launcher of bench.py exchanges them with one
+ * all_gather; both partition by the same rule).  Statuses of every item are exactly those of bbs_core_proof_verify_batch
+ * on the item's own curve.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bbs_pool bbs_pool;
+typedef struct bbs_pv_list {      /* the items of ONE curve of a list, as for bbs_core_proof_verify_batch */
+    int curve;
+    size_t n;
+    const uint8_t* proofs_fixed;
+    const uint8_t* commitments;    const uint64_t* commit_off;
+    const uint8_t* disclosed_msgs; const uint64_t* dmsg_off;
+    const uint64_t* disclosed_idx; const uint64_t* didx_off;
+    const uint8_t* headers;        const uint64_t* hdr_off;     /* hdr_off / ph_off may be NULL: all empty */
+    const uint8_t* ph;             const uint64_t* ph_off;
+    const uint64_t* global_index;  /* NULL: status[k] is item k of this section.  Else: item k is item global_index[k] of
+                                    * the caller's whole (mixed) list and its status is written to status[global_index[k]] */
+    int8_t* status;
+} bbs_pv_list;
+/* device_ids: the member devices, in share order; an id may repeat (two context sets on one GPU -- what a test on a
+ * one-GPU box uses).  BBS_E_NO_DEVICE if an id does not exist. */
+int bbs_pool_create(const int* device_ids, size_t n_devices, bbs_pool** out);
+void bbs_pool_destroy(bbs_pool* pool);
+size_t bbs_pool_device_count(const bbs_pool* pool);
+/* the same configuration on every member's context of `curve` (contexts are created at the first call naming the curve) */
+int bbs_pool_set_window_bits(bbs_pool* pool, int curve, int bits);
+int bbs_pool_set_generators(bbs_pool* pool, int curve, const uint8_t* generators, size_t count, const uint8_t* api_id,
+                            size_t api_id_len);
+int bbs_pool_set_public_key(bbs_pool* pool, int curve, const uint8_t* pk_affine, int is_identity);
+/* jobs outstanding per member (default 6, the plateau of the single-GPU serving loop) */
+int bbs_pool_set_inflight(bbs_pool* pool, int jobs_per_member);
+/* member `member`'s context of `curve`, e.g. to run any other operation of this ABI on that device */
+int bbs_pool_context(bbs_pool* pool, int curve, size_t member, bbs_ctx** out);
+/* Verify the list.  Blocks until every status has been written.  max_batch = 0: 4096.  BBS_E_STATE if a section's curve
+ * has no generators / public key yet; BBS_E_ARG before anything is submitted if a section is malformed.  One call at a
+ * time per pool (calls are serialised inside). */
+int bbs_pool_proof_verify(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch);
 
 #ifdef __cplusplus
 }

@@ -849,6 +849,74 @@ def check_bv_tiles(curve, lib_path=None, n=16384, L=8, R=2, window_bits=None, jo
     eng.close()
 
 
+def check_pool(lib_path=None, devices=(0, 0), per_curve=40, L=4, R=2, window_bits=None, max_batch=16):
+    """bbs_pool: a mixed BN254 + BLS12-381 list fanned out over the pool's members BEHIND the C ABI (SURVEY 8(b) / 8(e);
+    here both members are device 0 -- two context sets on one GPU, or the host twin).  Item i of the list is BLS12-381 for odd i,
+    BN254 for even i; every 16th item has a commitment changed (fails at the challenge, src/proof_verify.rs:108-110), two
+    items are self-consistent proofs of forged signatures (fail in the pairing only, :112-115), one has a disclosed index out
+    of range (Err before any arithmetic, :139-150).  The pool's statuses -- written by the library into ONE array in list
+    order through the sections' global indexes -- must equal what a single context per curve says about the same items,
+    whatever the job size (shares cut into several jobs, a ragged last job, a member with an empty share)."""
+    from bbs_sign_amd.pool import Pool
+    total = 2 * per_curve
+    curve_of_item = ["bls12_381" if (i & 1) else "bn254" for i in range(total)]
+    items, single = {}, {}
+    pool = Pool(list(devices), lib_path)
+    assert pool.device_count() == len(devices)
+    for curve in ("bls12_381", "bn254"):
+        suite, eng, gens, sk = bench_engine(curve, L, lib_path, window_bits)
+        c = suite.curve
+        ids = [i for i in range(total) if curve_of_item[i] == curve]
+        msgs, disclosed, rnds = bench_items(suite, eng, len(ids), L, R, ids=ids)
+        sigs, st = eng.core_sign_batch(msgs)
+        assert (st == 1).all()
+        forged_at = {ids[3], ids[len(ids) - 1]}
+        fs = [Signature(c.g1_add(s.a, c.g1), s.e) if g in forged_at else s for g, s in zip(ids, sigs)]
+        proofs, st = eng.core_proof_gen_batch(fs, msgs, disclosed, rnds)
+        assert (st == 1).all()
+        dm = [m[:R] for m in msgs]
+        didx = [list(d) for d in disclosed]
+        for k, g in enumerate(ids):
+            if g % 16 == 0:
+                proofs[k].commitments[0] = (proofs[k].commitments[0] + 1) % c.r
+        didx[5] = didx[5][:-1] + [L]                                      # InvalidDisclosedIndex
+        items[curve] = (ids, proofs, dm, didx)
+        single[curve] = eng.core_proof_verify_batch(proofs, dm, didx)
+        want_c = [(-3 if k == 5 else (0 if (g % 16 == 0 or g in forged_at) else 1)) for k, g in enumerate(ids)]
+        assert [int(x) for x in single[curve]] == want_c, (curve, [int(x) for x in single[curve]])
+        pool.set_window_bits(curve, window_bits if window_bits is not None else (4 if lib_path else 8))
+        pool.set_generators(curve, gens, suite.api_id)
+        pool.set_public_key(curve, eng.public_key())
+        eng.close()
+    want = np.zeros(total, dtype=np.int8)
+    for curve, (ids, _, _, _) in items.items():
+        want[ids] = single[curve]
+
+    def fetch(curve, ids):
+        all_ids, proofs, dm, didx = items[curve]
+        pos = {g: k for k, g in enumerate(all_ids)}
+        sel = [pos[g] for g in ids]
+        return [proofs[k] for k in sel], [dm[k] for k in sel], [didx[k] for k in sel]
+
+    for mb in (max_batch, 7, 0):                                          # several jobs per share; ragged jobs; one job per share
+        got = pool.proof_verify_mixed(curve_of_item, fetch, max_batch=mb)
+        assert [int(x) for x in got] == [int(x) for x in want], (mb, [i for i in range(total) if got[i] != want[i]][:8])
+    # sections without a global index: per-section status arrays, same verdicts
+    secs = [pool.pack(curve, *items[curve][1:]) for curve in sorted(items)]
+    got = pool.proof_verify_packed(secs, max_batch=max_batch)
+    assert [int(x) for x in got] == [int(x) for c2 in sorted(items) for x in single[c2]]
+    # a curve that was never configured is refused before anything runs; an empty list is fine
+    p2 = Pool(list(devices), lib_path)
+    try:
+        p2.proof_verify_packed([pool.pack("bls12_381", *items["bls12_381"][1:])])
+        raise AssertionError("an unconfigured pool verified a list")
+    except Exception as e:
+        assert getattr(e, "rc", None) == -102, e                          # BBS_E_STATE
+    assert len(p2.proof_verify_packed([])) == 0
+    p2.close()
+    pool.close()
+
+
 def check_mixed_curves_in_flight(lib_path=None, n=1024, per_curve=3, rounds=4):
     """BASELINE config 5 on one device: BN254 and BLS12-381 proof_verify batches resident and in flight together
     (every job on its own streams, two contexts), every 16th item corrupted: the statuses of every job are exact."""

@@ -320,6 +320,31 @@ def test_dedicated_queues_under_the_runtimes_default_pool():
     assert line["checks"]["statuses_exact_every_step"] is True and line["config"]["dedicated_queues"] == 12 and line["config"]["hw_queues"] == 4
 
 
+@pytest.mark.parametrize("pool,dedicated", [("14", "16"), ("32", "0"), ("4", "16")])
+def test_hardware_queue_budget_never_aborts(pool, dedicated):
+    """Pooled + dedicated hardware queues x the largest kernel frame is a CHECKED budget (runtime.hpp queue_budget): with
+    GPU_MAX_HW_QUEUES=14 and bbs_runtime_set_dedicated_queues(16) -- a legal configuration that made the runtime abort the
+    process in round 4 once more than ~ 20 queues were in use -- 32 one-stream jobs in flight run to completion with exact
+    statuses; likewise with a pool that is itself over budget (32: the library stops creating streams at the budget and the
+    jobs beyond it share their context's stream).  The process must END NORMALLY: a runtime abort is a non-zero exit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPU_MAX_HW_QUEUES"] = pool
+    env["BBS_DEDICATED_QUEUES"] = dedicated
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "queue_budget_probe.py"), "32", "1024", "3"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["statuses_exact"] is True
+    b = line["queue_budget"]
+    assert b["pool"] == int(pool) and b["total"] >= 8 and b["dedicated_cap"] == max(0, b["total"] - b["pool"]), b
+    assert b["scratch_bytes_per_lane"] <= 1900, b      # the largest kernel frame of the library (round 4: 2848)
+
+
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_proof_gen_unusual_points(curve):
     pc.check_proof_gen_unusual_points(curve, None)
@@ -329,3 +354,10 @@ def test_proof_gen_unusual_points(curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_proof_gen_unusual_points_latency_form(curve):
     pc.check_proof_gen_unusual_points(curve, None)
+
+
+def test_pool_two_members_on_one_gpu():
+    """bbs_pool with device ids (0, 0): two context sets, two submitting threads inside the library, one GPU.  A mixed BN254 +
+    BLS12-381 list with corrupted, forged and malformed items: statuses in list order = one context per curve."""
+    pc.check_pool(None, devices=(0, 0), per_curve=300, L=8, R=3, window_bits=8, max_batch=64)
+

@@ -161,3 +161,13 @@ def test_proof_gen_unusual_points(twin, curve):
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_proof_gen_unusual_points_latency_form(twin, curve):
     pc.check_proof_gen_unusual_points(curve, twin)
+
+
+def test_pool_two_members(twin):
+    """bbs_pool (SURVEY 8(b) / 8(e) behind the C ABI): a mixed-curve list over two members, merged statuses = one context per curve"""
+    pc.check_pool(twin, devices=(0, 0), per_curve=24)
+
+
+def test_pool_three_members_uneven_shares(twin):
+    pc.check_pool(twin, devices=(0, 0, 0), per_curve=13, max_batch=3)
+
