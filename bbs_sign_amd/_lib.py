@@ -122,6 +122,9 @@ SIGNATURES = {
     "bbs_pool_set_inflight": (ci, [vp, ci]),
     "bbs_pool_context": (ci, [vp, ci, sz, ctypes.POINTER(vp)]),
     "bbs_pool_proof_verify": (ci, [vp, ctypes.POINTER(PvList), sz, sz]),
+    "bbs_pool_proof_verify_submit": (ci, [vp, ctypes.POINTER(PvList), sz, sz, ctypes.POINTER(vp)]),
+    "bbs_pool_job_wait": (ci, [vp]),
+    "bbs_pool_job_free": (None, [vp]),
     "bbs_runtime_queue_budget": (ci, [ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(sz)]),
     "bbs_device_free_bytes": (sz, [ci]),
     "bbs_ctx_table_bytes": (sz, [vp]),

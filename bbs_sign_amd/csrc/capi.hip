@@ -1373,8 +1373,7 @@ int bbs_pool_set_public_key(bbs_pool* pool, int curve, const uint8_t* pk, int is
 }
 int bbs_pool_set_inflight(bbs_pool* pool, int jobs_per_member) {
     if (!pool || jobs_per_member < 1 || jobs_per_member > 64) return BBS_E_ARG;
-    std::lock_guard<std::mutex> g(pool->mu);
-    pool->inflight = jobs_per_member;
+    pool->inflight.store(jobs_per_member);
     return BBS_OK;
 }
 int bbs_pool_context(bbs_pool* pool, int curve, size_t member, bbs_ctx** out) {
@@ -1384,7 +1383,17 @@ int bbs_pool_context(bbs_pool* pool, int curve, size_t member, bbs_ctx** out) {
     *out = pool->ctx[bbs_pool::curve_slot(curve)][member];
     return BBS_OK;
 }
+int bbs_pool_proof_verify_submit(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch, bbs_pool_job** job_out) {
+    return pool_proof_verify_submit(pool, lists, n_lists, max_batch, job_out);
+}
+int bbs_pool_job_wait(bbs_pool_job* job) { return pool_job_wait(job); }
+void bbs_pool_job_free(bbs_pool_job* job) { pool_job_free(job); }
 int bbs_pool_proof_verify(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch) {
-    return pool_proof_verify(pool, lists, n_lists, max_batch);
+    bbs_pool_job* job = nullptr;
+    int rc = pool_proof_verify_submit(pool, lists, n_lists, max_batch, &job);
+    if (rc) return rc;
+    rc = pool_job_wait(job);
+    pool_job_free(job);
+    return rc;
 }
 #pragma GCC visibility pop

@@ -95,7 +95,8 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     // e * A needs only what the ingest stage left: in the latency form it runs on the job's side stream beside the scalars
     // and the fixed-base chunks (critical path 3.0 instead of 0.13 + 0.9 + 3.0 ms); in the throughput form the job keeps to
     // one stream -- one hardware queue per job, and with eight jobs alive the order of a job's own kernels does not matter
-    const int side = job->latency_form ? 1 : 0;
+    static const int side_forced = []() { const char* v = getenv("BBS_VF_SIDE"); return v ? atoi(v) : -1; }();      // A/B: 0 never, 1 always
+    const int side = side_forced >= 0 ? (side_forced ? 1 : 0) : (job->latency_form ? 1 : 0);
     j->stages.push_back({"vf_var_mul", [j, side]() { return rt::launch<VfVarMul<C>>(side ? j->stream_aux(1) : j->stream(), j->a, j->n); }, side, 0});
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"vf_fixed_chunks", [j]() { return rt::launch<VfFixedChunk<C>>(j->stream(), j->a, j->n * (size_t)NFIX); }});

@@ -45,6 +45,23 @@ class PackedSection:
         rec.status = status.ctypes.data_as(_lib.c_i8p)
 
 
+class PoolJob:
+    """A list in flight on the pool (bbs_pool_job)."""
+
+    def __init__(self, pool, h, recs, sections, outs, whole, n_total):
+        self.pool, self.h, self.recs, self.sections, self.outs, self.whole, self.n_total = pool, h, recs, sections, outs, whole, n_total
+
+    def wait(self) -> np.ndarray:
+        rc = self.pool.lib.bbs_pool_job_wait(self.h)
+        self.pool.lib.bbs_pool_job_free(self.h)
+        self.h = None
+        if rc:
+            raise BbsRuntimeError(rc, "bbs_pool_job_wait")
+        if self.whole is not None:
+            return self.whole[:self.n_total]
+        return np.concatenate([o[:s.n] for o, s in zip(self.outs, self.sections)]) if self.sections else np.zeros(0, dtype=np.int8)
+
+
 class Pool:
     """One context per (curve, member device); `devices` may repeat an id (two context sets on one GPU)."""
 
@@ -113,21 +130,26 @@ class Pool:
     def pack(self, curve, proofs, disclosed_msgs, disclosed_idx, headers=None, phs=None, global_index=None) -> PackedSection:
         return PackedSection(self.packer(curve), proofs, disclosed_msgs, disclosed_idx, headers, phs, global_index)
 
-    def proof_verify_packed(self, sections: List[PackedSection], n_total: Optional[int] = None, max_batch: int = 0) -> np.ndarray:
-        """bbs_pool_proof_verify on packed sections.  n_total given: every section carries a global index and ONE status
-        array of the whole list comes back; else the sections' status arrays, concatenated in section order."""
+    def submit_packed(self, sections: List[PackedSection], n_total: Optional[int] = None, max_batch: int = 0) -> "PoolJob":
+        """bbs_pool_proof_verify_submit on packed sections; ``job.wait()`` returns the statuses.  n_total given: every section
+        carries a global index and ONE status array of the whole list comes back; else the sections' status arrays,
+        concatenated in section order.  The sections must stay alive until wait() (the job keeps a reference)."""
         recs = (_lib.PvList * max(1, len(sections)))()
         if n_total is not None:
             whole = np.full(max(n_total, 1), -128, dtype=np.int8)
             outs = [whole] * len(sections)
         else:
+            whole = None
             outs = [np.full(max(s.n, 1), -128, dtype=np.int8) for s in sections]
         for r, s, o in zip(recs, sections, outs):
             s.fill(r, o)
-        self._chk(self.lib.bbs_pool_proof_verify(self.h, recs, len(sections), max_batch), "bbs_pool_proof_verify")
-        if n_total is not None:
-            return whole[:n_total]
-        return np.concatenate([o[:s.n] for o, s in zip(outs, sections)]) if sections else np.zeros(0, dtype=np.int8)
+        h = ctypes.c_void_p()
+        self._chk(self.lib.bbs_pool_proof_verify_submit(self.h, recs, len(sections), max_batch, ctypes.byref(h)), "bbs_pool_proof_verify_submit")
+        return PoolJob(self, h, recs, sections, outs, whole, n_total)
+
+    def proof_verify_packed(self, sections: List[PackedSection], n_total: Optional[int] = None, max_batch: int = 0) -> np.ndarray:
+        """submit + wait"""
+        return self.submit_packed(sections, n_total, max_batch).wait()
 
     def proof_verify_mixed(self, curve_of_item: Sequence[str], fetch_items, max_batch: int = 0) -> np.ndarray:
         """A list whose item i is of curve curve_of_item[i]; fetch_items(curve, ids) -> (proofs, disclosed_msgs,

@@ -205,10 +205,23 @@ def main():
     ap.add_argument("--all-ranks-on-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the process group (RCCL for --backend nccl) even "
                     "with one rank, so that the collectives of the N > 1 path run on the real backend of a one-GPU box")
+    ap.add_argument("--single-process", action="store_true", help="mixed65536 only: ONE process drives all --gpus devices through bbs_pool -- "
+                    "the multi-GPU fan-out BEHIND the C ABI (include/bbs_sign_amd.h, SURVEY 8(b)), what a Rust / C host gets -- "
+                    "instead of one process per GPU and an all_gather")
+    ap.add_argument("--pool-devices", default=None, help="--single-process: comma-separated member device ids (default 0 .. --gpus - 1; an "
+                    "id may repeat: two members on one GPU)")
     ap.add_argument("--min-region-s", type=float, default=1.0, help="if the K timed steps last less than this, a second, "
                     "longer region of the same loop is timed and reported beside `value` as `long_region` (0 = off)")
     args = ap.parse_args()
 
+    if args.single_process:
+        if args.config != "mixed65536":
+            raise SystemExit("bench.py: --single-process goes with --config mixed65536")
+        from bbs_sign_amd import workload as pc
+        from bench_mixed import run_mixed_pool
+        devices = [int(x) for x in args.pool_devices.split(",")] if args.pool_devices else list(range(args.gpus))
+        run_mixed_pool(args, pc, devices, total=args.total)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a bare `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process, before this process has
         # touched torch.cuda or HIP (a process that initialised the GPU must never exec), and leave with its exit code

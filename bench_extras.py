@@ -4,6 +4,38 @@ import ctypes
 import time
 
 
+def op_roofline(counters, counters_file, lib_hash, op, items_per_s, in_flight):
+    """SURVEY 8(d) asks for sign / verify / proof_gen "plus fraction of roofline" as well.  From the per-kernel counters of
+    one 4096-item job of the operation (rocprofv3 --pmc, tools/run_profile_ops.sh -> profiles/*_counters.json, key "ops") and
+    the rate measured HERE with `in_flight` resident jobs:
+      * hbm (the roofline the contract names): algorithmic bytes per item x items/s against 8 TB/s, and the measured traffic of
+        one launch (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) over the algorithmic bytes;
+      * valu_issue (the resource that binds): the SIMD time this run spent per wavefront instruction (1024 SIMDs / rate /
+        instructions) against the micro-benchmarked issue cost of each kernel's opcode mix at the occupancy its registers
+        allow -- frac = modelled / spent = how much of the SIMDs' time went into issuing the operation's instructions."""
+    spec = ((counters or {}).get("ops") or {}).get(op)
+    if not spec or not items_per_s:
+        return None
+    ks = spec["kernels"]
+    n0 = float(spec.get("items_per_launch", 4096))
+    insts = sum(k["valu_insts"] for k in ks.values())
+    model_ns = sum(k["valu_insts"] * k["ns_per_inst_at_that_occupancy"] for k in ks.values()) / insts
+    spent_ns = 1024.0 * (n0 / items_per_s) * 1e9 / insts
+    traffic = sum(2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"] for k in ks.values()) * 1024.0
+    alg = spec["alg_bytes_per_item"] * n0
+    current = (counters.get("library_source_hash") == lib_hash) if counters.get("library_source_hash") else None
+    return {"items_per_s": items_per_s, "jobs_in_flight": in_flight,
+            "valu_issue": {"wave_insts_per_item": insts / n0, "valu_wave_insts_per_job": insts,
+                           "ns_per_wave_inst_per_simd": {"this_run": spent_ns, "ubench_mix_at_kernel_occupancy": model_ns},
+                           "frac": model_ns / spent_ns,
+                           "kernels": {st: {"valu_wave_insts": k["valu_insts"], "waves_per_simd": k["waves_per_simd"],
+                                            "ns_per_inst": k["ns_per_inst_at_that_occupancy"]} for st, k in ks.items()}},
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_item": spec["alg_bytes_per_item"], "achieved": spec["alg_bytes_per_item"] * items_per_s / 1e9,
+                         "peak": 8000.0, "unit": "GB/s", "frac": spec["alg_bytes_per_item"] * items_per_s / 1e9 / 8000.0,
+                         "traffic": traffic, "hbm_traffic_over_algorithmic": traffic / alg},
+            "source": counters_file, "counters_from_this_library": current}
+
+
 def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs, dm, device, submit_loop, make_slots, slots=None):
     from bbs_sign_amd import Job
 
@@ -58,6 +90,17 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
            # (the comb's table stage makes a proof_gen job longer: it takes 12 in flight to fill the chip where 8 did)
            "proof_gen_12_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 12, 48)}
     out["bls12_381"] = bls
+    # fraction of roofline of the other three operations (counters: profiles/*_counters.json "ops")
+    try:
+        import bench as _bench
+        counters, counters_file = _bench.load_counters()
+        lib_hash = eng.lib.bbs_source_hash().decode()
+        for op, key, k_in in (("sign", "sign_8_in_flight", 8), ("verify", "verify_8_in_flight", 8), ("proof_gen", "proof_gen_12_in_flight", 12)):
+            r = op_roofline(counters, counters_file, lib_hash, op, bls.get(key), k_in)
+            if r:
+                out[op] = r
+    except Exception as e:       # a missing / older counters file must not take the bench down
+        out["ops_roofline_error"] = repr(e)
 
     # ---- the reference's only usable proof_verify bench sweep (benches/proof_verify.rs:145-175): L = 32, R in {1..32}
     sweep = {}

@@ -121,3 +121,83 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
             "prepare_s_rank0": t_prep}))
     for e in engines.values():
         e.close()
+
+
+def run_mixed_pool(args, pc, devices, total=65536, lib_path=None, emit=None, L=32, R=8):
+    """BASELINE configs[4] with ONE process: the list goes through bbs_pool (csrc/pool.hpp) -- partitioned by curve and then
+    contiguously over the pool's member devices INSIDE the library, one submitting thread per member, statuses written into
+    the caller's array in list order.  A step = the whole list once; `ahead` lists are kept in flight
+    (bbs_pool_proof_verify_submit / bbs_pool_job_wait) so that the members never drain between lists.  Every 16th item of the
+    list is corrupted and every list's statuses are compared with that pattern.  Strong scaling over the members."""
+    import time as _time
+
+    import numpy as np
+    from bbs_sign_amd.pool import Pool
+    if emit is None:
+        def emit(line):
+            print(line, flush=True)
+    curve_of_item = ["bls12_381" if (i & 1) else "bn254" for i in range(total)]
+    expect = np.array([0 if i % 16 == 0 else 1 for i in range(total)], dtype=np.int8)
+    pool = Pool(devices, lib_path)
+    pool.set_inflight(max(1, args.inflight))
+    t_prep = _time.perf_counter()
+    sections = []
+    for curve, w in (("bls12_381", args.window_bits), ("bn254", min(args.window_bits, 16))):
+        suite, eng, gens, sk = pc.bench_engine(curve, L, lib_path, w, device=devices[0])
+        ids = [i for i in range(total) if curve_of_item[i] == curve]
+        out_p, out_dm, out_di = [], [], []
+        for lo in range(0, len(ids), 2048):
+            part = ids[lo:lo + 2048]
+            msgs, disclosed, rnds = pc.bench_items(suite, eng, len(part), L, R, ids=part)
+            sigs, st = eng.core_sign_batch(msgs)
+            assert (st == 1).all()
+            proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+            assert (st == 1).all()
+            for g, p in zip(part, proofs):
+                if g % 16 == 0:
+                    p.commitments[0] = (p.commitments[0] + 1) % suite.curve.r
+            out_p += proofs; out_dm += [m[:R] for m in msgs]; out_di += disclosed
+        pk = eng.public_key()
+        eng.close()                                    # the generating engine's tables leave before the pool's are built
+        pool.set_window_bits(curve, w)
+        pool.set_generators(curve, gens, suite.api_id)
+        pool.set_public_key(curve, pk)
+        sections.append(pool.pack(curve, out_p, out_dm, out_di, global_index=ids))
+    t_prep = _time.perf_counter() - t_prep
+    jobs_per_list = sum(-(-(-(-s.n // len(devices))) // args.batch) for s in sections)     # per member: ceil(share / batch) per curve
+    ahead = getattr(args, "lists_in_flight", None) or max(2, -(-max(args.inflight, 8) // max(1, jobs_per_list)))
+    if args.warmup < 0 or args.steps < 1:
+        raise SystemExit("bench_mixed: --steps must be >= 1 and --warmup >= 0 (got %d / %d)" % (args.steps, args.warmup))
+
+    def run_lists(count):
+        out, flying = [], []
+        for _ in range(count):
+            flying.append(pool.submit_packed(sections, n_total=total, max_batch=args.batch))
+            if len(flying) >= ahead:
+                out.append(flying.pop(0).wait())
+        while flying:
+            out.append(flying.pop(0).wait())
+        return out
+
+    for res in run_lists(args.warmup):
+        assert np.array_equal(res, expect), "warm-up statuses differ from the expected pattern"
+    t0 = _time.perf_counter()
+    results = run_lists(args.steps)
+    dt = _time.perf_counter() - t0
+    for res in results:
+        assert np.array_equal(res, expect), "statuses differ from the expected pattern"
+    emit(json.dumps({
+        "metric": "BBS+ proof_verify/sec (mixed BN254 + BLS12-381 list of 65536)", "value": total * args.steps / dt,
+        "unit": "proof_verify/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: %d proof_verify = %d BN254 + %d BLS12-381 (L=%d, R=%d), ONE process: bbs_pool over "
+                               "member devices %s (sharded by curve, then contiguously, inside the library; one submitting thread per "
+                               "member; no collective), jobs of at most %d items from host buffers" % (total, total // 2, total // 2, L, R, devices, args.batch),
+                   "pool_members": len(devices), "jobs_per_member_per_list": jobs_per_list, "batches_in_flight_per_member": args.inflight,
+                   "lists_in_flight": ahead, "single_process": True,
+                   "fixed_base_window_bits": {"bls12_381": args.window_bits, "bn254": min(args.window_bits, 16)}},
+        "checks": {"statuses_exact_every_step": True, "corrupted": "every 16th global item"},
+        "prepare_s": t_prep}))
+    pool.close()
+

@@ -667,8 +667,8 @@ int bbs_selftest_f2dot2(int curve, size_t n_terms, const uint8_t* a, const uint8
  * it.  A pool owns one context per (curve, member device) with the same generators and issuer key on every member; a list
  * is handed over as one section per curve in the layout of bbs_core_proof_verify_batch.  Every section is cut into
  * contiguous shares of ceil(n / members) items, every share into jobs of at most max_batch items, and the jobs of a member
- * run from ONE submitting thread per member through bbs_core_proof_verify_submit (completion-order retire, curves
- * alternating).  The statuses land in the caller's array in the caller's order: one process drives every GPU, so no
+ * run from ONE submitting thread per member (owned by the pool) through bbs_core_proof_verify_submit (completion-order
+ * retire, curves alternating).  The statuses land in the caller's array in the caller's order: one process drives every GPU, so no
  * exchange between processes exists on this path (the one-process-per-GPU launcher of bench.py exchanges them with one
  * all_gather; both partition by the same rule).  Statuses of every item are exactly those of bbs_core_proof_verify_batch
  * on the item's own curve.
@@ -701,9 +701,21 @@ int bbs_pool_set_public_key(bbs_pool* pool, int curve, const uint8_t* pk_affine,
 int bbs_pool_set_inflight(bbs_pool* pool, int jobs_per_member);
 /* member `member`'s context of `curve`, e.g. to run any other operation of this ABI on that device */
 int bbs_pool_context(bbs_pool* pool, int curve, size_t member, bbs_ctx** out);
-/* Verify the list.  Blocks until every status has been written.  max_batch = 0: 4096.  BBS_E_STATE if a section's curve
- * has no generators / public key yet; BBS_E_ARG before anything is submitted if a section is malformed.  One call at a
- * time per pool (calls are serialised inside). */
+/* Verify a list: the sections are cut into jobs and queued to the members' submitting threads (one per member, inside the
+ * library); the call returns at once.  bbs_pool_job_wait blocks until every status of THIS list has been written and returns
+ * the first failure of any member (BBS_OK otherwise); then bbs_pool_job_free.  Several lists may be in flight: a member does
+ * not drain between lists -- the jobs of the next one go in while the last jobs of this one finish -- and lists complete in
+ * submission order per member.  The caller's input buffers AND the bbs_pv_list array's contents must stay valid until
+ * bbs_pool_job_wait has returned (unlike bbs_core_proof_verify_submit, the jobs are staged later, by the members' threads).
+ * max_batch = 0: 4096.  BBS_E_STATE if a section's curve has no generators / public key yet; BBS_E_ARG before anything is
+ * queued if a section is malformed.  The bbs_pool_set_* calls are BBS_E_STATE while a list is in flight.  Free every job
+ * before bbs_pool_destroy. */
+typedef struct bbs_pool_job bbs_pool_job;
+int bbs_pool_proof_verify_submit(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch,
+                                 bbs_pool_job** job_out);
+int bbs_pool_job_wait(bbs_pool_job* job);
+void bbs_pool_job_free(bbs_pool_job* job);
+/* submit + wait + free */
 int bbs_pool_proof_verify(bbs_pool* pool, const bbs_pv_list* lists, size_t n_lists, size_t max_batch);
 
 #ifdef __cplusplus

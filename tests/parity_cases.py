@@ -901,6 +901,18 @@ def check_pool(lib_path=None, devices=(0, 0), per_curve=40, L=4, R=2, window_bit
     for mb in (max_batch, 7, 0):                                          # several jobs per share; ragged jobs; one job per share
         got = pool.proof_verify_mixed(curve_of_item, fetch, max_batch=mb)
         assert [int(x) for x in got] == [int(x) for x in want], (mb, [i for i in range(total) if got[i] != want[i]][:8])
+    # several lists in flight (bbs_pool_proof_verify_submit): the members do not drain between them; every list's own statuses
+    packed = [pool.pack(c2, *fetch(c2, [i for i in range(total) if curve_of_item[i] == c2]), global_index=[i for i in range(total) if curve_of_item[i] == c2])
+              for c2 in sorted(items)]
+    flying = [pool.submit_packed(packed, n_total=total, max_batch=mb) for mb in (max_batch, 5, 0, max_batch)]
+    try:
+        pool.set_window_bits("bls12_381", 8)
+        raise AssertionError("the pool was reconfigured while lists were in flight")
+    except Exception as e:
+        assert getattr(e, "rc", None) == -102, e                          # BBS_E_STATE
+    for f in flying:
+        got = f.wait()
+        assert [int(x) for x in got] == [int(x) for x in want]
     # sections without a global index: per-section status arrays, same verdicts
     secs = [pool.pack(curve, *items[curve][1:]) for curve in sorted(items)]
     got = pool.proof_verify_packed(secs, max_batch=max_batch)

@@ -19,7 +19,35 @@ import sys
 
 STAGE_OF = {"PairDist<BlsCurve>": "pairing_6lane", "PvMsmPart<BlsCurve>": "pv_msm_parts", "PvChallenge<BlsCurve>": "pv_challenge",
             "PvScalars<BlsCurve>": "pv_scalars", "PvFinish": "pv_finish", "PairMillerHalf<BlsCurve>": "pair_miller",
-            "PairFinalDist<BlsCurve>": "pair_final_exp", "PairMillerBoth<BlsCurve>": "pair_miller_both"}
+            "PairFinalDist<BlsCurve>": "pair_final_exp", "PairMillerBoth<BlsCurve>": "pair_miller_both",
+            # round 5: the multi-scalar multiplication as kernels of their own (stages.hpp)
+            "PvT1Chain<BlsCurve>": "pv_t1_chain", "PvVarMul<BlsCurve>": "pv_var_mul", "PvFixedChunk<BlsCurve>": "pv_fixed_chunks",
+            "PvChains<BlsCurve>": "pv_chains"}
+# the other three operations (tools/run_profile_ops.sh -> <prefix>_pmc_ops.csv): kernel -> stage name, per operation; SURVEY 8(d)'s
+# algorithmic bytes per item (BLS12-381, L = 32, R = 8)
+OPS = {"sign": {"alg_bytes": 1104, "kernels": {"VfIngest<BlsCurve>": "sg_ingest", "SgScalars<BlsCurve>": "sg_scalars", "SgMsmPart<BlsCurve>": "sg_msm_parts",
+                                               "SgCombine<BlsCurve>": "sg_combine", "SgEmit<BlsCurve>": "sg_emit"}},
+       "verify": {"alg_bytes": 1105, "kernels": {"VfIngest<BlsCurve>": "vf_ingest", "VfScalars<BlsCurve>": "vf_scalars", "VfVarMul<BlsCurve>": "vf_var_mul",
+                                                 "VfFixedChunk<BlsCurve>": "vf_fixed_chunks", "VfCombine<BlsCurve>": "vf_combine", "PairDist<BlsCurve>": "pairing_6lane"}},
+       "proof_gen": {"alg_bytes": 3136, "kernels": {"PgIngest<BlsCurve>": "pg_ingest", "PgScalars<BlsCurve>": "pg_scalars", "PgBPart<BlsCurve>": "pg_b_parts",
+                                                    "PgBCombine<BlsCurve>": "pg_b_combine", "PgTables<BlsCurve>": "pg_tables", "PgVarPart<BlsCurve>": "pg_var_parts",
+                                                    "PgFinalize<BlsCurve>": "pg_finalize", "PgEmit<BlsCurve>": "pg_emit"}}}
+
+
+def load_occupancy(path):
+    """waves per SIMD of every kernel from tools/kernel_meta.sh output (<prefix>_kernel_meta.txt): 512 registers per lane and
+    SIMD, a wavefront takes vgpr + agpr of them (allocation granule 8); 1 when the file is missing"""
+    import os
+    import re
+    occ = {}
+    if not os.path.exists(path):
+        return occ
+    for line in open(path):
+        m = re.match(r"\d*(\w+?)INS1_\d+(\w+?)E.*vgpr=(\d+) agpr=(\d+)", line.strip())
+        if m:
+            regs = -(-max(int(m.group(3)) + int(m.group(4)), 1) // 8) * 8
+            occ["%s<%s>" % (m.group(1), m.group(2))] = max(1, min(8, 512 // regs))
+    return occ
 SIMPLE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32",
           "v_mov_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32", "v_not_b32", "v_max_i32", "v_min_i32", "v_max_u32",
           "v_min_u32", "v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32", "v_mul_i32_i24", "v_mul_u32_u24", "v_bfrev_b32"}
@@ -74,6 +102,43 @@ def classify(op):
     return "vop3"
 
 
+def model_ops(pre, ub, hist, occupancy, classify):
+    """sign / verify / proof_gen from <prefix>_pmc_ops.csv: per kernel the counters of one 4096-item launch and the modelled
+    issue cost of its opcode mix (ns per wave-instruction per SIMD at the occupancy its registers allow)"""
+    import os
+    path = pre + "_pmc_ops.csv"
+    if not os.path.exists(path):
+        return None
+    pmc = collections.defaultdict(lambda: collections.defaultdict(dict))
+    for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):
+        pmc[r["op"]][r["kernel"]][r["counter"]] = float(r["mean_per_launch"])
+    out = {}
+    any_hist = hist.get("PvT1Chain<BlsCurve>") or next(iter(hist.values()))
+    for op, spec in OPS.items():
+        ks = {}
+        for k, stage in spec["kernels"].items():
+            c = pmc.get(op, {}).get(k)
+            if not c or "SQ_INSTS_VALU" not in c:
+                continue
+            h = hist.get(k) or any_hist
+            tot = sum(h.values())
+            share = collections.Counter()
+            for o, nn in h.items():
+                share[classify(o)] += nn / tot
+            w = min(2, occupancy.get(k, 1))
+            ns = sum(share[cl] * class_costs_ns(ub, w)[cl] for cl in share)
+            ks[stage] = {"kernel": k, "valu_insts": c["SQ_INSTS_VALU"], "FETCH_SIZE_KiB": c.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": c.get("WRITE_SIZE", 0.0),
+                         "waves": c.get("SQ_WAVES"), "waves_per_simd": w, "ns_per_inst_at_that_occupancy": round(ns, 4),
+                         "ns_per_inst_if_waves_per_simd": {str(x): round(sum(share[cl] * class_costs_ns(ub, x)[cl] for cl in share), 4) for x in (1, 2, 4, 8)},
+                         "own_isa_histogram": bool(hist.get(k)), "duration_ns_exclusive": c.get("duration_ns")}
+        if ks:
+            out[op] = {"alg_bytes_per_item": spec["alg_bytes"], "items_per_launch": 4096, "kernels": ks}
+            print("%-10s %d kernels, %.4g VALU wave-instructions per 4096-item job, traffic %.1f MB" % (
+                op, len(ks), sum(v["valu_insts"] for v in ks.values()),
+                sum(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"] for v in ks.values()) * 1024 / 1e6))
+    return out or None
+
+
 def main():
     pre = sys.argv[1]
     ub = load_ubench(pre + "_ubench_valu_int.csv")
@@ -87,15 +152,17 @@ def main():
             if r["opcode"].startswith("v_"):
                 hist[r["kernel"]][r["opcode"]] += int(r["count"])
     kernels = {}
+    occupancy = load_occupancy(pre + "_kernel_meta.txt")
     print("%-24s %12s %7s %7s %7s %7s %9s" % ("kernel", "SQ_INSTS_VALU", "mad", "vop3", "simple", "carry", "cyc/inst"))
     for k, stage in STAGE_OF.items():
         if k not in pmc or "SQ_INSTS_VALU" not in pmc[k]:
             continue
         c = pmc[k]
-        waves_per_simd = 1            # every proof_verify kernel runs one wavefront per SIMD (registers): DESIGN.md 5
+        # waves per SIMD the kernel's registers allow (the big kernels: one; the fixed-base chunks since round 5: two)
+        waves_per_simd = min(2, occupancy.get(k, 1))
         cost = class_costs(ub, waves_per_simd)
         own = bool(hist.get(k))
-        h = hist.get(k) or hist.get("PvMsmPart<BlsCurve>")      # no histogram of its own (older profile sets): the MSM kernel's mix
+        h = hist.get(k) or hist.get("PvT1Chain<BlsCurve>") or hist.get("PvMsmPart<BlsCurve>")      # no histogram of its own: a chain kernel's mix
         tot = sum(h.values())
         share = collections.Counter()
         for op, n in h.items():
@@ -125,7 +192,8 @@ def main():
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bbs_sign_amd import build as _build
-    out = {"kernels": kernels, "clock_ghz_under_load": clock, "library_source_hash": os.environ.get("BBS_PROFILED_HASH") or _build.source_hash(),
+    ops = model_ops(pre, ub, hist, occupancy, classify)
+    out = {"kernels": kernels, "ops": ops, "clock_ghz_under_load": clock, "library_source_hash": os.environ.get("BBS_PROFILED_HASH") or _build.source_hash(),
            "source": "%s_{pmc,ubench_valu_int,isa_histogram}.csv via tools/valu_model.py" % pre,
            "note": "SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE: rocprofv3 --pmc, mean of the last launches, one 4096-item BLS12-381 batch; rocprofv3 "
                    "serialises dispatches while collecting counters, so cycle counters are exclusive-run values; clock = GRBM_GUI_ACTIVE / 8 / kernel duration"}
