@@ -5,11 +5,15 @@
 
 // ---- proof_verify ----------------------------------------------------------------------------
 // where a job's doubling chains run (see pv_upload): 3 / 2 / 1; BBS_PV_MSM_LAYOUT overrides (A/B), read once.
-// one_queue: the job is meant to own ONE hardware queue (batch verification's throughput form keeps many jobs alive)
-inline int pv_msm_layout(bool one_queue) {
+// one_queue: the job is meant to own ONE hardware queue (batch verification's throughput form keeps many jobs alive).
+// latency_form: T1's three terms are single multiplications (PvVarMul parts 0 .. 2): all four multiplications go to the side
+// stream as one launch, so that the main stream's scalars -> fixed-base chunks run BESIDE them -- on the main stream in front
+// of the scalars they made the MSM chain (2.85 + 0.13 + 0.9 + 0.6 ms) longer than the pairing (4.2 ms) it runs beside:
+// one batch at a time 4.7 against 4.35 ms (profiles/r05_a_ab_split_msm_layouts.log, new3 vs new2).
+inline int pv_msm_layout(bool one_queue, bool latency_form) {
     static const int forced = []() { const char* v = getenv("BBS_PV_MSM_LAYOUT"); const int k = v ? atoi(v) : 0; return (k >= 1 && k <= 3) ? k : 0; }();
     if (forced) return forced;
-    return one_queue ? 1 : 3;
+    return one_queue ? 1 : (latency_form ? 2 : 3);
 }
 template <class C>
 struct PvJob : JobBase<C> {
@@ -168,8 +172,9 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         // follows the MSM chain (verify: 7.4 -> 6.9 ms), but beside the 768 wavefronts of this operation's latency-form MSM
         // chain it oversubscribes the 1024 SIMDs and the queued wavefronts cost more than the split saves (measured
         // 5.1 ms split vs 4.4 ms fused, profiles/r03_j_latency_form_split.log)
-        add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane", false, 0, false);
-        msm_chain(pv_msm_layout(false));
+        static const bool lat_split = []() { const char* v = getenv("BBS_PV_LAT_SPLIT"); return v && atoi(v) != 0; }();      // A/B knob
+        add_pairing_stages<C>(j, &j->pa, 1, "pair_miller", "pair_final_exp", "pairing_6lane", false, 0, lat_split);
+        msm_chain(pv_msm_layout(false, job->latency_form));
         j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
         j->stages.push_back({"pv_finish", [j]() { return rt::launch<PvFinish>(j->stream(), j->fin, j->n); }, 0, 1});
     } else {
@@ -183,7 +188,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         const int aux = job->latency_form ? 1 : 0;
         if (aux && (rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
                                                   job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1, true))) return rc;
-        msm_chain(pv_msm_layout(!aux));
+        msm_chain(pv_msm_layout(!aux, job->latency_form));
         if (aux) {
             j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
         } else {

@@ -86,6 +86,16 @@ __device__ __forceinline__ Fp2<C> d_coef(const Lane6& L, const Fp2<C>& g, int sr
 #ifndef BBS_DIST_UNROLL
 #define BBS_DIST_UNROLL 1        // iterations of the dot-product loops kept rolled (1) or unrolled (6 / 4): A/B knob
 #endif
+// 1 (round 5): the factor xi of a wrapped term (w^6 = xi) is applied by the lane that PUBLISHES the operand, not by the lane
+// that fetches it.  Every fetched operand used to be multiplied by xi on every lane (two limb chains) and then selected -- per
+// term of every dot product; but in each step of each operation a lane's value is fetched by lanes that all want the same form
+// of it (plain, or times xi), and which form depends only on the publishing lane's own index and the step.  So a lane
+// computes xi * (its coefficient) ONCE per operation and publishes the form its readers want: one select per term instead of
+// a multiplication by xi and a select.  Same field elements term by term (checked by the six-lane self-tests against the
+// oracle's Fp12); A/B knob.
+#ifndef BBS_DIST_XI_AT_SOURCE
+#define BBS_DIST_XI_AT_SOURCE 1
+#endif
 #if BBS_DIST_LAZY
 // f * h: lane k computes its own output coefficient  c_k = sum_j g_j h_{(k-j) mod 6} xi^[j > k]  as ONE Fp2 dot
 // product (tower.hpp F2Acc): the six products are accumulated as unreduced column sums and reduced once --
@@ -122,13 +132,21 @@ __device__ __attribute__((noinline)) Fp2<C> d_mul(const Lane6& L, const Fp2<C>& 
 #else
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
+#if BBS_DIST_XI_AT_SOURCE
+    // the reader of this lane's h at step j is lane (k + j) mod 6, and it wrapped (wants xi h) iff k + j >= 6
+    const Fp2<C> hx = f2_mul_xi<C>(h);
+#endif
 #pragma unroll BBS_DIST_UNROLL
     for (int j = 0; j < GRP; j++) {
         const Fp2<C> a = d_coef<C>(L, g, j);
         int src = k - j;
         if (src < 0) src += GRP;
+#if BBS_DIST_XI_AT_SOURCE
+        const Fp2<C> b = d_coef<C>(L, f2_sel<C>(k + j >= GRP, hx, h), src);
+#else
         Fp2<C> b = d_coef<C>(L, h, src);
         b = f2_sel<C>(j > k, f2_mul_xi<C>(b), b);
+#endif
         f2acc_mac<C, 1>(acc, a, b);
     }
     return f2acc_finish<C>(acc);
@@ -189,15 +207,28 @@ BBS_DIST_MILLER Fp2<C> d_sqr(const Lane6& L, const Fp2<C>& g) {
 #else
     F2Acc<C> acc;
     f2acc_zero<C>(acc);
+#if BBS_DIST_XI_AT_SOURCE
+    // who reads this lane's g as the SECOND factor of slot s, and does the pair wrap (i + j >= 6)?  From the table above: slot 0
+    // never wraps; slot 1: lanes 3 and 5 are read by wrapping pairs only ((3,3), (2,5)), lanes 2 and 4 by plain ones; slots 2
+    // and 3: lanes 4 and 5 by wrapping pairs only ((3,4), (4,4), (1,5), (4,5) / (2,4), (3,5), (5,5)), lane 3 by plain ones.
+    const Fp2<C> gx = f2_mul_xi<C>(g);
+    // bit s of the mask: this lane publishes xi g in slot s
+    const uint32_t xmask = (k == 3) ? 0x2u : ((k == 4) ? 0xCu : ((k == 5) ? 0xEu : 0u));
+#endif
 #pragma unroll BBS_DIST_UNROLL
     for (int s = 0; s < 4; s++) {
         const uint32_t i = (pk >> (6 * s)) & 7u, j = (pk >> (6 * s + 3)) & 7u;
         const bool used = i != 7u;
         const uint32_t ii = used ? i : 0u, jj = used ? j : 0u;
         Fp2<C> a = d_coef<C>(L, g, (int)ii);
+#if BBS_DIST_XI_AT_SOURCE
+        const Fp2<C> b = d_coef<C>(L, f2_sel<C>(((xmask >> s) & 1u) != 0, gx, g), (int)jj);
+        a = f2_sel<C>(used, a, f2_zero<C>());
+#else
         Fp2<C> b = d_coef<C>(L, g, (int)jj);
         a = f2_sel<C>(used, a, f2_zero<C>());
         b = f2_sel<C>(ii + jj >= (uint32_t)GRP, f2_mul_xi<C>(b), b);
+#endif
         f2acc_mac_sh<C>(acc, a, b, (used && ii != jj) ? 1u : 0u);
     }
     return f2acc_finish<C>(acc);
@@ -323,10 +354,18 @@ BBS_DIST_MILLER Fp2<C> d_mul_line(const Lane6& L, const Fp2<C>& g, const LineEnt
     // l = c + lx w^2 + yP w^3 (M twist) :  c_k = g_k c + xi^[k<2] g_{k-2} lx + xi^[k<3] g_{k-3} yP
     // l = yP + lx w + c w^3   (D twist) :  c_k = g_k yP + xi^[k<1] g_{k-1} lx + xi^[k<3] g_{k-3} c
     constexpr int SA = C::K::TWIST_M ? 2 : 1;
+#if BBS_DIST_XI_AT_SOURCE
+    // g_(k - SA) is read from lane k - SA + 6 exactly when it wraps: lanes >= 6 - SA publish xi g for the first fetch, lanes
+    // >= 3 for the second
+    const Fp2<C> gx = f2_mul_xi<C>(g);
+    const Fp2<C> a = d_coef<C>(L, f2_sel<C>(k >= GRP - SA, gx, g), k < SA ? k + GRP - SA : k - SA);
+    const Fp2<C> b = d_coef<C>(L, f2_sel<C>(k >= 3, gx, g), k < 3 ? k + 3 : k - 3);
+#else
     Fp2<C> a = d_coef<C>(L, g, k < SA ? k + GRP - SA : k - SA);
     Fp2<C> b = d_coef<C>(L, g, k < 3 ? k + 3 : k - 3);
     a = f2_sel<C>(k < SA, f2_mul_xi<C>(a), a);
     b = f2_sel<C>(k < 3, f2_mul_xi<C>(b), b);
+#endif
 #if BBS_DIST_TWOPASS_MILLER
     F2AccLo<C> lo;
     f2acc_lo_zero<C>(lo);

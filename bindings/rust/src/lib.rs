@@ -65,8 +65,118 @@ extern "C" {
     fn bbs_issuer_proof_verify(issuer: *mut BbsIssuer, n: usize, proof_octets: *const u8, oct_off: *const u64,
         msg_bytes: *const u8, msg_byte_off: *const u64, msg_item_off: *const u64, disclosed_idx: *const u64, didx_off: *const u64,
         headers: *const u8, hdr_off: *const u64, ph: *const u8, ph_off: *const u64, status: *mut i8) -> c_int;
+    // a list of proofs over SEVERAL GPUs from one process (the multi-GPU fan-out is inside the library): see `GpuPool`
+    fn bbs_pool_create(device_ids: *const c_int, n_devices: usize, out: *mut *mut BbsPool) -> c_int;
+    fn bbs_pool_destroy(pool: *mut BbsPool);
+    fn bbs_pool_device_count(pool: *const BbsPool) -> usize;
+    fn bbs_pool_set_window_bits(pool: *mut BbsPool, curve: c_int, bits: c_int) -> c_int;
+    fn bbs_pool_set_generators(pool: *mut BbsPool, curve: c_int, gens: *const u8, count: usize, api_id: *const u8, api_id_len: usize) -> c_int;
+    fn bbs_pool_set_public_key(pool: *mut BbsPool, curve: c_int, pk: *const u8, is_identity: c_int) -> c_int;
+    fn bbs_pool_set_inflight(pool: *mut BbsPool, jobs_per_member: c_int) -> c_int;
+    fn bbs_pool_proof_verify_submit(pool: *mut BbsPool, lists: *const BbsPvList, n_lists: usize, max_batch: usize, job_out: *mut *mut BbsPoolJob) -> c_int;
+    fn bbs_pool_job_wait(job: *mut BbsPoolJob) -> c_int;
+    fn bbs_pool_job_free(job: *mut BbsPoolJob);
+    fn bbs_pool_proof_verify(pool: *mut BbsPool, lists: *const BbsPvList, n_lists: usize, max_batch: usize) -> c_int;
+    fn bbs_runtime_queue_budget(device_id: c_int, total: *mut c_int, pool: *mut c_int, dedicated_cap: *mut c_int, scratch_bytes_per_lane: *mut usize) -> c_int;
 }
 #[repr(C)] pub struct BbsIssuer { _p: [u8; 0] }
+#[repr(C)] pub struct BbsPool { _p: [u8; 0] }
+#[repr(C)] pub struct BbsPoolJob { _p: [u8; 0] }
+/// `struct bbs_pv_list` of the header: the items of ONE curve of a list, in the layout of `bbs_core_proof_verify_submit`.
+#[repr(C)]
+pub struct BbsPvList {
+    pub curve: c_int, pub n: usize,
+    pub proofs_fixed: *const u8, pub commitments: *const u8, pub commit_off: *const u64,
+    pub disclosed_msgs: *const u8, pub dmsg_off: *const u64, pub disclosed_idx: *const u64, pub didx_off: *const u64,
+    pub headers: *const u8, pub hdr_off: *const u64, pub ph: *const u8, pub ph_off: *const u64,
+    pub global_index: *const u64, pub status: *mut i8,
+}
+
+/// `core_proof_verify` (src/proof_verify.rs:64-116) over a LIST of proofs on SEVERAL GPUs from one process -- north_star's
+/// "Rust host -> C ABI -> 8 GPUs".  The library owns one context per (curve, device) and one submitting thread per device; a
+/// list is one `PackedProofs` per curve (what `GpuIssuer::proof_verify_submit` packs for one context); the statuses come back
+/// in the caller's order.  Partition: by curve, then contiguous ceil(n / devices) items per device.
+pub struct GpuPool { pool: *mut BbsPool }
+/// one curve's items of a list, packed (owned buffers: they must outlive the call / the job)
+pub struct PackedProofs {
+    pub curve: c_int, pub n: usize, pub proofs_fixed: Vec<u8>, pub commitments: Vec<u8>, pub commit_off: Vec<u64>,
+    pub disclosed_msgs: Vec<u8>, pub dmsg_off: Vec<u64>, pub disclosed_idx: Vec<u64>, pub didx_off: Vec<u64>,
+    pub headers: Vec<u8>, pub hdr_off: Vec<u64>, pub ph: Vec<u8>, pub ph_off: Vec<u64>,
+    /// position of item k of this section in the caller's whole list
+    pub global_index: Vec<u64>,
+}
+impl GpuPool {
+    pub fn new(devices: &[c_int]) -> Self {
+        assert!(!devices.is_empty(), "GpuPool: at least one device");
+        let mut pool = std::ptr::null_mut();
+        let rc = unsafe { bbs_pool_create(devices.as_ptr(), devices.len(), &mut pool) };
+        assert_eq!(rc, 0, "bbs_pool_create: {rc}");
+        let me = GpuPool { pool };
+        assert_eq!(unsafe { bbs_pool_device_count(me.pool) }, devices.len());
+        me
+    }
+    /// the same generators and issuer key on every device (`generators_le` / `pk_affine_le`: the records of the header)
+    pub fn configure<E: GpuCurve>(&self, generators_le: &[u8], count: usize, api_id: &[u8], pk_affine_le: &[u8], jobs_per_device: c_int) {
+        let fpb = unsafe { bbs_fp_bytes(E::CURVE_ID) };
+        assert_eq!(generators_le.len(), count * 2 * fpb, "generators: {count} affine points of {} bytes", 2 * fpb);
+        assert_eq!(pk_affine_le.len(), 4 * fpb, "public key record: 4 x {fpb} bytes");
+        unsafe {
+            assert_eq!(bbs_pool_set_window_bits(self.pool, E::CURVE_ID, 0), 0);          // width by free device memory
+            assert_eq!(bbs_pool_set_generators(self.pool, E::CURVE_ID, generators_le.as_ptr(), count, api_id.as_ptr(), api_id.len()), 0);
+            assert_eq!(bbs_pool_set_public_key(self.pool, E::CURVE_ID, pk_affine_le.as_ptr(), 0), 0);
+            assert_eq!(bbs_pool_set_inflight(self.pool, jobs_per_device), 0);
+        }
+    }
+    /// The whole list, blocking; `total` = length of the caller's list (every section's `global_index` points into it).
+    pub fn proof_verify(&self, sections: &[PackedProofs], total: usize) -> Vec<Result<bool, ProofGenError>> {
+        let mut status = vec![-128i8; total.max(1)];
+        let lists = Self::lists(sections, total, &mut status);
+        let rc = unsafe { bbs_pool_proof_verify(self.pool, lists.as_ptr(), lists.len(), 0) };
+        assert_eq!(rc, 0, "bbs_pool_proof_verify: {rc}");
+        status[..total].iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
+    }
+    /// The same without waiting: several lists may be in flight (a device does not drain between them).
+    pub fn proof_verify_submit<'a>(&'a self, sections: &'a [PackedProofs], total: usize) -> PendingList<'a> {
+        let mut status = vec![-128i8; total.max(1)];
+        let lists = Self::lists(sections, total, &mut status);
+        let mut job = std::ptr::null_mut();
+        let rc = unsafe { bbs_pool_proof_verify_submit(self.pool, lists.as_ptr(), lists.len(), 0, &mut job) };
+        assert_eq!(rc, 0, "bbs_pool_proof_verify_submit: {rc}");
+        PendingList { job, status, total, _lists: lists, _sections: sections }
+    }
+    fn lists(sections: &[PackedProofs], total: usize, status: &mut Vec<i8>) -> Vec<BbsPvList> {
+        sections.iter().map(|s| {
+            // every length the library will read, checked before the call
+            assert!(s.commit_off.len() == s.n + 1 && s.dmsg_off.len() == s.n + 1 && s.didx_off.len() == s.n + 1
+                    && s.hdr_off.len() == s.n + 1 && s.ph_off.len() == s.n + 1 && s.global_index.len() == s.n, "PackedProofs: offsets per item");
+            assert!(s.global_index.iter().all(|&g| (g as usize) < total), "PackedProofs: global index out of the list");
+            BbsPvList { curve: s.curve, n: s.n, proofs_fixed: s.proofs_fixed.as_ptr(), commitments: s.commitments.as_ptr(), commit_off: s.commit_off.as_ptr(),
+                        disclosed_msgs: s.disclosed_msgs.as_ptr(), dmsg_off: s.dmsg_off.as_ptr(), disclosed_idx: s.disclosed_idx.as_ptr(), didx_off: s.didx_off.as_ptr(),
+                        headers: s.headers.as_ptr(), hdr_off: s.hdr_off.as_ptr(), ph: s.ph.as_ptr(), ph_off: s.ph_off.as_ptr(),
+                        global_index: s.global_index.as_ptr(), status: status.as_mut_ptr() }
+        }).collect()
+    }
+    /// hardware queues the library will use on a device (pooled + dedicated) and the kernel frame that sets the bound
+    pub fn queue_budget(device: c_int) -> (c_int, c_int, c_int, usize) {
+        let (mut t, mut p, mut d, mut s) = (0, 0, 0, 0usize);
+        let rc = unsafe { bbs_runtime_queue_budget(device, &mut t, &mut p, &mut d, &mut s) };
+        assert_eq!(rc, 0, "bbs_runtime_queue_budget: {rc}");
+        (t, p, d, s)
+    }
+}
+impl Drop for GpuPool { fn drop(&mut self) { unsafe { bbs_pool_destroy(self.pool) } } }
+/// a list in flight on the pool; borrows the pool and the packed sections, which therefore outlive it
+pub struct PendingList<'a> { job: *mut BbsPoolJob, status: Vec<i8>, total: usize, _lists: Vec<BbsPvList>, _sections: &'a [PackedProofs] }
+impl<'a> PendingList<'a> {
+    pub fn wait(mut self) -> Vec<Result<bool, ProofGenError>> {
+        let rc = unsafe { bbs_pool_job_wait(self.job) };
+        unsafe { bbs_pool_job_free(self.job) };
+        self.job = std::ptr::null_mut();
+        assert_eq!(rc, 0, "bbs_pool_job_wait: {rc}");
+        self.status[..self.total].iter().map(|&s| match s { 1 => Ok(true), 0 => Ok(false), e => Err(proof_error(e)) }).collect()
+    }
+}
+impl<'a> Drop for PendingList<'a> { fn drop(&mut self) { if !self.job.is_null() { unsafe { bbs_pool_job_free(self.job) } } } }
 
 /// `proof_verify` (src/proof_verify.rs:19-61) for a list of proofs whose numbers of messages differ: the reference derives the
 /// generators from `proof.commitments.len() + disclosed_indexes.len() + 1` on every call (:40-43); here the library keeps

@@ -22,6 +22,13 @@
 
 enum { L = 3, N = 4 };                 /* messages per item, items per batch */
 
+/* what run_curve leaves for run_pool: the three valid proofs of the curve with everything bbs_core_proof_verify_submit takes */
+static struct {
+    uint8_t gens[(L + 1) * 2 * 48], pk[4 * 48], pf[3 * (6 * 48 + 128)], cm[N * L * 32], dm[4 * 32], hdr[16], ph[4];
+    uint64_t cmo[4], dmo[4], di[4], dio[4], ho[4], po[4];
+    char api_id[128];
+} saved[2];
+
 static const char* SUITE_ID[2] = {"BBS_BLS12381G1_XMD:SHA-256_SSWU_RO_", "BBS_QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_"};
 
 /* the shim's msg_to_scalars(): every message of every item in one bbs_hash_to_scalar_batch call */
@@ -308,6 +315,13 @@ static int run_curve(int curve) {
         bbs_issuer_destroy(issuer);
     }
 
+    /* kept for run_pool */
+    memcpy(saved[curve].gens, gens, (L + 1) * 2 * fpb); memcpy(saved[curve].pk, pk, 4 * fpb); memcpy(saved[curve].pf, pf, 3 * pf_rec);
+    memcpy(saved[curve].cm, cm, sizeof cm); memcpy(saved[curve].dm, dm, sizeof dm); memcpy(saved[curve].hdr, hdr4, 15); memcpy(saved[curve].ph, ph_bytes, 2);
+    for (int i = 0; i < 4; i++) { saved[curve].cmo[i] = cmo[i]; saved[curve].dmo[i] = dmo[i]; saved[curve].dio[i] = dio3[i]; saved[curve].ho[i] = ho4[i]; saved[curve].po[i] = po[i]; }
+    for (int i = 0; i < 3; i++) saved[curve].di[i] = di[i];
+    snprintf(saved[curve].api_id, sizeof saved[curve].api_id, "%s", api_id);
+
     bbs_ctx_destroy(vctx);                                                                                               /* step 18 */
     bbs_ctx_destroy(ctx);
     free(gens); free(pf);
@@ -315,10 +329,62 @@ static int run_curve(int curve) {
     return 0;
 }
 
+/* GpuPool of the shim: a MIXED list (item i of curve i & 1 ... here BLS12-381 at the even positions) over a pool of two members,
+ * both on device 0 -- two context sets on one GPU, what a one-GPU box can show of the multi-GPU fan-out behind the ABI. */
+static void run_pool(void) {
+    int devs[2] = {0, 0};
+    bbs_pool* pool = NULL;
+    CHECK(bbs_pool_create(devs, 2, &pool) == BBS_OK && pool && bbs_pool_device_count(pool) == 2);                        /* step 19 */
+    for (int c = 0; c < 2; c++) {
+        CHECK(bbs_pool_set_window_bits(pool, c, 5) == BBS_OK);                                                           /* step 20 */
+        CHECK(bbs_pool_set_generators(pool, c, saved[c].gens, L + 1, (const uint8_t*)saved[c].api_id, strlen(saved[c].api_id)) == BBS_OK);
+        CHECK(bbs_pool_set_public_key(pool, c, saved[c].pk, 0) == BBS_OK);
+    }
+    CHECK(bbs_pool_set_inflight(pool, 3) == BBS_OK);
+    int qt = 0, qp = 0, qd = 0;
+    size_t qs = 0;
+    CHECK(bbs_runtime_queue_budget(0, &qt, &qp, &qd, &qs) == BBS_OK && qt >= 0 && qd == (qt > qp ? qt - qp : 0));
+    /* the list: BLS12-381 proofs at positions 0, 2, 4, BN254 proofs at 1, 3, 5 */
+    uint64_t gi[2][3] = {{0, 2, 4}, {1, 3, 5}};
+    int8_t status[6];
+    bbs_pv_list lists[2];
+    for (int c = 0; c < 2; c++) {
+        memset(&lists[c], 0, sizeof lists[c]);
+        lists[c].curve = c; lists[c].n = 3; lists[c].proofs_fixed = saved[c].pf;
+        lists[c].commitments = saved[c].cm; lists[c].commit_off = saved[c].cmo; lists[c].disclosed_msgs = saved[c].dm; lists[c].dmsg_off = saved[c].dmo;
+        lists[c].disclosed_idx = saved[c].di; lists[c].didx_off = saved[c].dio; lists[c].headers = saved[c].hdr; lists[c].hdr_off = saved[c].ho;
+        lists[c].ph = saved[c].ph; lists[c].ph_off = saved[c].po; lists[c].global_index = gi[c]; lists[c].status = status;
+    }
+    memset(status, 99, sizeof status);
+    CHECK(bbs_pool_proof_verify(pool, lists, 2, 2) == BBS_OK);          /* shares of 2 + 1 items per member and curve */     /* step 21 */
+    for (int i = 0; i < 6; i++) CHECK(status[i] == 1);
+    /* one commitment of the BN254 item at list position 3 altered; two lists in flight, the second one clean again */
+    uint8_t cm_bad[N * L * 32];
+    memcpy(cm_bad, saved[1].cm, sizeof cm_bad);
+    cm_bad[32 * saved[1].cmo[1]] ^= 1;
+    int8_t st_bad[6], st_ok[6];
+    bbs_pv_list bad[2] = {lists[0], lists[1]}, ok[2] = {lists[0], lists[1]};
+    bad[1].commitments = cm_bad; bad[0].status = st_bad; bad[1].status = st_bad; ok[0].status = st_ok; ok[1].status = st_ok;
+    memset(st_bad, 99, 6); memset(st_ok, 99, 6);
+    bbs_pool_job *j1 = NULL, *j2 = NULL;
+    CHECK(bbs_pool_proof_verify_submit(pool, bad, 2, 0, &j1) == BBS_OK && j1);                                           /* step 22 */
+    CHECK(bbs_pool_proof_verify_submit(pool, ok, 2, 1, &j2) == BBS_OK && j2);
+    CHECK(bbs_pool_set_window_bits(pool, 0, 5) == BBS_E_STATE);          /* no reconfiguration while lists are in flight */
+    CHECK(bbs_pool_job_wait(j1) == BBS_OK && bbs_pool_job_wait(j2) == BBS_OK);                                           /* step 23 */
+    bbs_pool_job_free(j1); bbs_pool_job_free(j2);
+    for (int i = 0; i < 6; i++) CHECK(st_bad[i] == (i == 3 ? 0 : 1) && st_ok[i] == 1);
+    bbs_ctx* c1 = NULL;
+    CHECK(bbs_pool_context(pool, BBS_CURVE_BN254, 1, &c1) == BBS_OK && c1);
+    CHECK(bbs_pool_context(pool, BBS_CURVE_BN254, 2, &c1) == BBS_E_ARG);
+    bbs_pool_destroy(pool);                                                                                              /* step 24 */
+    printf("pool: mixed list over two members ok (queue budget: %d queues, pool %d, kernel frame %zu B per lane)\n", qt, qp, qs);
+}
+
 int main(void) {
     printf("%s\n", bbs_version());
     run_curve(BBS_CURVE_BLS12_381);
     run_curve(BBS_CURVE_BN254);
+    run_pool();
     printf("all checks passed\n");
     return 0;
 }
