@@ -154,11 +154,18 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
     //   2 : all chains as ONE launch on the second side stream
     //   1 : all chains as one launch on the main stream behind the fixed-base chunks (a job that owns one hardware queue:
     //       batch verification's throughput form)
-    auto msm_chain = [j](int layout) {
+    // chains_behind_scalars (layout 2 only): the side stream forks behind the scalar stage instead of in front of it.  Batch
+    // verification's latency form runs its bucket kernel (k_pip_window: workgroups of four wavefronts that need room on ONE
+    // compute unit together) on the first side stream from the start; chains that start at the same moment spread a long
+    // wavefront over every compute unit first and the bucket workgroups then wait for whole compute units (measured: that
+    // kernel 1.3 -> 4.1 ms, the batch 4.8 -> 7.6 ms, profiles/r05_g_single_batch_forms.log).  0.14 ms later they come second.
+    auto msm_chain = [j](int layout, bool chains_behind_scalars = false) {
+        auto chains2 = [j]() { j->stages.push_back({"pv_chains", [j]() { return rt::launch<PvChains<C>>(j->stream_aux(2), j->a, j->n * PvChains<C>::units(j->a)); }, 2, 0}); };
         if (layout == 3) j->stages.push_back({"pv_t1_chain", [j]() { return rt::launch<PvT1Chain<C>>(j->stream_aux(2), j->a, j->n); }, 2, 0});
-        if (layout == 2) j->stages.push_back({"pv_chains", [j]() { return rt::launch<PvChains<C>>(j->stream_aux(2), j->a, j->n * PvChains<C>::units(j->a)); }, 2, 0});
+        if (layout == 2 && !chains_behind_scalars) chains2();
         if (layout == 3) j->stages.push_back({"pv_var_mul", [j]() { return rt::launch<PvVarMul<C>>(j->stream(), j->a, j->n * (size_t)(j->a.nvar - PvVarMul<C>::first_part(j->a))); }});
         j->stages.push_back({"pv_scalars", [j]() { return rt::launch<PvScalars<C>>(j->stream(), j->a, j->n); }});
+        if (layout == 2 && chains_behind_scalars) chains2();
         if (j->a.fixwk.pts0) j->stages.push_back({"pv_fixed_tree", [j]() { return rt::launch<PvFixedTree<C>>(j->stream(), j->a, j->n); }});
         else j->stages.push_back({"pv_fixed_chunks", [j]() { return rt::launch<PvFixedChunk<C>>(j->stream(), j->a, j->n * (size_t)NFIX); }});
         if (layout == 1) j->stages.push_back({"pv_chains", [j]() { return rt::launch<PvChains<C>>(j->stream(), j->a, j->n * PvChains<C>::units(j->a)); }});
@@ -188,7 +195,7 @@ int pv_upload(Ctx<C>* ctx, size_t n, const uint8_t* proofs_fixed, const uint8_t*
         const int aux = job->latency_form ? 1 : 0;
         if (aux && (rc = add_batch_combination<C>(j, &j->bv, ctx, n, a.cc, a.pts, a.pts + (size_t)2 * NC * n, 1,
                                                   job->d_status0.template as<int8_t>(), ST_PENDING, 1, 1, true))) return rc;
-        msm_chain(pv_msm_layout(!aux, job->latency_form));
+        msm_chain(pv_msm_layout(!aux, job->latency_form), aux != 0);
         if (aux) {
             j->stages.push_back({"pv_challenge", [j]() { return rt::launch<PvChallenge<C>>(j->stream(), j->a, j->n); }, 0, join_chains});
         } else {

@@ -792,8 +792,20 @@ struct bbs_job {
         if (reset()) return BBS_E_HIP;
         if (ev && ev->record(stream())) return BBS_E_HIP;
         unsigned forked = 0;
+        // FAULT INJECTION for the fail-closed tests (tests/parity_cases.py::check_fail_closed_submit): the stages named in
+        // BBS_FAULT_SKIP_STAGE (comma-separated) are not launched, so the items they would have decided stay undecided and
+        // every way out of the library must refuse with BBS_E_STATE.  Read at every run; unset in any real deployment.
+        const char* skip = getenv("BBS_FAULT_SKIP_STAGE");
+        auto skipped = [skip](const char* name) {
+            if (!skip || !*skip) return false;
+            const size_t len = std::strlen(name);
+            for (const char* p = skip; (p = std::strstr(p, name)) != nullptr; p += len)
+                if ((p == skip || p[-1] == ',') && (p[len] == 0 || p[len] == ',')) return true;
+            return false;
+        };
         for (auto& s : stages) {
             if (s.aux < 0 || s.aux > N_AUX) return BBS_E_STATE;
+            if (skipped(s.name)) continue;
             if (s.aux && !((forked >> s.aux) & 1u)) { if (fork_aux(s.aux)) return BBS_E_HIP; forked |= 1u << s.aux; }
             for (int k = 1; k <= N_AUX; k++)
                 if (((s.join >> (k - 1)) & 1) && ((forked >> k) & 1u)) { if (join_aux(k)) return BBS_E_HIP; }

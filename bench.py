@@ -349,6 +349,11 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BLS12-381 core_proof_verify, batch %d per GPU, 32 msgs / 8 disclosed, empty "
                                    "header/ph, one issuer key (BASELINE configs[3], proof_verify leg)" % n,
+                       "operating_point": ("ONE issuer key and generator set per GPU with %d-bit fixed-base windows (%.1f GB of tables: a choice for a "
+                                           "service with one issuer, sized for the 288 GB of HBM3E); the library's own default, "
+                                           "bbs_ctx_set_window_bits(ctx, 0), is 16 bits (2.1 GB) at 32 messages -- that rate is "
+                                           "`value_at_library_default_window_bits`" % (
+                                               args.window_bits, (L + 2) * ((256 + args.window_bits - 1) // args.window_bits) * (1 << (args.window_bits - 1)) * 2 * 14 * 4 / 1e9)),
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
                        "batches_in_flight": n_slots, "retire_order": "fifo (oldest first)" if args.fifo_retire else "completion (bbs_jobs_wait_any)",
                        "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),
@@ -468,6 +473,11 @@ def main():
                                   for k, v in kc.items()]
         if extras is not None:
             out["other_ops"] = extras
+            w16 = ((extras.get("bls12_381") or {}).get("host_inclusive_by_window_bits") or {}).get("16")
+            if w16 and args.window_bits != 16:
+                out["value_at_library_default_window_bits"] = {
+                    "window_bits": 16, "proof_verify_per_s": w16["proof_verify_per_s"], "table_bytes": w16["table_bytes"],
+                    "note": "the same submit loop on the same batches with the tables the library picks by itself (64 steps, untimed leg)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1064,6 +1064,94 @@ def check_window_widths(curve, lib_path=None, widths=(5, 7, 11, 13), L=2, seed=3
         eng.close()
 
 
+def check_fail_closed_submit(curve, lib_path=None):
+    """EVERY *_submit entry point of the C ABI ends in the one epilogue of capi.hip (submit_with_results): run, copy the statuses
+    (and records) to page-locked memory, arm, deliver at bbs_job_wait -- and delivery refuses with BBS_E_STATE if ANY item is
+    still undecided.  Shown for each entry point through its *_batch form (= submit + wait) with the stage that decides the
+    items left out on purpose (BBS_FAULT_SKIP_STAGE, runtime.hpp): the call must fail with BBS_E_STATE, never hand out a
+    status or a record, and work normally again once the fault is gone.  (src/proof_verify.rs:108-115, src/verify.rs:88-92: a
+    verdict the pipeline did not reach must not read as Ok(true).)"""
+    import os
+    from bbs_sign_amd.engine import BbsRuntimeError
+    from bbs_sign_amd import Issuer
+    rng = random.Random(23)
+    suite = bbs.SUITES[curve]
+    c = suite.curve
+    L, n = 3, 3
+    gens = gens_for(suite, L + 1)
+    sk = rng.randrange(1, c.r)
+    eng = make_engine(curve, gens, suite.api_id, lib_path, sk=sk)
+    eng.set_latency_mode(False)
+    raw = [[bytes([65 + i, 48 + j]) * (1 + j) for j in range(L)] for i in range(n)]
+    msgs = [eng.hash_to_scalar_batch(r, suite.api_id + b"MAP_MSG_TO_SCALAR_AS_HASH_") for r in raw]
+    disclosed = [[0], [1, 2], []]
+    rnds = [[rng.randrange(1, c.r) for _ in range(5 + L - len(d))] for d in disclosed]
+    sigs, st = eng.core_sign_batch(msgs)
+    assert list(st) == [1] * n
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert list(st) == [1] * n
+    dm = [[msgs[i][j] for j in disclosed[i]] for i in range(n)]
+    draw = [[raw[i][j] for j in disclosed[i]] for i in range(n)]
+    sig_oct, st = eng.sign_octets_batch(msgs)
+    assert list(st) == [1] * n
+    pf_oct, st = eng.proof_gen_octets_batch(sigs, msgs, disclosed, rnds)
+    assert list(st) == [1] * n
+    VERIFY_SKIP = "pairing_6lane,pair_final_exp,pair_final"      # throughput form on the GPU / the host twin's one-lane stages
+    calls = [
+        ("bbs_core_proof_verify_submit", "pv_finish", lambda: eng.core_proof_verify_batch(proofs, dm, disclosed)),
+        ("bbs_proof_verify_octets_submit", "pv_finish", lambda: eng.proof_verify_octets_batch(pf_oct, dm, disclosed)),
+        ("bbs_proof_verify_wire_submit", "pv_finish", lambda: eng.proof_verify_wire_batch(pf_oct, draw, disclosed)),
+        ("bbs_core_verify_submit", VERIFY_SKIP, lambda: eng.core_verify_batch(sigs, msgs)),
+        ("bbs_verify_octets_submit", VERIFY_SKIP, lambda: eng.verify_octets_batch(sig_oct, msgs)),
+        ("bbs_verify_wire_submit", VERIFY_SKIP, lambda: eng.verify_wire_batch(sig_oct, raw)),
+        ("bbs_core_sign_submit", "sg_combine", lambda: eng.core_sign_batch(msgs)),
+        ("bbs_sign_octets_submit", "sg_combine", lambda: eng.sign_octets_batch(msgs)),
+        ("bbs_sign_wire_submit", "sg_combine", lambda: eng.sign_wire_batch(raw)),
+        ("bbs_core_proof_gen_submit", "pg_finalize", lambda: eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)),
+        ("bbs_proof_gen_octets_submit", "pg_finalize", lambda: eng.proof_gen_octets_batch(sigs, msgs, disclosed, rnds)),
+        ("bbs_proof_gen_wire_submit", "pg_finalize", lambda: eng.proof_gen_wire_batch(sig_oct, raw, disclosed, rnds)),
+    ]
+    try:
+        for name, skip, call in calls:
+            os.environ["BBS_FAULT_SKIP_STAGE"] = skip
+            try:
+                got = call()
+            except BbsRuntimeError as e:
+                assert e.rc == -102, (name, e.rc)
+            else:
+                raise AssertionError("%s delivered %r although the stage that decides the items never ran" % (name, got))
+            os.environ["BBS_FAULT_SKIP_STAGE"] = ""
+            got = call()                                        # the fault gone: the same call answers
+            st = got[1] if isinstance(got, tuple) else got
+            assert [int(x) for x in st] == [1] * n, (name, list(st))
+        # the issuer's routed calls end in the same submit forms (its own generators: create_generators by hash-to-curve)
+        iss = Issuer(curve, suite.api_id, lib_path=lib_path, window_bits=4 if lib_path else 8)
+        iss.set_secret_key(sk)
+        i_sig, st = iss.sign(raw)
+        assert list(st) == [1] * n
+        i_pf, st = iss.proof_gen(i_sig, raw, disclosed, rnds)
+        assert list(st) == [1] * n
+        for name, skip, call in (("bbs_issuer_proof_verify", "pv_finish", lambda: iss.proof_verify(i_pf, draw, disclosed)),
+                                 ("bbs_issuer_verify", VERIFY_SKIP, lambda: iss.verify(i_sig, raw)),
+                                 ("bbs_issuer_sign", "sg_combine", lambda: iss.sign(raw)),
+                                 ("bbs_issuer_proof_gen", "pg_finalize", lambda: iss.proof_gen(i_sig, raw, disclosed, rnds))):
+            os.environ["BBS_FAULT_SKIP_STAGE"] = skip
+            try:
+                got = call()
+            except BbsRuntimeError as e:
+                assert e.rc == -102, (name, e.rc)
+            else:
+                raise AssertionError("%s delivered %r with undecided items" % (name, got))
+            os.environ["BBS_FAULT_SKIP_STAGE"] = ""
+            got = call()
+            st = got[1] if isinstance(got, tuple) else got
+            assert [int(x) for x in st] == [1] * n, (name, list(st))
+        iss.close()
+    finally:
+        os.environ.pop("BBS_FAULT_SKIP_STAGE", None)
+    eng.close()
+
+
 def check_fail_closed(curve, lib_path=None):
     """A job whose kernels never ran has decided nothing: its statuses are the internal pending value, which the C ABI
     refuses to return (BBS_E_STATE) -- it must never read as Ok(true).  After a run the same job reports normally."""

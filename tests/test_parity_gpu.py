@@ -361,3 +361,8 @@ def test_pool_two_members_on_one_gpu():
     BLS12-381 list with corrupted, forged and malformed items: statuses in list order = one context per curve."""
     pc.check_pool(None, devices=(0, 0), per_curve=300, L=8, R=3, window_bits=8, max_batch=64)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_fail_closed_every_submit_entry_point(curve):
+    pc.check_fail_closed_submit(curve, None)
+

@@ -171,3 +171,8 @@ def test_pool_two_members(twin):
 def test_pool_three_members_uneven_shares(twin):
     pc.check_pool(twin, devices=(0, 0, 0), per_curve=13, max_batch=3)
 
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_fail_closed_every_submit_entry_point(twin, curve):
+    pc.check_fail_closed_submit(curve, twin)
+

@@ -1,8 +1,40 @@
 #!/bin/bash
 # TEST-ONLY: AddressSanitizer + UBSan build of the host twin (CPU; GPU sanitizers are not available on this pool) and a
 # run of the parity cases through it.  ~20 min of compile time on 8 cores.  usage: tools/sanitize_twin.sh [outdir]
+# TSAN=1 tools/sanitize_twin.sh [outdir]: ThreadSanitizer instead, and only the cases in which several host threads meet --
+# the issuer's contexts shared by threads, one context driven by several threads, the pool's member threads and its lists in
+# flight, completion-order retire (round 5: the data races of issuer.hpp the previous review listed).
 set -e -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+if [ -n "$TSAN" ]; then
+  OUT=${1:-$ROOT/bbs_sign_amd/build/tsan}; mkdir -p $OUT
+  if [ -z "$SKIP_BUILD" ] || [ ! -f $OUT/libbbs_hosttwin_tsan_TESTONLY.so ]; then
+    ls $ROOT/bbs_sign_amd/csrc/*.hip | xargs -P ${JOBS:-8} -I{} sh -c "hipcc -O1 -g --offload-host-only -x hip -DBBS_HOST_TWIN -DBBS_CHECK_BOUNDS -fPIC -fsanitize=thread -fno-omit-frame-pointer -c {} -o $OUT/\$(basename {} .hip).o"
+    hipcc -shared -fPIC --offload-host-only -fsanitize=thread -shared-libsan $OUT/*.o -o $OUT/libbbs_hosttwin_tsan_TESTONLY.so
+  fi
+  RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)
+  cat > $OUT/run_tsan.py <<PY
+import sys
+sys.path.insert(0, "$ROOT"); sys.path.insert(0, "$ROOT/tests")
+import parity_cases as pc
+lib = "$OUT/libbbs_hosttwin_tsan_TESTONLY.so"
+for curve in ("bls12_381", "bn254"):
+    pc.check_issuer_threads(curve, lib, threads=3, rounds=2)
+    pc.check_issuer_budget(curve, lib)
+    pc.check_submit(curve, lib)
+    print(curve, "ok", flush=True)
+pc.check_threads(lib, threads=3, rounds=2, n=5)
+pc.check_pool(lib, devices=(0, 0, 0), per_curve=13, max_batch=3)
+print("thread sanitizer run ok")
+PY
+  set +e
+  TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0 LD_PRELOAD=$RT python3 $OUT/run_tsan.py > $OUT/run.log 2>&1
+  rc=$?
+  grep -E "WARNING: ThreadSanitizer|ok" $OUT/run.log | sort | uniq -c
+  if [ $rc -ne 0 ] || ! grep -q "thread sanitizer run ok" $OUT/run.log || grep -q "WARNING: ThreadSanitizer" $OUT/run.log; then echo "THREAD SANITIZER RUN FAILED OR REPORTED (rc=$rc)"; grep -A25 "WARNING: ThreadSanitizer" $OUT/run.log | head -120; exit 1; fi
+  [ -n "$KEEP_SAN" ] || rm -f $OUT/*.o $OUT/libbbs_hosttwin_tsan_TESTONLY.so
+  exit 0
+fi
 OUT=${1:-$ROOT/bbs_sign_amd/build/san}; mkdir -p $OUT
 pids=()
 # SKIP_BUILD=1 with an instrumented library present: neither compile nor link (the objects may be gone)
