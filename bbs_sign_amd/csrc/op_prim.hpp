@@ -17,7 +17,7 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
     // leaves the previous generator set, its tables and gens_set as they were.
     const int L_new = (int)count - 1;
     const int nb = L_new + 2;                    // fixed-base tables over [P1, Q1, H_1..H_L]
-    auto table_bytes_at = [&](int c) { return (size_t)nb * ((256 + c - 1) / c) * ((size_t)1 << (c - 1)) * 2 * N * 4; };
+    auto table_bytes_at = [&](int c) { return (size_t)nb * ((256 + c - 1) / c) * ((size_t)1 << (c - 1)) * fix_tab_stride<C>() * 4; };
     // candidate widths, widest first.  A requested width is the only candidate.  Automatic: the widest of {20, 16, 12, 8}
     // whose tables fit 1/32 of the memory now free on the device and 8 GiB -- at 32 messages that is 16 bits (2 GB, 16
     // additions per scalar); 20 bits (26 GB, 13 additions, +3.5 % proof_verify/s) is a deliberate choice for a verifier with
@@ -44,7 +44,7 @@ int Ctx<C>::set_generators(const uint8_t* g, size_t count, const uint8_t* aid, s
     for (int c : widths) {
         W = (256 + c - 1) / c;
         per_win = (size_t)1 << (c - 1);                         // signed digits: |digit| = 1 .. 2^(c-1)
-        if (n_winbase.alloc((size_t)nb * W * 2 * N * 4) == 0 && n_tables.alloc((size_t)nb * W * per_win * 2 * N * 4) == 0) { wb = c; break; }
+        if (n_winbase.alloc((size_t)nb * W * 2 * N * 4) == 0 && n_tables.alloc((size_t)nb * W * per_win * fix_tab_stride<C>() * 4) == 0) { wb = c; break; }
         n_winbase.release(); n_tables.release();
     }
     if (!wb) return BBS_E_NOMEM;

@@ -78,12 +78,37 @@ struct CtxConsts {
     int win_bits;                // c
     int n_windows;               // W = ceil(256 / c)
     uint32_t fix_bias[8];        // K = sum over w < W - 1 of 2^(c w + c - 1): signed-digit recoding of the fixed-base scalars
-    const uint32_t* tables;      // [base][window][|digit| - 1][2N] affine Montgomery, |digit| in 1 .. 2^(c-1)
+    const uint32_t* tables;      // [base][window][|digit| - 1][fix_tab_stride] affine Montgomery, |digit| in 1 .. 2^(c-1)
     uint32_t frob[3][6][2][C::FpP::N];   // xi^(m (p^k - 1)/6), Montgomery (for the lane-sliced Fp12)
     MillerSchedule sched;
     LineTable<C> tab_pk;         // lines of W = pk
     LineTable<C> tab_bp2;        // lines of BP2
 };
+
+// Words from one entry of the fixed-base window tables to the next.  An entry is 2N words (x, y); BLS12-381's 112 bytes are
+// padded to 128 (round 5): the tables are read at random, one entry per mixed addition, and an unaligned 112-byte entry
+// straddles two 128-byte lines in 7 cases of 8 -- the counters showed 2 x 205 MB fetched per 4096-item batch for 203 MB of
+// entries (profiles/r05_p_pmc.csv before the change).  Aligned, an entry is one line and seven 16-byte loads.  BN254's 80
+// bytes stay packed (16-byte aligned; padding them to 128 would cost 60 % more table memory).
+#ifndef BBS_FIX_TAB_PACKED
+#define BBS_FIX_TAB_PACKED 0     // A/B knob: 1 = entries packed at 2N words as before round 5
+#endif
+template <class C>
+constexpr int fix_tab_stride() { return (!BBS_FIX_TAB_PACKED && 2 * C::FpP::N == 28) ? 32 : 2 * C::FpP::N; }
+// one entry (16-byte loads: every entry starts on a 16-byte boundary)
+template <class C>
+BBS_HD void fix_tab_load(const uint32_t* e, G1Aff<C>& q) {
+    constexpr int N = C::FpP::N;
+    static_assert((2 * N) % 4 == 0 && fix_tab_stride<C>() % 4 == 0, "table entries are whole 16-byte groups");
+    uint32_t w[2 * N];
+#pragma unroll
+    for (int g = 0; g < 2 * N / 4; g++) {
+        const uint4 v = reinterpret_cast<const uint4*>(e)[g];
+        w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) { q.x.v[j] = w[j]; q.y.v[j] = w[N + j]; }
+}
 
 // ---- SoA helpers ----------------------------------------------------------------------------
 template <int NW>
@@ -257,9 +282,7 @@ __host__ __device__ inline void fixed_msm_chunk_to(const CtxConsts<C>& cc, const
         bool neg;
         const uint32_t d = fixed_digit(sc, w, c, W, neg);
         if (d == 0) return false;
-        const uint32_t* e = cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N);
-#pragma unroll
-        for (int j = 0; j < N; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[N + j]; }
+        fix_tab_load<C>(cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * fix_tab_stride<C>(), q);
         q.y = fe_select<typename C::FpP>(neg, fe_neg<typename C::FpP>(q.y), q.y);
         return true;
     };
@@ -327,7 +350,7 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
             soa_ld<8>(fscal + (size_t)k * 8 * n, n, i, sc);
             fixed_bias_scalar<C>(cc, sc);
             const uint32_t d = fixed_digit(sc, w, c, W, neg);
-            return d ? cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * (2 * N) : nullptr;
+            return d ? cc.tables + (((size_t)k * W + w) * per_win + (d - 1)) * fix_tab_stride<C>() : nullptr;
         };
         constexpr int G = 4;
         for (int t0 = 0; t0 < T; t0 += G) {
@@ -338,8 +361,7 @@ __host__ __device__ inline void fixed_msm_tree_to(const CtxConsts<C>& cc, const 
                 bool neg = false;
                 const uint32_t* e = t0 + g < T ? entry(t0 + g, neg) : nullptr;
                 if (e) {
-#pragma unroll
-                    for (int j = 0; j < N; j++) { q[g].x.v[j] = e[j]; q[g].y.v[j] = e[N + j]; }
+                    fix_tab_load<C>(e, q[g]);
                     q[g].y = fe_select<P>(neg, fe_neg<P>(q[g].y), q[g].y);
                 }
             }
@@ -941,7 +963,7 @@ struct TabArgs {
     int n_bases, win_bits, n_windows;
     const uint32_t* bases;    // [n_bases][2N] Montgomery affine (AoS)
     uint32_t* winbase;        // [n_bases][W][2N] : 2^(c*w) * G_k
-    uint32_t* tables;         // [n_bases][W][2^(c-1)][2N]
+    uint32_t* tables;         // [n_bases][W][2^(c-1)][fix_tab_stride]
 };
 
 // lane per base: the W window bases by repeated doubling
@@ -978,8 +1000,9 @@ struct TabEntry {
             if ((d >> i) & 1u) r = g1j_add_aff<C>(r, b);
         }
         G1Aff<C> o = g1j_to_aff<C>(r);
-        uint32_t* dst = a.tables + t * 2 * N;
+        uint32_t* dst = a.tables + t * fix_tab_stride<C>();
         for (int j = 0; j < N; j++) { dst[j] = o.x.v[j]; dst[N + j] = o.y.v[j]; }
+        for (int j = 2 * N; j < fix_tab_stride<C>(); j++) dst[j] = 0;
     }
 };
 

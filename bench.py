@@ -353,7 +353,7 @@ def main():
                                            "service with one issuer, sized for the 288 GB of HBM3E); the library's own default, "
                                            "bbs_ctx_set_window_bits(ctx, 0), is 16 bits (2.1 GB) at 32 messages -- that rate is "
                                            "`value_at_library_default_window_bits`" % (
-                                               args.window_bits, (L + 2) * ((256 + args.window_bits - 1) // args.window_bits) * (1 << (args.window_bits - 1)) * 2 * 14 * 4 / 1e9)),
+                                               args.window_bits, (L + 2) * ((256 + args.window_bits - 1) // args.window_bits) * (1 << (args.window_bits - 1)) * 128 / 1e9)),
                        "batch_per_gpu": n, "messages": L, "disclosed": R, "fixed_base_window_bits": args.window_bits,
                        "batches_in_flight": n_slots, "retire_order": "fifo (oldest first)" if args.fifo_retire else "completion (bbs_jobs_wait_any)",
                        "hw_queues": int(eng.lib.bbs_runtime_hw_queues()),

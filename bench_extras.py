@@ -129,14 +129,14 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         t0 = time.perf_counter()
         bad, _, _ = submit_loop(e2, use, 64, len(use))
         cmp_w[str(w)] = {"proof_verify_per_s": n * 64 / (time.perf_counter() - t0),
-                         "table_bytes": (L + 2) * ((256 + w - 1) // w) * (1 << (w - 1)) * 2 * 14 * 4}
+                         "table_bytes": (L + 2) * ((256 + w - 1) // w) * (1 << (w - 1)) * 128}
         assert bad == 0
         e2.close()
     wb = args.window_bits
     bls["host_inclusive_by_window_bits"] = dict(cmp_w, note="same loop as the headline (distinct batches, %d in flight); the headline's own width "
                                                 "(%d bits, %d table bytes) is `value`; the library default, bbs_ctx_set_window_bits(ctx, 0), picks "
                                                 "the widest of 20 / 16 / 12 / 8 that fits an eighth of the free device memory"
-                                                % (args.inflight, wb, (L + 2) * ((256 + wb - 1) // wb) * (1 << (wb - 1)) * 2 * 14 * 4))
+                                                % (args.inflight, wb, (L + 2) * ((256 + wb - 1) // wb) * (1 << (wb - 1)) * 128))
 
     # ---- one batch at a time in latency mode (bbs_ctx_set_latency_mode: T1's three terms on three lanes), and the
     # price of that mode with eight batches in flight
