@@ -28,6 +28,6 @@ for w in widths:
         x.free()
     windows = (256 + w - 1) // w
     print("w=%2d windows=%2d table=%8.1f MB  sg_msm_parts %.3f ms (%.1f us per addition)  one batch %.2f ms  8 in flight %.2f M sign/s"
-          % (w, windows, 34 * windows * (1 << (w - 1)) * 112 / 1e6, st["sg_msm_parts"] / 3, st["sg_msm_parts"] / 3 * 1e3 / (34 * windows / 8.0),
+          % (w, windows, 34 * windows * (1 << (w - 1)) * 128 / 1e6, st.get("sg_msm_parts", 0) / 3, st.get("sg_msm_parts", 0) / 3 * 1e3 / (34 * windows / 8.0),
              tot / 3, n * 64 / (ms * 1e-3) / 1e6), flush=True)
     eng.close()
