@@ -94,9 +94,11 @@ int vf_upload(Ctx<C>* ctx, size_t n, const uint8_t* sigs, const uint8_t* msgs, c
     VfJob<C>* j = job.get();
     // e * A needs only what the ingest stage left: it runs on the job's side stream beside the scalars and the fixed-base
     // chunks (critical path 3.0 instead of 0.13 + 0.9 + 3.0 ms).  In both forms: with 6 / 8 / 12 resident jobs in flight
-    // 1.75 / 1.79 / 1.81 M verify/s against 1.64 / 1.71 / 1.81 with the job kept to one stream (profiles/r05_e_verify_var_mul_side_stream.log).
+    // 1.75 / 1.79 / 1.81 M verify/s against 1.64 / 1.71 / 1.81 with the job kept to one stream
+    // (profiles/r05_e_verify_var_mul_side_stream.log).  Except batch verification's throughput form, whose jobs are kept alive
+    // by the dozen and must own ONE hardware queue each (32 in flight: 4.2 M/s on one stream, 3.1 M/s on two).
     static const int side_forced = []() { const char* v = getenv("BBS_VF_SIDE"); return v ? atoi(v) : -1; }();      // A/B: 0 never, 1 always
-    const int side = side_forced >= 0 ? (side_forced ? 1 : 0) : 1;
+    const int side = side_forced >= 0 ? (side_forced ? 1 : 0) : ((ctx->batch_verify && !job->latency_form) ? 0 : 1);
     j->stages.push_back({"vf_var_mul", [j, side]() { return rt::launch<VfVarMul<C>>(side ? j->stream_aux(1) : j->stream(), j->a, j->n); }, side, 0});
     j->stages.push_back({"vf_scalars", [j]() { return rt::launch<VfScalars<C>>(j->stream(), j->a, j->n); }});
     j->stages.push_back({"vf_fixed_chunks", [j]() { return rt::launch<VfFixedChunk<C>>(j->stream(), j->a, j->n * (size_t)NFIX); }});

@@ -437,7 +437,7 @@ def main():
                     "frac": tot_cyc / avail, "issue_cycles_per_step": tot_cyc, "simd_cycles_available_per_step": avail,
                     "frac_of_multiwave_ceiling": tot_cyc8 / avail,
                     "frac_if_2_waves_per_simd_issue_costs": tot_cyc2 / avail,
-                    "cycles_per_inst": {"as_run_1_wave_per_simd": tot_cyc / tot_inst, "2_waves_per_simd": tot_cyc2 / tot_inst,
+                    "cycles_per_inst": {"as_run": tot_cyc / tot_inst, "2_waves_per_simd": tot_cyc2 / tot_inst,
                                         "8_waves_per_simd": tot_cyc8 / tot_inst},
                     "ns_per_wave_inst_per_simd": {"this_run": ns_run, "ubench_mix_by_waves_per_simd": ns_mix,
                                                   "frac_of_2_wave_cost": (ns_mix["2"] / ns_run) if ns_mix else None,
@@ -459,8 +459,9 @@ def main():
                             "for 2 cycles (simple VOP2) to ~4 (v_mad_u64_u32, 61 percent of these kernels), but ONE wavefront alone "
                             "issues at most one instruction per 4 - 5 cycles (MI355X_MICROARCH.md:54,473,489; "
                             "profiles/*_ubench_valu_int.csv).  frac = share of the SIMD cycles the step needs to issue its "
-                            "instructions at the costs a wavefront ALONE on its SIMD pays -- what the kernels run at (398 / 384 "
-                            "VGPRs: one wavefront per SIMD).  frac_of_multiwave_ceiling prices the SAME instructions at the costs "
+                            "instructions at the costs a wavefront ALONE on its SIMD pays -- what the big kernels run at (pairing 420, "
+                            "doubling chains 292 / 336 registers: one wavefront per SIMD; the fixed-base chunks, a kernel of their own since "
+                            "round 5, 246: two, priced at the two-wavefront cost).  frac_of_multiwave_ceiling prices the SAME instructions at the costs "
                             "eight co-resident wavefronts see (this instruction mix: %.2f cycles per instruction instead of %.2f): "
                             "the hardware's real ceiling for this mix, which the design cannot reach without fitting 2+ wavefronts "
                             "per SIMD (<= 256 VGPRs, no spills; DESIGN.md 5, profiles/r04_*_occupancy*)" % (

@@ -64,16 +64,15 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
     def run_lists(count):
         """`count` passes over the list, `ahead` of them submitted before the oldest is collected.  The statuses of list k
         are exchanged (ONE all_gather of int8) asynchronously: started when the list's jobs have delivered, finished and
-        merged one list later -- the submitting thread goes on retiring and submitting, it never sleeps on the collective
+        merged two lists later -- the submitting thread goes on retiring and submitting, it never sleeps on the collective
         (mixed.StatusExchange).  Merged statuses come back in list order."""
-        out, handles, exchange = [], [], None
+        out, handles, exchanges = [], [], []
+        lag = 2                                            # exchanges outstanding before the oldest is finished: it has had two lists' time
 
         def collected(h):
-            nonlocal exchange
-            started = exch.start(pipe.collect(h))
-            if exchange is not None:
-                out.append(exch.finish(exchange))
-            exchange = started
+            exchanges.append(exch.start(pipe.collect(h)))
+            while len(exchanges) > lag:
+                out.append(exch.finish(exchanges.pop(0)))
 
         for k in range(count):
             handles.append(pipe.submit_list())
@@ -81,8 +80,8 @@ def run_mixed(args, pc, torch, dist, rank, local_rank, world, red_dev, barrier, 
                 collected(handles.pop(0))
         while handles:
             collected(handles.pop(0))
-        if exchange is not None:
-            out.append(exch.finish(exchange))
+        while exchanges:
+            out.append(exch.finish(exchanges.pop(0)))
         return out
 
     if args.warmup < 0 or args.steps < 1:
