@@ -30,7 +30,11 @@ while time.time() - t0 < budget:
         pc.check_issuer_mixed_lengths(curve, None, seed=seed, lengths=tuple(lens), oracle_items=(0,))
         if seed % 4 == 0:
             pc.check_issuer_budget(curve, None, seed=seed)          # bounded contexts: eviction, rebuild, -43, refused configuration
+        if seed % 5 == 0:
+            pc.check_fail_closed_submit(curve, None)                # round 5: every submit entry point refuses undecided items
         done += 1
+    if seed % 3 == 0:
+        pc.check_pool(None, devices=(0, 0), per_curve=24 + seed % 17, L=3 + seed % 4, R=1 + seed % 2, window_bits=8, max_batch=5 + seed % 9)      # round 5: mixed list through bbs_pool
     seed += 1
     print("seed", seed, "cases", done, "elapsed %.0f s" % (time.time() - t0), flush=True)
 print("stress ok:", done, "cases")
