@@ -36,6 +36,17 @@ inline void share_of(size_t n, size_t D, size_t d, size_t& lo, size_t& hi) {
     hi = std::min(n, lo + per);
 }
 struct Piece { size_t li, lo, hi; };          // one job: items [lo, hi) of section `li`
+// a ragged part of a section as the staging code will judge it for every job cut from it (runtime.hpp RaggedIn::measure):
+// offsets never decrease, the total is not garbage, and there is data behind a non-empty total.  Checked for the whole
+// section BEFORE anything is queued, so that a malformed list is refused by the submitting call and not by a member's
+// thread after other jobs of the list have run.
+inline bool ragged_ok(const uint64_t* off, const void* data, size_t n) {
+    if (!off) return true;
+    for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+    const uint64_t total = off[n] - off[0];
+    if (total > ((uint64_t)1 << 36)) return false;
+    return total == 0 || data != nullptr;
+}
 }  // namespace pool_detail
 
 // a list in flight on the pool: the sections as the caller gave them (the caller's buffers stay valid until wait), where
@@ -202,6 +213,9 @@ inline int pool_proof_verify_submit(bbs_pool* p, const bbs_pv_list* lists, size_
         const bbs_pv_list& L = lists[li];
         const int s = bbs_pool::curve_slot(L.curve);
         if (s < 0 || (L.n && (!L.status || !L.proofs_fixed || !L.commit_off || !L.dmsg_off || !L.didx_off))) return BBS_E_ARG;
+        if (L.n && !(pool_detail::ragged_ok(L.commit_off, L.commitments, L.n) && pool_detail::ragged_ok(L.dmsg_off, L.disclosed_msgs, L.n) &&
+                     pool_detail::ragged_ok(L.didx_off, L.disclosed_idx, L.n) && pool_detail::ragged_ok(L.hdr_off, L.headers, L.n) &&
+                     pool_detail::ragged_ok(L.ph_off, L.ph, L.n))) return BBS_E_ARG;
         if (L.n && p->ctx[s].empty()) return BBS_E_STATE;          // no generators / key for this curve yet
     }
     auto job = std::unique_ptr<bbs_pool_job>(new bbs_pool_job());

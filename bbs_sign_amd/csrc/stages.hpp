@@ -58,6 +58,22 @@ constexpr int8_t ST_PAIRING = -127;   // every check before the pairing passed: 
 #ifndef BBS_MSM_WAVES
 #define BBS_MSM_WAVES 1          // multi-scalar-multiplication stages (2 and 3 measured: no gain, spills)
 #endif
+// The doubling-chain kernels of proof_verify capped at 256 registers, so that two of their wavefronts -- or one and a
+// wavefront of a fixed-base chunk kernel (246) -- share a SIMD.  They are 64 wavefronts of 3 - 5 ms each per batch: alone on a
+// SIMD they keep the other 212 registers of it idle for that long.  Round 5, measured on the headline loop (profiles/r05_i_*,
+// three alternating repeats): BLS12-381 T1 chain 300 -> 256 registers (97 spilled) long_region 1.581 -> 1.606 M/s; the
+// single multiplication 354 -> 256 as well (251 spilled) no further gain (1.60 M) -- it stays at one.  BN254's three kernels
+// need 244 / 264 / 266: capped, 0 / 10 / 26 spilled; likewise BN254's PvChallenge(Bv), VfVarMul, MsmVarMul (264 - 268).
+#ifndef BBS_T1_WAVES
+#define BBS_T1_WAVES 2
+#endif
+#ifndef BBS_VARMUL_WAVES
+#define BBS_VARMUL_WAVES 1       // BLS12-381; BN254: 2 (chain_waves below)
+#endif
+#ifndef BBS_BN_CHAIN_WAVES
+#define BBS_BN_CHAIN_WAVES 2
+#endif
+template <class C> constexpr int chain_waves(int bls_default) { return C::FpP::N <= 10 ? BBS_BN_CHAIN_WAVES : bls_default; }
 
 // ---- context constants resident in HBM ------------------------------------------------------
 struct HashCtx {
@@ -626,6 +642,7 @@ struct PvScalars {
 // compute for such an item is never read (PvChallenge runs behind all three and skips it).
 template <class C>
 struct PvT1Chain {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(BBS_T1_WAVES);
     static BBS_HD void run(const PvArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         constexpr int NC = C::FpP::NC;
@@ -684,6 +701,7 @@ struct PvT1Chain {
 // queues is a budget: DESIGN.md 5 rule 6).  Reads the points in canonical form, as the ingest stage left them.
 template <class C>
 struct PvVarMul {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(BBS_VARMUL_WAVES);
     static __host__ __device__ int first_part(const PvArgs<C>& a) { return a.nvar == PV_NVAR ? 1 : 0; }
     static BBS_HD void run(const PvArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
@@ -709,6 +727,7 @@ struct PvVarMul {
 // everything on one stream (batch verification's throughput form), where two launches would run one after the other
 template <class C>
 struct PvChains {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(BBS_T1_WAVES < BBS_VARMUL_WAVES ? BBS_T1_WAVES : BBS_VARMUL_WAVES);
     static __host__ __device__ size_t units(const PvArgs<C>& a) { return (size_t)1 + (size_t)(a.nvar - PvVarMul<C>::first_part(a)); }
     static BBS_HD void run(const PvArgs<C>& a, size_t t) {
         if (t < a.n) PvT1Chain<C>::run(a, t);
@@ -748,6 +767,7 @@ struct PvFixedTree {
 // stage 3 (lane per item): combine parts, normalise, challenge hash, compare
 template <class C>
 struct PvChallenge {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(1);      // BN254: 264 - 268 registers -> 256
     static __host__ __device__ void run(const PvArgs<C>& a, size_t i) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;
@@ -814,6 +834,7 @@ struct PvChallenge {
 };
 template <class C>
 struct PvChallengeBv {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(1);      // BN254: 264 - 268 registers -> 256
     static __host__ __device__ void run(const PvArgs<C>& a, size_t i) { PvChallenge<C>::run_with_bv_prep(a, i); }
 };
 
@@ -1176,6 +1197,7 @@ struct VfScalars {
 // lane per item: A on the curve?, its Montgomery copy, e * A (window table in HBM) -> partials[0]
 template <class C>
 struct VfVarMul {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(1);      // BN254: 264 - 268 registers -> 256
     static BBS_HD void run(const VfArgs<C>& a, size_t i) {
         const size_t n = a.n;
         if (a.status[i] != ST_PENDING) return;
@@ -1906,6 +1928,7 @@ struct MsmArgs {
 // lane per (variable-base term, item)
 template <class C>
 struct MsmVarMul {
+    static constexpr int WAVES_PER_EU = chain_waves<C>(1);      // BN254: 264 - 268 registers -> 256
     static BBS_HD void run(const MsmArgs<C>& a, size_t t) {
         constexpr int N = C::FpP::N;
         const size_t n = a.n;

@@ -154,3 +154,87 @@ def test_runtime_and_wait_any_arguments(twin):
     assert lib.bbs_job_poll(None) == E_ARG
     assert lib.bbs_ctx_table_bytes(None) == 0 and lib.bbs_issuer_table_bytes(None) == 0
     assert lib.bbs_issuer_set_budget(None, 4, 0) == E_ARG
+
+
+def test_pool_misuse_is_refused(twin):
+    """bbs_pool_*: NULL handles, devices that do not exist, sections with NULL parts or garbage offsets are refused BY THE
+    SUBMITTING CALL (nothing is queued to the members' threads), a curve without generators / key is BBS_E_STATE, and the pool
+    still verifies a good list afterwards."""
+    from bbs_sign_amd.pool import Pool
+    lib = _lib.load_library(twin)
+    E_NO_DEVICE = -104
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 2)(0, 0)
+    assert lib.bbs_pool_create(None, 2, ctypes.byref(h)) == E_ARG
+    assert lib.bbs_pool_create(ids, 0, ctypes.byref(h)) == E_ARG
+    assert lib.bbs_pool_create(ids, 2, None) == E_ARG
+    bad = (ctypes.c_int * 2)(0, 4096)
+    assert lib.bbs_pool_create(bad, 2, ctypes.byref(h)) == E_NO_DEVICE
+    neg = (ctypes.c_int * 1)(-1)
+    assert lib.bbs_pool_create(neg, 1, ctypes.byref(h)) == E_NO_DEVICE
+    assert lib.bbs_pool_device_count(None) == 0
+    assert lib.bbs_pool_set_window_bits(None, 0, 4) == E_ARG and lib.bbs_pool_set_inflight(None, 4) == E_ARG
+    assert lib.bbs_pool_set_generators(None, 0, None, 0, None, 0) == E_ARG and lib.bbs_pool_set_public_key(None, 0, None, 1) == E_ARG
+    assert lib.bbs_pool_proof_verify(None, None, 0, 0) == E_ARG and lib.bbs_pool_job_wait(None) == E_ARG
+    lib.bbs_pool_job_free(None)
+    lib.bbs_pool_destroy(None)
+
+    suite = bbs.SUITES["bls12_381"]
+    L, R, n = 3, 1, 6
+    gens = pc.gens_for(suite, L + 1)
+    eng = pc.make_engine("bls12_381", gens, suite.api_id, twin, sk=11)
+    msgs, disclosed, rnds = pc.bench_items(suite, eng, n, L, R)
+    sigs, st = eng.core_sign_batch(msgs)
+    proofs, st = eng.core_proof_gen_batch(sigs, msgs, disclosed, rnds)
+    assert (st == 1).all()
+    dm, didx = [m[:R] for m in msgs], [list(d) for d in disclosed]
+    pool = Pool([0, 0], twin)
+    ph = pool.h
+    assert lib.bbs_pool_set_inflight(ph, 0) == E_ARG and lib.bbs_pool_set_inflight(ph, 65) == E_ARG
+    assert lib.bbs_pool_set_window_bits(ph, 7, 4) == E_ARG                           # no such curve
+    ctx = ctypes.c_void_p()
+    assert lib.bbs_pool_context(ph, 0, 2, ctypes.byref(ctx)) == E_ARG               # two members: 0 and 1
+    assert lib.bbs_pool_context(ph, 0, 0, None) == E_ARG
+    sec = pool.pack("bls12_381", proofs, dm, didx)
+    job = ctypes.c_void_p()
+
+    status = np.zeros(n, dtype=np.int8)
+
+    def submit(mutate=None, n_lists=1):
+        arr = (_lib.PvList * 1)()
+        sec.fill(arr[0], status)
+        if mutate:
+            mutate(arr[0])
+        return lib.bbs_pool_proof_verify_submit(ph, arr, n_lists, 4, ctypes.byref(job))
+
+    assert submit() == E_STATE                                                        # no generators / key for the curve yet
+    pool.set_window_bits("bls12_381", 4)
+    pool.set_generators("bls12_381", gens, suite.api_id)
+    pool.set_public_key("bls12_381", eng.public_key())
+    assert lib.bbs_pool_proof_verify_submit(ph, None, 1, 4, ctypes.byref(job)) == E_ARG
+    assert lib.bbs_pool_proof_verify_submit(ph, (_lib.PvList * 1)(), 1, 4, None) == E_ARG
+    none8, none64 = ctypes.cast(None, _lib.c_u8p), ctypes.cast(None, _lib.c_u64p)
+    for field, null in (("status", ctypes.cast(None, _lib.c_i8p)), ("proofs_fixed", none8), ("commit_off", none64), ("dmsg_off", none64),
+                        ("didx_off", none64), ("commitments", none8), ("disclosed_msgs", none8), ("disclosed_idx", none64)):
+        assert submit(lambda s, f=field, v=null: setattr(s, f, v)) == E_ARG, field
+    assert submit(lambda s: setattr(s, "curve", 9)) == E_ARG
+    # offsets that decrease / are absurd, in every ragged part: refused by the call, not by a member's thread later
+    for field in ("commit_off", "dmsg_off", "didx_off"):
+        ref = (_lib.PvList * 1)()
+        sec.fill(ref[0], status)
+        good = np.ctypeslib.as_array(getattr(ref[0], field), shape=(n + 1,)).copy()
+        dec = good.copy(); dec[2] = dec[1] - 1 if dec[1] else np.uint64(1 << 40); dec[3] = 0
+        huge = good.copy(); huge[n] = np.uint64(1) << np.uint64(50)
+        for arr in (dec, huge):
+            assert submit(lambda s, f=field, a=arr: setattr(s, f, a.ctypes.data_as(_lib.c_u64p))) == E_ARG, field
+    hdr_off = np.zeros(n + 1, dtype=np.uint64); hdr_off[n] = 5
+
+    def headers_without_data(s):
+        s.hdr_off, s.headers = hdr_off.ctypes.data_as(_lib.c_u64p), none8
+    assert submit(headers_without_data) == E_ARG                                      # 5 header bytes, no header data
+    # nothing of the refused calls is in flight: reconfiguration is allowed, and a good list verifies
+    pool.set_inflight(2)
+    got = pool.proof_verify_packed([sec], max_batch=4)
+    assert [int(x) for x in got] == [1] * n
+    pool.close()
+    eng.close()
