@@ -14,6 +14,9 @@ timeout -k 10 400 python bench.py --config mixed65536 --total 8192 --steps 60 --
 timeout -k 10 400 python bench.py --config mixed65536 --total 65536 --steps 8 --warmup 2 > $O/r05_z_mixed65536.json 2> $O/r05_z_mixed65536.err || { tail -5 $O/r05_z_mixed65536.err; exit 1; }
 timeout -k 10 400 python bench.py --config mixed65536 --single-process --total 65536 --steps 8 --warmup 2 > $O/r05_z_pool65536.json 2> $O/r05_z_pool65536.err || { tail -5 $O/r05_z_pool65536.err; exit 1; }
 timeout -k 10 400 python bench.py --config mixed65536 --single-process --total 8192 --steps 60 --warmup 6 > $O/r05_z_pool8192.json 2> $O/r05_z_pool8192.err || { tail -5 $O/r05_z_pool8192.err; exit 1; }
+for k in 5 7 8; do
+  timeout -k 10 200 python bench.py --no-extras --no-cpu-baseline --steps 96 --inflight $k > $O/r05_z_bench_inflight$k.json 2> $O/r05_z_bench_inflight$k.err || { tail -5 $O/r05_z_bench_inflight$k.err; exit 1; }
+done
 timeout -k 10 200 python tools/quick_pipeline_trace.py 20 6 > $O/r05_pt_pipeline_trace_k20.log 2>&1 || echo "pipeline trace failed"
 python - <<'PY'
 import json, glob, os
