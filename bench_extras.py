@@ -28,6 +28,8 @@ def op_roofline(counters, counters_file, lib_hash, op, items_per_s, in_flight):
             "valu_issue": {"wave_insts_per_item": insts / n0, "valu_wave_insts_per_job": insts,
                            "ns_per_wave_inst_per_simd": {"this_run": spent_ns, "ubench_mix_at_kernel_occupancy": model_ns},
                            "frac": model_ns / spent_ns,
+                           "frac_note": "modelled issue cost (micro-benchmark of the kernels' opcode mixes, +-3 %: clock and mix) over SIMD time "
+                                        "spent; at or slightly above 1 = the operation runs at the issue ceiling within the model's error",
                            "kernels": {st: {"valu_wave_insts": k["valu_insts"], "waves_per_simd": k["waves_per_simd"],
                                             "ns_per_inst": k["ns_per_inst_at_that_occupancy"]} for st, k in ks.items()}},
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_item": spec["alg_bytes_per_item"], "achieved": spec["alg_bytes_per_item"] * items_per_s / 1e9,
