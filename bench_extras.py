@@ -90,14 +90,20 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
            "verify_8_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs)),
            "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds)),
            # (the comb's table stage makes a proof_gen job longer: it takes 12 in flight to fill the chip where 8 did)
-           "proof_gen_12_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 12, 48)}
+           "proof_gen_12_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 12, 48),
+           # (round 5, profiles/r05_m_other_ops_by_inflight.log: the short jobs of sign and the five-stage jobs of proof_gen fill
+           # the chip at 16 in flight -- sign 8.4 - 9.0 M at 8, 10.0 - 10.2 M at 12, 10.2 - 10.7 M at 16, 9.4 M at 20; proof_gen
+           # 2.45 / 2.73 / 2.80 / 2.45 M at 8 / 12 / 16 / 20; verify is flat from 8: 1.83 / 1.86 / 1.84 M)
+           "sign_16_in_flight": rate_k(lambda: eng.core_sign_upload(msgs), 16, 96),
+           "verify_12_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs), 12, 48),
+           "proof_gen_16_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 16, 64)}
     out["bls12_381"] = bls
     # fraction of roofline of the other three operations (counters: profiles/*_counters.json "ops")
     try:
         import bench as _bench
         counters, counters_file = _bench.load_counters()
         lib_hash = eng.lib.bbs_source_hash().decode()
-        for op, key, k_in in (("sign", "sign_8_in_flight", 8), ("verify", "verify_8_in_flight", 8), ("proof_gen", "proof_gen_12_in_flight", 12)):
+        for op, key, k_in in (("sign", "sign_16_in_flight", 16), ("verify", "verify_12_in_flight", 12), ("proof_gen", "proof_gen_16_in_flight", 16)):
             r = op_roofline(counters, counters_file, lib_hash, op, bls.get(key), k_in)
             if r:
                 out[op] = r
