@@ -416,7 +416,12 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
                     "sign_8_in_flight": rate_k(lambda: eb.core_sign_upload(mb)),
                     "verify_8_in_flight": rate_k(lambda: eb.core_verify_upload(sb, mb)),
                     "proof_gen_8_in_flight": rate_k(lambda: eb.core_proof_gen_upload(sb, mb, db, rb)),
-                    "proof_verify_8_in_flight": rate_k(lambda: eb.core_proof_verify_upload(pb, dmb, db))}
+                    "proof_verify_8_in_flight": rate_k(lambda: eb.core_proof_verify_upload(pb, dmb, db)),
+                    # (profiles/r05_m_other_ops_by_inflight_bn254.log: BN254's shorter jobs fill the chip at 16 in flight)
+                    "sign_16_in_flight": rate_k(lambda: eb.core_sign_upload(mb), 16, 96),
+                    "verify_12_in_flight": rate_k(lambda: eb.core_verify_upload(sb, mb), 12, 48),
+                    "proof_gen_16_in_flight": rate_k(lambda: eb.core_proof_gen_upload(sb, mb, db, rb), 16, 64),
+                    "proof_verify_16_in_flight": rate_k(lambda: eb.core_proof_verify_upload(pb, dmb, db), 16, 64)}
     mj = [eng.core_proof_verify_upload(proofs, dm, disclosed) for _ in range(4)] + \
          [eb.core_proof_verify_upload(pb, dmb, db) for _ in range(4)]
     for j in mj:
