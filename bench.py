@@ -459,9 +459,9 @@ def main():
                             "for 2 cycles (simple VOP2) to ~4 (v_mad_u64_u32, 61 percent of these kernels), but ONE wavefront alone "
                             "issues at most one instruction per 4 - 5 cycles (MI355X_MICROARCH.md:54,473,489; "
                             "profiles/*_ubench_valu_int.csv).  frac = share of the SIMD cycles the step needs to issue its "
-                            "instructions at the costs a wavefront ALONE on its SIMD pays -- what the big kernels run at (pairing 420, "
-                            "doubling chains 292 / 336 registers: one wavefront per SIMD; the fixed-base chunks, a kernel of their own since "
-                            "round 5, 246: two, priced at the two-wavefront cost).  frac_of_multiwave_ceiling prices the SAME instructions at the costs "
+                            "instructions at the costs a wavefront ALONE on its SIMD pays -- what the big kernels run at (pairing 420, the "
+                            "single multiplication 354 registers: one wavefront per SIMD; T1's chain, capped at 256, and the fixed-base "
+                            "chunks, 246, both kernels of their own since round 5: two, priced at the two-wavefront cost).  frac_of_multiwave_ceiling prices the SAME instructions at the costs "
                             "eight co-resident wavefronts see (this instruction mix: %.2f cycles per instruction instead of %.2f): "
                             "the hardware's real ceiling for this mix, which the design cannot reach without fitting 2+ wavefronts "
                             "per SIMD (<= 256 VGPRs, no spills; DESIGN.md 5, profiles/r04_*_occupancy*)" % (
