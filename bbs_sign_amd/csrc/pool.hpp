@@ -241,12 +241,12 @@ inline int pool_proof_verify_submit(bbs_pool* p, const bbs_pv_list* lists, size_
 // blocks until every member has retired its jobs of this list; scatters the sections that carry a global index
 inline int pool_job_wait(bbs_pool_job* j) {
     if (!j) return BBS_E_ARG;
-    {
-        std::unique_lock<std::mutex> lk(j->mu);
-        j->cv.wait(lk, [&]() { return j->members_left == 0; });
-        if (j->scattered) return j->rc;
-        j->scattered = true;
-    }
+    // under the job's lock until the statuses are where the caller reads them: a second thread waiting on the same job returns
+    // only after the first has finished scattering (the members are done with the job by then, nobody else wants the lock)
+    std::unique_lock<std::mutex> lk(j->mu);
+    j->cv.wait(lk, [&]() { return j->members_left == 0; });
+    if (j->scattered) return j->rc;
+    j->scattered = true;
     j->pool->lists_in_flight.fetch_sub(1);
     if (j->rc) return j->rc;                                        // (statuses of the jobs that did deliver are in place; the list failed)
     for (size_t li = 0; li < j->lists.size(); li++)
