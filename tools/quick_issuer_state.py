@@ -1,7 +1,8 @@
 """Does the issuer's rate depend on what the process did before?  (development aid behind bench_extras' issuer legs.)
-Measures the two-length list with 4 lists in flight (tools/quick_issuer.py's leg) in a fresh process, then again after the
-process has had `churn` proof_verify jobs alive at once (each with its three streams) and freed them.
-usage: python tools/quick_issuer_state.py [churn_jobs]"""
+Measures the two-length list (tools/quick_issuer.py's leg) with 2 .. 6 lists in flight while ANOTHER context of the process is
+alive (as the bench's main engine is during bench_extras' issuer legs: its stream sits in front of the jobs' streams in the
+creation-ordered pool, which shifts which job streams share a hardware queue) and again after that context has been closed.
+usage: python tools/quick_issuer_state.py"""
 import os
 import sys
 import time
@@ -9,7 +10,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bbs_sign_amd import workload as pc
 from bbs_sign_amd import Issuer, Job, api as _api
 
-churn = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = 4096
 items = {}
 for L, r in ((32, 8), (16, 4)):
@@ -44,21 +44,9 @@ def leg(tag, k=4):
     print("%-44s %8.0f proof_verify/s" % (tag, 32 * n / (time.perf_counter() - t1)), flush=True)
 
 
-leg("fresh process")
-leg("fresh process (again)")
-js = [eng.core_proof_verify_upload(proofs[:n // 2], dm[:n // 2], disclosed[:n // 2]) for _ in range(churn)]
-for j in js:
-    j.run()
-for j in js:
-    j.wait()
-    j.free()
-leg("after %d jobs alive at once and freed" % churn)
-eng.set_batch_verification(True)
-js = [eng.core_proof_verify_upload(proofs[:n // 2], dm[:n // 2], disclosed[:n // 2]) for _ in range(churn)]
-Job.run_many_timed(js, 2 * churn)
-for j in js:
-    j.free()
-eng.set_batch_verification(False)
-leg("after %d batch-verification jobs as well" % churn)
-iss.close()
+for k in (2, 3, 4, 5, 6):
+    leg("another context alive, %d lists in flight" % k, k)
 eng.close()
+for k in (2, 3, 4, 5, 6):
+    leg("no other context, %d lists in flight" % k, k)
+iss.close()
