@@ -21,6 +21,7 @@ for L, r in ((32, 8), (16, 4)):
     items[L] = ([_api.proof_to_octets("bls12_381", p_) for p_ in pf], raw, d)
     if L == 32:
         keep = (s, e, pf, [x[:r] for x in m], d)
+        churn_items = (m, d, rn, sg)
     else:
         e.close()
 suite, eng, proofs, dm, disclosed = keep
@@ -46,6 +47,20 @@ def leg(tag, k=4):
 
 for k in (2, 3, 4, 5, 6):
     leg("another context alive, %d lists in flight" % k, k)
+if os.environ.get("CHURN"):
+    # what bench_extras does before its issuer legs: many resident jobs of the other operations alive at once, then freed
+    msgs_, disc_, rnds_, sigs_ = churn_items
+    for make, k in ((lambda: eng.core_sign_upload(msgs_), 16), (lambda: eng.core_proof_gen_upload(sigs_, msgs_, disc_, rnds_), 16),
+                    (lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32)):
+        js = [make() for _ in range(k)]
+        for j in js:
+            j.run()
+        for j in js:
+            j.wait()
+        Job.run_many_timed(js, 2 * k)
+        for j in js:
+            j.free()
+        leg("after %d more resident jobs alive at once, 6 lists in flight" % k, 6)
 eng.close()
 for k in (2, 3, 4, 5, 6):
     leg("no other context, %d lists in flight" % k, k)
