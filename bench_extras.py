@@ -81,6 +81,43 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
             j.free()
         return size * steps / dt
 
+    # development aid (BBS_BENCH_ISSUER_PROBE=1): the issuer's two-length list, six lists in flight, measured at several points
+    # of this function -- which leg leaves the state in which the issuer legs further down run at half their stand-alone rate?
+    probe = {"iss": None}
+
+    def issuer_probe(tag):
+        import os as _os
+        if not _os.environ.get("BBS_BENCH_ISSUER_PROBE"):
+            return
+        from bbs_sign_amd import Issuer, api as _api2
+        if probe["iss"] is None:
+            s16, e16, _, _ = pc.bench_engine("bls12_381", 16, None, 16, device=device)
+            m16, d16, r16 = pc.bench_items(s16, e16, n // 2, 16, 4, 0)
+            sg16, _st = e16.core_sign_batch(m16)
+            pf16, _st = e16.core_proof_gen_batch(sg16, m16, d16, r16)
+            e16.close()
+            raw = lambda cnt, r: [[pc.expand_message(b"bbs-bench-msg" + pc.i2osp(b, 8) + pc.i2osp(j, 8), b"BBS_BENCH_MSG_DST_", 32) for j in range(r)] for b in range(cnt)]
+            o32 = [_api2.proof_to_octets("bls12_381", p_) for p_ in proofs[:n // 2]]
+            o16 = [_api2.proof_to_octets("bls12_381", p_) for p_ in pf16]
+            iss = Issuer("bls12_381", suite.api_id, device=device, window_bits=16)
+            iss.set_public_key(eng.public_key())
+            mo = [x for pair in zip(o32, o16) for x in pair]
+            mr = [x for pair in zip(raw(n // 2, R), raw(n // 2, 4)) for x in pair]
+            mi = [x for pair in zip(disclosed[:n // 2], d16) for x in pair]
+            probe["iss"] = (iss,) + tuple(iss.pack_proof_verify(mo, mr, mi))
+            assert (iss.proof_verify_packed(probe["iss"][1], probe["iss"][3]) == 1).all()
+        iss, n_p, keep_p, args_p = probe["iss"]
+        pend = []
+        for phase in (0, 1):
+            t9 = time.perf_counter()
+            for _ in range(32):
+                if len(pend) >= 6:
+                    j = pend.pop(0); j.wait(); j.free()
+                pend.append(iss.proof_verify_submit_packed(n_p, args_p))
+            while pend:
+                j = pend.pop(0); j.wait(); j.free()
+        out.setdefault("issuer_probe", {})[tag] = 32 * n / (time.perf_counter() - t9)
+
     eng.set_latency_mode(False)        # every leg below states its form: throughput unless it says otherwise
     out = {"unit": "items/s; single = one 4096-item resident batch at a time, *_8_in_flight = eight resident batches; jobs in "
                    "the throughput form unless a leg says otherwise"}
@@ -98,6 +135,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
            "verify_12_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs), 12, 48),
            "proof_gen_16_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, disclosed, rnds), 16, 64)}
     out["bls12_381"] = bls
+    issuer_probe("1 after the basic legs (sign / verify / proof_gen, up to 16 in flight)")
     # fraction of roofline of the other three operations (counters: profiles/*_counters.json "ops")
     try:
         import bench as _bench
@@ -124,6 +162,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         sweep["R=%d" % r] = {"proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(pr, dm_r, d_r)),
                              "proof_gen_8_in_flight": rate_k(lambda: eng.core_proof_gen_upload(sigs, msgs, d_r, rn_r))}
     bls["disclosed_sweep_L32"] = sweep
+    issuer_probe("2 after the disclosed sweep")
 
     # ---- window widths of the fixed-base tables (signed digits: 2^(w-1) entries per base and window), the headline's loop on
     # the headline's own packed batches (distinct data in every slot: a 26 GB table is touched at different entries by every
@@ -158,22 +197,28 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
                            "stage_ms": {k: v / 3 for k, v in lst.items()},
                            "proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed))}
     eng.set_latency_mode(False)
+    issuer_probe("3 after the window-width engines (created and closed)")
     # ---- larger batches need fewer batches in flight to fill the chip (one 16384-item batch is 2560 + 1640 wavefronts
     # of the two long kernels on 1024 SIMDs): resident, two and four in flight
     big = (proofs * 4, dm * 4, disclosed * 4)
     bls["batch_16384"] = {"proof_verify_2_in_flight": rate_k(lambda: eng.core_proof_verify_upload(*big), 2, 8),
                           "proof_verify_4_in_flight": rate_k(lambda: eng.core_proof_verify_upload(*big), 4, 12)}
 
+    issuer_probe("4 after the 16384-item jobs")
     # ---- opt-in modes (not the headline): batch verification, subgroup vouching
     eng.set_batch_verification(True)
     bls["proof_verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32, 96)
+    issuer_probe("5a after proof_verify batch verification, 32 jobs in flight")
     bls["proof_verify_batch_verification_16384_items"] = rate_k(
         lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 48)
+    issuer_probe("5b after 16384-item batch-verification jobs, 12 in flight")
     bls["verify_batch_verification_32_in_flight"] = rate_k(lambda: eng.core_verify_upload(sigs, msgs), 32, 96)
+    issuer_probe("5c after verify batch verification, 32 jobs in flight")
     # the same 4096-item jobs retired in completion order, as a serving loop does (round 4): jobs whose tails end early go
     # again at once instead of waiting for an older job (profiles/r04_k_bv_paced.log)
     bls["proof_verify_batch_verification_16_in_flight_completion_order"] = rate_k_any(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 16, 160)
     eng.set_batch_verification(False)
+    issuer_probe("5 after the batch-verification legs (32 jobs in flight)")
     eng.set_points_in_subgroup(True)
     bls["points_in_subgroup"] = {"proof_verify_8_in_flight": rate_k(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed)),
                                  "verify_8_in_flight": rate_k(lambda: eng.core_verify_upload(sigs, msgs)),
@@ -189,6 +234,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
         bls["points_in_subgroup"]["proof_verify_host_inclusive"] = n * 96 / (time.perf_counter() - t0)
         assert bad == 0
     eng.set_points_in_subgroup(False)
+    issuer_probe("6 after the vouched legs")
 
     # ---- ingest of octet strings: 3 n point decompressions + subgroup checks on the device
     import numpy as np
@@ -259,6 +305,7 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
     while pend:
         retire_o()
     bls["proof_verify_wire_raw_messages_host_inclusive"] = 64 * n / (time.perf_counter() - t1)
+    issuer_probe("7 after the wire legs")
 
     # ---- bbs_issuer: ONE call over proofs of two different lengths (half 32 messages / 8 disclosed, half 16 / 4), raw
     # disclosed messages, the library routing the items to the context of their own message count (two groups in flight);

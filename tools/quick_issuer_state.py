@@ -45,14 +45,35 @@ def leg(tag, k=4):
     print("%-44s %8.0f proof_verify/s" % (tag, 32 * n / (time.perf_counter() - t1)), flush=True)
 
 
-for k in (2, 3, 4, 5, 6):
+big = None
+if os.environ.get("BIG"):                        # a third context with 20-bit tables (29.7 GB), as the bench's main engine
+    big = pc.bench_engine("bls12_381", 32, None, 20)[1]
+    leg("a 20-bit context alive as well, 6 lists in flight", 6)
+for k in ((6,) if os.environ.get("BIG") else (2, 3, 4, 5, 6)):
     leg("another context alive, %d lists in flight" % k, k)
+if os.environ.get("WIRE"):                       # bench_extras' wire legs run right before its issuer legs: 8 wire jobs in flight
+    oct32, raw32, d32 = items[32]
+    pend = []
+    for _ in range(32):
+        if len(pend) >= 8:
+            j = pend.pop(0); j.wait(); j.free()
+        pend.append(eng.proof_verify_wire_submit(oct32, raw32, d32))
+    while pend:
+        j = pend.pop(0); j.wait(); j.free()
+    leg("after 32 wire jobs (8 in flight), 6 lists in flight", 6)
 if os.environ.get("CHURN"):
-    # what bench_extras does before its issuer legs: many resident jobs of the other operations alive at once, then freed
+    # what bench_extras does before its issuer legs: many resident jobs of the other operations alive at once, then freed.
+    # CHURN = comma list of kind:jobs, kind in sg, pg, pv, vf, pvbv, vfbv (bv = batch verification on)
     msgs_, disc_, rnds_, sigs_ = churn_items
-    for make, k in ((lambda: eng.core_sign_upload(msgs_), 16), (lambda: eng.core_proof_gen_upload(sigs_, msgs_, disc_, rnds_), 16),
-                    (lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32)):
-        js = [make() for _ in range(k)]
+    eng.set_latency_mode(False)
+    makers = {"sg": lambda: eng.core_sign_upload(msgs_), "pg": lambda: eng.core_proof_gen_upload(sigs_, msgs_, disc_, rnds_),
+              "pv": lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), "vf": lambda: eng.core_verify_upload(sigs_, msgs_)}
+    for spec in os.environ["CHURN"].split(","):
+        kind, k = spec.split(":")
+        k = int(k)
+        bv = kind.endswith("bv")
+        eng.set_batch_verification(bv)
+        js = [makers[kind[:2]]() for _ in range(k)]
         for j in js:
             j.run()
         for j in js:
@@ -60,7 +81,8 @@ if os.environ.get("CHURN"):
         Job.run_many_timed(js, 2 * k)
         for j in js:
             j.free()
-        leg("after %d more resident jobs alive at once, 6 lists in flight" % k, 6)
+        eng.set_batch_verification(False)
+        leg("after %d %s jobs alive at once, 6 lists in flight" % (k, kind), 6)
 eng.close()
 for k in (2, 3, 4, 5, 6):
     leg("no other context, %d lists in flight" % k, k)
