@@ -87,7 +87,13 @@ inline void stream_destroy(Stream& s);
 // 8 GiB per device; larger ones (the window tables) are allocated and freed directly.
 struct Pools {
     std::mutex mu;
-    std::map<int, std::multimap<size_t, void*>> bufs;
+    // a pooled buffer remembers WHEN it came back (`clock`): when the pool is full the buffers that have waited longest -- what
+    // an earlier workload left behind -- make room, never the working set (round 5: evicting by size, smallest first, let
+    // twelve 16384-item jobs' buffers sit in a full pool for ever while a later workload of smaller jobs paid hipMalloc /
+    // hipFree -- a device synchronisation -- on every buffer: the issuer's lists at half their rate)
+    struct Pooled { void* p; uint64_t seq; };
+    uint64_t clock = 0;
+    std::map<int, std::multimap<size_t, Pooled>> bufs;
     std::map<int, size_t> pooled_bytes;
     // streams: handed out in creation order (lowest creation index first), not last-freed-first.  The runtime binds a
     // stream to one of the GPU_MAX_HW_QUEUES hardware queues when it is created, round robin; a job's two streams
@@ -101,8 +107,15 @@ struct Pools {
     std::map<int, std::vector<hipEvent_t>> events;
     // page-locked host staging buffers (one per batch: raw inputs in, statuses out), by size class; hipHostMalloc
     // costs hundreds of microseconds, a batch call must not pay it
-    std::multimap<size_t, void*> pinned;
+    std::multimap<size_t, Pooled> pinned;
     size_t pinned_bytes = 0;
+    // the entry of `m` that has waited longest among the size classes other than `cls` (m.end(): there is none)
+    template <class M> static typename M::iterator oldest_other(M& m, size_t cls) {
+        auto best = m.end();
+        for (auto it = m.begin(); it != m.end(); ++it)
+            if (it->first != cls && (best == m.end() || it->second.seq < best->second.seq)) best = it;
+        return best;
+    }
     std::map<int, std::vector<hipEvent_t>> timing_events;      // events WITH timing (stage timers), recycled
     std::map<int, int> dedicated_made;                         // streams with a hardware queue of their own, per device
     std::map<int, int> pooled_made;                            // streams drawn from the runtime's GPU_MAX_HW_QUEUES pool, per device (alive or recycled here)
@@ -123,7 +136,7 @@ inline int dmalloc(void** p, size_t b) {
         std::lock_guard<std::mutex> g(P.mu);
         auto& m = P.bufs[current_device()];
         auto it = m.find(cls);
-        if (it != m.end()) { *p = it->second; m.erase(it); P.pooled_bytes[current_device()] -= cls; return 0; }
+        if (it != m.end()) { *p = it->second.p; m.erase(it); P.pooled_bytes[current_device()] -= cls; return 0; }
     }
     if (hipMalloc(p, cls) == hipSuccess) return 0;
     (void)hipGetLastError();      // an allocation that failed must not be reported again by the next launch's error check
@@ -134,20 +147,19 @@ inline void dfree(void* p, size_t b, int dev) {        // dev = the device the b
     const size_t cls = size_class(b);
     std::vector<void*> evicted;
     if (cls <= POOL_MAX_BUF) {
-        // as hfree: the size in use now is kept, buffers of other sizes make room when the pool is full
+        // as hfree: the size in use now is kept; when the pool is full, the buffers of other sizes that have waited longest make room
         Pools& P = Pools::get();
         std::lock_guard<std::mutex> g(P.mu);
         auto& m = P.bufs[dev];
         size_t& tot = P.pooled_bytes[dev];
         while (tot + cls > POOL_MAX_TOTAL && !m.empty()) {
-            auto it = m.begin();
-            if (it->first == cls) it = std::prev(m.end());
-            if (it->first == cls) break;
-            evicted.push_back(it->second);
+            auto it = Pools::oldest_other(m, cls);
+            if (it == m.end()) break;                          // only this size is cached: the pool is simply full of it
+            evicted.push_back(it->second.p);
             tot -= it->first;
             m.erase(it);
         }
-        if (tot + cls <= POOL_MAX_TOTAL) { m.emplace(cls, p); tot += cls; p = nullptr; }
+        if (tot + cls <= POOL_MAX_TOTAL) { m.emplace(cls, Pools::Pooled{p, ++P.clock}); tot += cls; p = nullptr; }
     }
     for (void* e : evicted) (void)hipFree(e);
     if (p) (void)hipFree(p);
@@ -181,7 +193,7 @@ inline int hmalloc(void** p, size_t b) {
         Pools& P = Pools::get();
         std::lock_guard<std::mutex> g(P.mu);
         auto it = P.pinned.find(cls);
-        if (it != P.pinned.end()) { *p = it->second; P.pinned.erase(it); P.pinned_bytes -= cls; return 0; }
+        if (it != P.pinned.end()) { *p = it->second.p; P.pinned.erase(it); P.pinned_bytes -= cls; return 0; }
     }
     return hipHostMalloc(p, cls, hipHostMallocPortable) == hipSuccess ? 0 : -1;      // portable: the pool is shared by every device of the process
 }
@@ -196,14 +208,13 @@ inline void hfree(void* p, size_t b) {
         std::lock_guard<std::mutex> g(P.mu);
         if (cls <= PINNED_POOL_MAX) {
             while (P.pinned_bytes + cls > PINNED_POOL_MAX && !P.pinned.empty()) {
-                auto it = P.pinned.begin();
-                if (it->first == cls) it = std::prev(P.pinned.end());
-                if (it->first == cls) break;                   // only this size is cached: the pool is simply full of it
-                evicted.push_back(it->second);
+                auto it = Pools::oldest_other(P.pinned, cls);
+                if (it == P.pinned.end()) break;               // only this size is cached: the pool is simply full of it
+                evicted.push_back(it->second.p);
                 P.pinned_bytes -= it->first;
                 P.pinned.erase(it);
             }
-            if (P.pinned_bytes + cls <= PINNED_POOL_MAX) { P.pinned.emplace(cls, p); P.pinned_bytes += cls; p = nullptr; }
+            if (P.pinned_bytes + cls <= PINNED_POOL_MAX) { P.pinned.emplace(cls, Pools::Pooled{p, ++P.clock}); P.pinned_bytes += cls; p = nullptr; }
         }
     }
     for (void* e : evicted) (void)hipHostFree(e);

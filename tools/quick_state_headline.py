@@ -56,4 +56,12 @@ eng.set_batch_verification(True)
 churn(lambda: eng.core_proof_verify_upload(proofs, dm, disclosed), 32, 64)
 eng.set_batch_verification(False)
 rate("after 32 batch-verification jobs as well")
+eng.set_batch_verification(True)
+churn(lambda: eng.core_proof_verify_upload(proofs * 4, dm * 4, disclosed * 4), 12, 24)
+eng.set_batch_verification(False)
+rate("after 12 batch-verification jobs of 16384 items as well")
+eng.set_batch_verification(True)
+churn(lambda: eng.core_verify_upload(sigs, msgs), 32, 64)
+eng.set_batch_verification(False)
+rate("after 32 batch-verification VERIFY jobs as well")
 eng.close()
