@@ -351,9 +351,10 @@ def other_ops(args, pc, eng, suite, n, L, R, msgs, disclosed, rnds, sigs, proofs
             while pend_i:
                 retire_i()
         bls["issuer_proof_verify_two_lengths_%d_lists_in_flight" % lists] = 32 * n / (time.perf_counter() - t1)
-    bls["issuer_note"] = ("the issuer legs run late in this process and depend on its state (which job streams share a hardware queue after "
-                          "the other legs' jobs: 0.4 - 0.75 M here across runs); the same loop in a process of its own: 1.05 - 1.13 M/s with six "
-                          "lists in flight, 0.92 M with four (tools/quick_issuer_state.py, profiles/r05_r_issuer_lists_in_flight.log)")
+    bls["issuer_note"] = ("lists in flight: four lists are 24 job streams on 20 hardware queues, a pothole (0.73 - 0.92 M stand-alone); six: 1.05 - "
+                          "1.13 M (tools/quick_issuer_state.py, profiles/r05_r_issuer_lists_in_flight.log).  Until the buffer pools evicted by age "
+                          "(round 5) these legs read 0.4 - 0.75 M here: the 16384-item jobs of earlier legs had filled the pools "
+                          "(profiles/r05_x_issuer_probe_inside_bench.log)")
     iss.close()
 
     # ---- the other three operations from HOST buffers through their submit forms, 8 batches in flight, results checked:
